@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""Headline benchmark: ICP scan-match throughput (BASELINE.json metric) on synthetic
+VLP16-shaped clouds, on N MI355X of one node.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = one CloudMatcher::align of one scan against the resident keyframe map
+(<=35 outer iterations of {27-neighbour correspondence search, <=4 LM iterations}).
+N=1 workload = BASELINE.json configs[1] ("C2"): 16 beams x 1800 azimuth steps vs a
+500k-point map, 0.5 m voxels, cap 20.  N>1 = weak scaling: a (16*N)-beam scan in
+firing (azimuth-major) order split into N contiguous index ranges, map replicated,
+one RCCL all-gather of 32 f64 per residual evaluation.
+
+The unit of `value` is one correspondence query (one source point searched against
+its 27 neighbour voxels and reduced into the normal equations), counted over all
+outer iterations and all ranks.  Inputs are resident in HBM before the timed region.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def build_workload(n_gpus, rank):
+    from lidar_odometry_demo_amd import synth
+
+    boxes = synth.make_boxes()
+    n_beams = 16 * n_gpus
+    if n_gpus == 1:
+        scan, ring, az, _ = synth.make_scan(16, 1800, boxes=boxes)
+        shard = scan
+        name = "C2: VLP16 16x1800 scan vs 500k-pt map, voxel 0.5 m, cap 20"
+    else:
+        el = synth.beam_elevations(16)
+        # 16*N beams spanning the VLP16 elevation range, firing (azimuth-major) order
+        saved = synth.beam_elevations
+        synth.beam_elevations = lambda n: np.linspace(el[0], el[-1], n)
+        try:
+            scan, ring, az, _ = synth.make_scan(n_beams, 1800, boxes=boxes)
+        finally:
+            synth.beam_elevations = saved
+        order = np.lexsort((ring, az))
+        scan = scan[order]
+        lo, hi = len(scan) * rank // n_gpus, len(scan) * (rank + 1) // n_gpus
+        shard = np.ascontiguousarray(scan[lo:hi])
+        name = (f"C2 weak-scaled: {n_beams}x1800 scan in {n_gpus} contiguous index ranges "
+                f"vs replicated 500k-pt map, voxel 0.5 m, cap 20")
+    map_xyz, map_nrm = synth.make_map_points(500_000, boxes=boxes)
+    return dict(scan=scan, shard=shard, map_xyz=map_xyz, map_nrm=map_nrm, name=name)
+
+
+def cpu_baseline(work, budget_s=20.0):
+    """The CPU restatement (oracle, kind "port") on the same workload, on this box's host
+    cores: search over all cores, solve single-threaded (mirrors std::execution::par +
+    Ceres num_threads=1).  Bounded sample: whole frames until ~budget_s."""
+    from oracle import oracle as O
+
+    cores = len(os.sched_getaffinity(0))
+    g = O.VoxelGrid(0.5, 20)
+    g.addCloud(work["map_xyz"], work["map_nrm"])
+    m = O.CloudMatcher(nthreads=cores)
+    frames, queries = 0, 0
+    t0 = time.perf_counter()
+    while True:
+        m.align(g, work["scan"], O.Pose3D())
+        frames += 1
+        queries += m.stats["queries"]
+        el = time.perf_counter() - t0
+        if el > budget_s or frames >= 50:
+            break
+    return {"value": queries / el / 1e6, "unit": "Mcorr/s", "cores": cores, "kind": "port",
+            "frames_per_s": frames / el,
+            "sample": f"{frames} full frames of the same workload ({queries} queries, {el:.1f} s); "
+                      "CPU restatement of the reference algorithm (oracle/), not the reference binary"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import lidar_odometry_demo_amd as lom
+
+    n = args.gpus
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if n > 1 and world != n:
+        raise SystemExit(f"--gpus {n} needs WORLD_SIZE={n} (launch with torch.distributed.run); got {world}")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if n > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    work = build_workload(n, rank)
+    grid = lom.VoxelGrid(0.5, 20, device=local_rank)
+    grid.addCloud(work["map_xyz"], work["map_nrm"])
+    grid.setProfiling(True)
+    d_scan = torch.from_numpy(work["shard"]).to(dev)
+    torch.cuda.synchronize()
+
+    if n > 1:
+        import ctypes as C
+
+        ident = torch.zeros(lom.capi.COMM_ID_BYTES, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            buf = C.create_string_buffer(lom.capi.COMM_ID_BYTES)
+            lom.capi.check(lom.capi.lib().lom_comm_unique_id(buf))
+            ident.copy_(torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8))
+        dist.broadcast(ident, 0)
+        lom.capi.check(lom.capi.lib().lom_comm_init(grid.handle, rank, n, bytes(ident.cpu().numpy().tobytes())),
+                       grid.handle)
+
+    matcher = lom.CloudMatcher()
+    guess = lom.Pose3D()
+
+    def step():
+        pose = matcher.alignDevice(grid, d_scan.data_ptr(), d_scan.shape[0], guess)
+        return pose, matcher.stats
+
+    for _ in range(args.warmup):
+        step()
+
+    def fence():
+        torch.cuda.synchronize()
+        if n > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    queries = launches = 0
+    match_ms = eval_ms = alg_bytes = 0.0
+    outer = evals = 0
+    for _ in range(args.steps):
+        pose, st = step()
+        queries += st["queries"]
+        launches += st["match_launches"]
+        match_ms += st["match_kernel_ms"]
+        eval_ms += st["eval_kernel_ms"]
+        alg_bytes += st["algorithmic_bytes"]
+        outer += st["outer_iterations"]
+        evals += st["evaluations"]
+    fence()
+    elapsed = time.perf_counter() - t0
+    if n > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        # stats are global (summed over ranks) after the in-library all-gather
+        value = queries / elapsed / 1e6
+        bytes_per_launch = alg_bytes / max(launches, 1) / n      # per GPU
+        avg_launch_s = match_ms / 1e3 / max(launches, 1)
+        achieved = bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
+        if n == 1 and os.path.exists(tpath):
+            with open(tpath) as f:
+                traffic = json.load(f).get("hbm_bytes_per_launch")
+        line = {
+            "metric": "icp_correspondences_per_sec",
+            "value": value,
+            "unit": "Mcorr/s",
+            "n_gpus": n,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "dtype_note": "f32 distances on f64-transformed queries (search); f64 residuals, Jacobians and solve",
+            "data": "synthetic",
+            "frames_per_s": args.steps / elapsed,
+            "config": {
+                "workload": work["name"],
+                "scan_points_per_gpu": int(d_scan.shape[0]),
+                "scan_points_total": int(len(work["scan"])),
+                "map_points_stored": grid.pointCount(),
+                "map_voxels": grid.size(),
+                "outer_iterations_per_frame": outer / args.steps,
+                "evaluations_per_frame": evals / args.steps,
+                "parallelism": f"source-range x{n}, map replicated" if n > 1 else "single GPU",
+            },
+            "roofline": {
+                "kernel": "k_match (27-neighbour correspondence search)",
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic,
+                "algorithmic_bytes_per_launch": bytes_per_launch,
+                "avg_launch_us": avg_launch_s * 1e6,
+                "launches": launches,
+                "eval_kernel_us_per_evaluation": eval_ms * 1e3 / max(evals, 1),
+                "note": "map (12 MB payload + table) fits the 256 MiB Infinity Cache: algorithmic "
+                        "bytes/time may exceed what HBM itself delivers",
+            },
+        }
+        if n == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(work)
+            line["speedup_vs_cpu_port"] = value / line["cpu_baseline"]["value"]
+        line["pose"] = {"t": [float(v) for v in pose.translation], "q_wxyz": [float(v) for v in pose.rotation]}
+        print(json.dumps(line), flush=True)
+
+    if n > 1:
+        lom.capi.lib().lom_comm_finalize(grid.handle)
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

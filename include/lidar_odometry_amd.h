@@ -1,0 +1,188 @@
+/*
+ * lidar_odometry_amd.h -- C ABI of the MI355X-native scan-matching core.
+ *
+ * Drop-in boundary for the hot path of vovo-4K/lidar_odometry_demo: the
+ * reference's VoxelGrid (src/voxel_grid.h:17-257), VoxelWithPlanes
+ * (src/voxel_with_planes.h:10-36), Pose3D (src/pose_3d.h:10-59) and
+ * CloudMatcher::align (src/cloud_matcher.h:15-16, src/cloud_matcher.cpp:105-178)
+ * are replaced by these entry points; the ROS2 node and LidarOdometry keep
+ * their C++ shape and call through include/lidar_odometry_amd.hpp (a header-only
+ * mirror of the reference classes over this ABI).  See INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++/torch types; never throws.
+ *   - every function returns 0 (LOM_OK) or a negative lom_status; functions
+ *     that return a count return int64 (negative = lom_status).
+ *   - points are 3 consecutive f32 (x,y,z) every `stride_bytes` bytes
+ *     (12 = packed, 16 = pcl::PointXYZ, 48 = pcl::PointNormal with the normal
+ *     at byte offset 16).  Normals use the same stride.
+ *   - poses are f32 {t[3], q[4] = w,x,y,z} like the reference's Pose3D.
+ *   - a handle owns all device memory, one HIP stream and one pinned result
+ *     buffer; it is single-caller (not internally locked).  Independent
+ *     handles may be used from different threads.
+ *   - there is NO CPU fallback: without a gfx950 device lom_map_create fails
+ *     with LOM_ERR_NO_DEVICE.
+ */
+#ifndef LIDAR_ODOMETRY_AMD_H
+#define LIDAR_ODOMETRY_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LOM_ABI_VERSION 1
+
+typedef enum {
+    LOM_OK = 0,
+    LOM_ERR_ARG = -1,       /* null/invalid argument                               */
+    LOM_ERR_OOM = -2,       /* host or device allocation failed                    */
+    LOM_ERR_RANGE = -3,     /* |coordinate / voxel_size| >= 2^20 or non-finite      */
+    LOM_ERR_HIP = -4,       /* HIP runtime error, text via lom_last_error()        */
+    LOM_ERR_NO_DEVICE = -5, /* no usable gfx950 device                             */
+    LOM_ERR_COMM = -6,      /* RCCL error                                          */
+    LOM_ERR_STATE = -7,     /* call not valid in this state                        */
+    LOM_ERR_HOOK = -8       /* a user hook returned non-zero                       */
+} lom_status;
+
+int lom_abi_version(void);
+/* number of visible HIP devices (0 when none; never initialises a context) */
+int lom_device_count(void);
+
+/* ---- Pose3D (src/pose_3d.h:10-59), f32 ---------------------------------- */
+typedef struct {
+    float t[3];
+    float q[4]; /* w, x, y, z */
+} lom_pose;
+
+void lom_pose_identity(lom_pose *out);                                         /* pose_3d.h:15-18 */
+void lom_pose_compose(const lom_pose *a, const lom_pose *b, lom_pose *out);    /* :29-32 */
+void lom_pose_inverse(const lom_pose *a, lom_pose *out);                       /* :34-39 */
+void lom_pose_relative_to(const lom_pose *a, const lom_pose *target, lom_pose *out); /* :23-27 */
+void lom_pose_rotation_matrix(const lom_pose *a, float R_rowmajor[9]);         /* :41-43 */
+/* CloudTransformer::transform / transformWithNormals (src/utils/cloud_transform.h:43-97),
+ * host-side f32; nrm_in/nrm_out may be NULL. */
+int lom_transform_points(const lom_pose *pose, const float *xyz_in, const float *nrm_in, size_t n,
+                         size_t stride_bytes_in, float *xyz_out, float *nrm_out,
+                         size_t stride_bytes_out);
+
+/* ---- VoxelGrid (src/voxel_grid.h:17-257) -------------------------------- */
+typedef struct lom_map lom_map;
+
+/* VoxelGrid(float voxel_size, size_t max_points), voxel_grid.h:48-52.
+ * capacity_hint = expected number of voxels (0 = default); device = HIP device index. */
+int lom_map_create(float voxel_size, size_t max_points, size_t capacity_hint, int device,
+                   lom_map **out);
+void lom_map_destroy(lom_map *m);
+const char *lom_last_error(const lom_map *m); /* NULL handle: error of the last failed create */
+
+int lom_map_clear(lom_map *m, float voxel_size);            /* setVoxelSize, :61-66 (clears) */
+int lom_map_set_max_points(lom_map *m, size_t max_points);  /* setMaxPoints, :56-59; only while empty */
+/* addCloud (:77-93) when nrm != NULL, addCloudWithoutNormals (:95-110) when nrm == NULL.
+ * Deterministic: a voxel keeps the first max_points points in call/input order. */
+int lom_map_add_points(lom_map *m, const float *xyz, const float *nrm, size_t n, size_t stride_bytes);
+/* same with device-resident input (pointers valid on the handle's device) */
+int lom_map_add_points_device(lom_map *m, const float *d_xyz, const float *d_nrm, size_t n,
+                              size_t stride_bytes);
+int lom_map_radius_cleanup(lom_map *m, const float center[3], float radius); /* :236-246 */
+int64_t lom_map_size(const lom_map *m);        /* number of voxels, :248-251 */
+int64_t lom_map_point_count(const lom_map *m); /* number of stored points */
+
+typedef enum {
+    LOM_EXPORT_FULL = 0,            /* getCloud, :112-130                       */
+    LOM_EXPORT_FULL_NO_NORMALS = 1, /* getCloudWithoutNormals, :133-147         */
+    LOM_EXPORT_FIRST_PER_VOXEL = 2  /* getSparseCloudWithoutNormals, :150-162   */
+} lom_export_mode;
+/* Packed (12-byte) host output in voxel creation order, insertion order inside a
+ * voxel.  Returns the number of points the export holds; writes at most `cap`.
+ * xyz_out / nrm_out may be NULL (count only). */
+int64_t lom_map_export(lom_map *m, int mode, float *xyz_out, float *nrm_out, size_t cap);
+
+/* ---- getCorrespondence / findMatchingPairs (voxel_grid.h:164-234) -------- */
+typedef struct {
+    int64_t index;   /* voxel_creation_index * max_points + in_voxel_index, or -1 */
+    float origin[3]; /* Correspondence::plane_origin  */
+    float normal[3]; /* Correspondence::plane_normal  */
+    float sq_dist;   /* f32 squared distance to the winner (0 if none) */
+    uint32_t n_cand; /* stored points scanned for this query */
+    uint32_t n_occ;  /* occupied voxels among the 27 neighbours */
+} lom_correspondence;
+
+/* Deterministic findMatchingPairs: one entry per source point, in source order
+ * (the reference's push order under its mutex is nondeterministic).  Returns the
+ * number of valid correspondences. */
+int64_t lom_match_find_pairs(lom_map *m, const float *src_xyz, size_t n, size_t stride_bytes,
+                             const float t[3], const float q_wxyz[4], float max_dist,
+                             lom_correspondence *out);
+
+/* ---- CloudMatcher::align (src/cloud_matcher.cpp:105-178) ---------------- */
+/* Reduced normal equations produced per evaluation (f64):
+ * [0..20] upper triangle (row-major, a<=b) of sum w J J^T, tangent order
+ * rotation(3), translation(3); [21..26] sum w J r; [27] sum 0.5*rho(r^2);
+ * [28] valid correspondences; [29] stored points scanned; [30] occupied
+ * neighbour voxels; [31] source points searched.  The translation prior is NOT
+ * included. */
+#define LOM_NSUMS 32
+
+typedef struct {
+    int32_t outer_iterations;  /* executed outer iterations (<=35)                  */
+    int32_t lm_iterations;     /* recorded LM iterations incl. iteration 0, total   */
+    int32_t evaluations;       /* residual evaluations, total                       */
+    int32_t match_launches;    /* correspondence-kernel launches (= outer its)      */
+    int64_t queries;           /* source points x outer iterations (this rank)      */
+    int64_t valid_last;        /* valid correspondences of the last outer iteration */
+    int64_t cand_total;        /* stored points scanned, all outer iterations       */
+    int64_t occ_total;         /* occupied neighbour voxels, all outer iterations   */
+    double final_cost;
+    double last_step_norm;
+    double match_kernel_ms;    /* HIP-event time of the correspondence launches (profiling on) */
+    double eval_kernel_ms;     /* HIP-event time of the evaluation launches (profiling on)     */
+    double algorithmic_bytes;  /* sum over queries of 444 + 12*cand + 12*valid     */
+} lom_align_stats;
+
+int lom_match_align(lom_map *m, const float *src_xyz, size_t n, size_t stride_bytes,
+                    const float guess_t[3], const float guess_q_wxyz[4], float out_t[3],
+                    float out_q_wxyz[4], lom_align_stats *stats_or_null);
+/* same, source cloud already resident on the handle's device */
+int lom_match_align_device(lom_map *m, const float *d_src_xyz, size_t n, size_t stride_bytes,
+                           const float guess_t[3], const float guess_q_wxyz[4], float out_t[3],
+                           float out_q_wxyz[4], lom_align_stats *stats_or_null);
+
+/* record HIP events around the kernels of lom_match_align* (stats->*_kernel_ms) */
+int lom_map_set_profiling(lom_map *m, int enabled);
+/* run the handle's work on a caller-owned hipStream_t (NULL = handle's own stream) */
+int lom_map_set_stream(lom_map *m, void *hip_stream);
+
+/* ---- multi-GPU: source points range-sharded, map replicated ------------- */
+/* One all-gather of LOM_NSUMS f64 per residual evaluation over RCCL, summed in
+ * rank order on every rank (results independent of the collective's tree). */
+#define LOM_COMM_ID_BYTES 128
+int lom_comm_unique_id(char id_out[LOM_COMM_ID_BYTES]);   /* rank 0: ncclGetUniqueId */
+int lom_comm_init(lom_map *m, int rank, int nranks, const char id[LOM_COMM_ID_BYTES]);
+int lom_comm_finalize(lom_map *m);
+
+/* ---- host-side align driver over user evaluators ------------------------ */
+/* lom_match_align* = this driver over the HIP kernels.  Exposed so that the
+ * driver (outer loop, LM policy, reduction order) can be exercised with other
+ * evaluators and collectives, e.g. world_size-2 gloo tests on CPU. */
+typedef struct {
+    void *user;
+    /* new correspondences at the f32 pose, then sums at (q,t) (f64, = widened pose) */
+    int (*match_eval)(void *user, const float pose_t[3], const float pose_q[4], const double q[4],
+                      const double t[3], double out[LOM_NSUMS]);
+    /* sums at (q,t) for the correspondences of the last match_eval */
+    int (*eval_fixed)(void *user, const double q[4], const double t[3], double out[LOM_NSUMS]);
+    /* optional: in-place sum over ranks of buf[count]; NULL = single rank */
+    int (*allreduce)(void *user, double *buf, int count);
+} lom_align_hooks;
+
+int lom_align_with_hooks(const lom_align_hooks *hooks, const float guess_t[3],
+                         const float guess_q_wxyz[4], float out_t[3], float out_q_wxyz[4],
+                         lom_align_stats *stats_or_null);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LIDAR_ODOMETRY_AMD_H */

@@ -1,0 +1,197 @@
+"""MI355X-native scan-matching core behind the reference's VoxelGrid /
+CloudMatcher / Pose3D interface (vovo-4K/lidar_odometry_demo:
+src/voxel_grid.h, src/cloud_matcher.h, src/pose_3d.h).
+
+Python mirror of the reference classes over the C ABI of
+include/lidar_odometry_amd.h -- same names, argument meaning and error
+behaviour, so parity tests read like the reference's own tests.  All compute
+runs in the HIP library; there is no CPU path in this package.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .capi import LomError  # noqa: F401
+
+__all__ = ["Pose3D", "VoxelGrid", "CloudMatcher", "transform_points", "LomError", "capi"]
+
+
+class Pose3D:
+    """reference src/pose_3d.h:10-59 (f32 translation + wxyz quaternion)."""
+
+    def __init__(self, translation=(0, 0, 0), rotation_wxyz=(1, 0, 0, 0)):
+        self.translation = np.asarray(translation, dtype=np.float32).copy()
+        self.rotation = np.asarray(rotation_wxyz, dtype=np.float32).copy()
+
+    def _c(self):
+        return capi.Pose(capi.f3(self.translation), capi.f4(self.rotation))
+
+    @staticmethod
+    def _from(c):
+        return Pose3D(np.array(c.t[:], np.float32), np.array(c.q[:], np.float32))
+
+    def compose(self, another):          # pose_3d.h:29-32
+        o = capi.Pose()
+        capi.lib().lom_pose_compose(C.byref(self._c()), C.byref(another._c()), C.byref(o))
+        return Pose3D._from(o)
+
+    def inverse(self):                   # pose_3d.h:34-39
+        o = capi.Pose()
+        capi.lib().lom_pose_inverse(C.byref(self._c()), C.byref(o))
+        return Pose3D._from(o)
+
+    def relativeTo(self, target):        # pose_3d.h:23-27
+        o = capi.Pose()
+        capi.lib().lom_pose_relative_to(C.byref(self._c()), C.byref(target._c()), C.byref(o))
+        return Pose3D._from(o)
+
+    def rotationMatrix(self):            # pose_3d.h:41-43
+        R = (C.c_float * 9)()
+        capi.lib().lom_pose_rotation_matrix(C.byref(self._c()), R)
+        return np.array(R[:], np.float32).reshape(3, 3)
+
+    def __repr__(self):
+        return f"Pose3D(t={self.translation.tolist()}, q_wxyz={self.rotation.tolist()})"
+
+
+def transform_points(pose, xyz, normals=None):
+    """CloudTransformer::transform / transformWithNormals (src/utils/cloud_transform.h:43-97)."""
+    xyz = capi.xyz_array(xyz)
+    out = np.empty_like(xyz)
+    nout = None
+    if normals is not None:
+        normals = capi.xyz_array(normals)
+        nout = np.empty_like(normals)
+    capi.check(capi.lib().lom_transform_points(
+        C.byref(pose._c()), xyz.ctypes.data, normals.ctypes.data if normals is not None else None,
+        len(xyz), 12, out.ctypes.data, nout.ctypes.data if normals is not None else None, 12))
+    return (out, nout) if normals is not None else out
+
+
+class VoxelGrid:
+    """reference src/voxel_grid.h:17-257, device-resident."""
+
+    def __init__(self, voxel_size=0.5, max_points=10, capacity_hint=0, device=0):
+        h = C.c_void_p()
+        rc = capi.lib().lom_map_create(float(voxel_size), int(max_points), int(capacity_hint), int(device),
+                                       C.byref(h))
+        if rc != 0:
+            capi.check(rc, None)
+        self._h = h
+        self.max_points = int(max_points)
+        self.device = int(device)
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            capi.lib().lom_map_destroy(h)
+            self._h = None
+
+    close = __del__
+
+    @property
+    def handle(self):
+        return self._h
+
+    def setMaxPoints(self, max_points):                    # voxel_grid.h:56-59
+        capi.check(capi.lib().lom_map_set_max_points(self._h, int(max_points)), self._h)
+        self.max_points = int(max_points)
+
+    def setVoxelSize(self, voxel_size):                    # voxel_grid.h:61-66 (clears)
+        capi.check(capi.lib().lom_map_clear(self._h, float(voxel_size)), self._h)
+
+    def addCloud(self, xyz, normals):                      # voxel_grid.h:77-93
+        xyz, normals = capi.xyz_array(xyz), capi.xyz_array(normals)
+        if len(xyz) != len(normals):
+            raise ValueError("xyz and normals differ in length")
+        capi.check(capi.lib().lom_map_add_points(self._h, xyz.ctypes.data, normals.ctypes.data, len(xyz), 12),
+                   self._h)
+
+    def addCloudInterleaved(self, records, stride_bytes, normal_offset_bytes=None):
+        """pcl-style records (e.g. 48-byte PointNormal: xyz at 0, normal at 16) without repacking."""
+        buf = np.ascontiguousarray(records)
+        n = buf.nbytes // stride_bytes
+        base = buf.ctypes.data
+        nrm = base + normal_offset_bytes if normal_offset_bytes is not None else None
+        capi.check(capi.lib().lom_map_add_points(self._h, base, nrm, n, stride_bytes), self._h)
+
+    def addCloudWithoutNormals(self, xyz):                 # voxel_grid.h:95-110
+        xyz = capi.xyz_array(xyz)
+        capi.check(capi.lib().lom_map_add_points(self._h, xyz.ctypes.data, None, len(xyz), 12), self._h)
+
+    def addCloudDevice(self, d_xyz_ptr, d_nrm_ptr, n, stride_bytes=12):
+        capi.check(capi.lib().lom_map_add_points_device(self._h, d_xyz_ptr, d_nrm_ptr, int(n), int(stride_bytes)),
+                   self._h)
+
+    def size(self):                                        # voxel_grid.h:248-251
+        return int(capi.check(capi.lib().lom_map_size(self._h), self._h))
+
+    def pointCount(self):
+        return int(capi.check(capi.lib().lom_map_point_count(self._h), self._h))
+
+    def _export(self, mode, want_normals):
+        n = capi.check(capi.lib().lom_map_export(self._h, mode, None, None, 0), self._h)
+        xyz = np.empty((n, 3), np.float32)
+        nrm = np.empty((n, 3), np.float32) if want_normals else None
+        if n:
+            capi.check(capi.lib().lom_map_export(self._h, mode, xyz.ctypes.data,
+                                                 nrm.ctypes.data if want_normals else None, n), self._h)
+        return xyz, nrm
+
+    def getCloud(self):                                    # voxel_grid.h:112-130
+        return self._export(capi.EXPORT_FULL, True)
+
+    def getCloudWithoutNormals(self):                      # voxel_grid.h:133-147
+        return self._export(capi.EXPORT_FULL_NO_NORMALS, False)[0]
+
+    def getSparseCloudWithoutNormals(self):                # voxel_grid.h:150-162
+        return self._export(capi.EXPORT_FIRST_PER_VOXEL, False)[0]
+
+    def radiusCleanup(self, point, radius):                # voxel_grid.h:236-246
+        capi.check(capi.lib().lom_map_radius_cleanup(self._h, capi.f3(point), float(radius)), self._h)
+
+    def findMatchingPairs(self, xyz, transform, max_correspondence_distance=0.3):
+        """voxel_grid.h:206-234; one entry per source point in source order (index < 0: no match)."""
+        xyz = capi.xyz_array(xyz)
+        out = np.zeros(len(xyz), capi.CORR_DTYPE)
+        capi.check(capi.lib().lom_match_find_pairs(
+            self._h, xyz.ctypes.data, len(xyz), 12, capi.f3(transform.translation), capi.f4(transform.rotation),
+            float(max_correspondence_distance), out.ctypes.data), self._h)
+        return out
+
+    def getCorrespondence(self, query, max_correspondence_distance_sq):
+        """voxel_grid.h:164-204 for a single already-transformed f32 query point."""
+        d = float(np.sqrt(np.float32(max_correspondence_distance_sq)))
+        c = self.findMatchingPairs(np.asarray(query, np.float32).reshape(1, 3), Pose3D(), d)
+        return c[0]
+
+    def setProfiling(self, on):
+        capi.check(capi.lib().lom_map_set_profiling(self._h, 1 if on else 0), self._h)
+
+
+class CloudMatcher:
+    """reference src/cloud_matcher.h:13-17 / src/cloud_matcher.cpp:105-178."""
+
+    def __init__(self):
+        self.stats = None
+
+    def align(self, keyframe, planar_cloud, position_guess):
+        xyz = capi.xyz_array(planar_cloud)
+        ot, oq = (C.c_float * 3)(), (C.c_float * 4)()
+        st = capi.AlignStats()
+        capi.check(capi.lib().lom_match_align(
+            keyframe.handle, xyz.ctypes.data, len(xyz), 12, capi.f3(position_guess.translation),
+            capi.f4(position_guess.rotation), ot, oq, C.byref(st)), keyframe.handle)
+        self.stats = st.asdict()
+        return Pose3D(np.array(ot[:], np.float32), np.array(oq[:], np.float32))
+
+    def alignDevice(self, keyframe, d_src_ptr, n, position_guess, stride_bytes=12):
+        """Source cloud already resident in HBM (device pointer, e.g. torch tensor.data_ptr())."""
+        ot, oq = (C.c_float * 3)(), (C.c_float * 4)()
+        st = capi.AlignStats()
+        capi.check(capi.lib().lom_match_align_device(
+            keyframe.handle, d_src_ptr, int(n), int(stride_bytes), capi.f3(position_guess.translation),
+            capi.f4(position_guess.rotation), ot, oq, C.byref(st)), keyframe.handle)
+        self.stats = st.asdict()
+        return Pose3D(np.array(ot[:], np.float32), np.array(oq[:], np.float32))

@@ -1,0 +1,175 @@
+"""ctypes binding of liblidar_odometry_amd.so (include/lidar_odometry_amd.h).
+
+There is no fallback: if the HIP library is missing this module raises, and
+without a gfx950 device every map constructor fails with LOM_ERR_NO_DEVICE.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblidar_odometry_amd.so")
+NSUMS = 32
+COMM_ID_BYTES = 128
+
+OK, ERR_ARG, ERR_OOM, ERR_RANGE, ERR_HIP, ERR_NO_DEVICE, ERR_COMM, ERR_STATE, ERR_HOOK = (
+    0, -1, -2, -3, -4, -5, -6, -7, -8)
+_ERR_NAMES = {ERR_ARG: "LOM_ERR_ARG", ERR_OOM: "LOM_ERR_OOM", ERR_RANGE: "LOM_ERR_RANGE",
+              ERR_HIP: "LOM_ERR_HIP", ERR_NO_DEVICE: "LOM_ERR_NO_DEVICE", ERR_COMM: "LOM_ERR_COMM",
+              ERR_STATE: "LOM_ERR_STATE", ERR_HOOK: "LOM_ERR_HOOK"}
+
+EXPORT_FULL, EXPORT_FULL_NO_NORMALS, EXPORT_FIRST_PER_VOXEL = 0, 1, 2
+
+
+class LomError(RuntimeError):
+    def __init__(self, code, text=""):
+        self.code = code
+        super().__init__(f"{_ERR_NAMES.get(code, code)}: {text}")
+
+
+class Pose(C.Structure):
+    _fields_ = [("t", C.c_float * 3), ("q", C.c_float * 4)]
+
+
+class Correspondence(C.Structure):
+    _fields_ = [("index", C.c_int64), ("origin", C.c_float * 3), ("normal", C.c_float * 3),
+                ("sq_dist", C.c_float), ("n_cand", C.c_uint32), ("n_occ", C.c_uint32)]
+
+
+CORR_DTYPE = np.dtype(
+    [("index", "<i8"), ("origin", "<f4", 3), ("normal", "<f4", 3), ("sq_dist", "<f4"),
+     ("n_cand", "<u4"), ("n_occ", "<u4")], align=True)
+
+
+class AlignStats(C.Structure):
+    _fields_ = [
+        ("outer_iterations", C.c_int32), ("lm_iterations", C.c_int32), ("evaluations", C.c_int32),
+        ("match_launches", C.c_int32), ("queries", C.c_int64), ("valid_last", C.c_int64),
+        ("cand_total", C.c_int64), ("occ_total", C.c_int64), ("final_cost", C.c_double),
+        ("last_step_norm", C.c_double), ("match_kernel_ms", C.c_double), ("eval_kernel_ms", C.c_double),
+        ("algorithmic_bytes", C.c_double),
+    ]
+
+    def asdict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+MATCH_EVAL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float),
+                            C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double))
+EVAL_FIXED_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                            C.POINTER(C.c_double))
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int)
+
+
+class AlignHooks(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("match_eval", MATCH_EVAL_FN), ("eval_fixed", EVAL_FIXED_FN),
+                ("allreduce", ALLREDUCE_FN)]
+
+
+# every symbol include/lidar_odometry_amd.h declares
+EXPORTED = [
+    "lom_abi_version", "lom_device_count", "lom_pose_identity", "lom_pose_compose", "lom_pose_inverse",
+    "lom_pose_relative_to", "lom_pose_rotation_matrix", "lom_transform_points", "lom_map_create",
+    "lom_map_destroy", "lom_last_error", "lom_map_clear", "lom_map_set_max_points", "lom_map_add_points",
+    "lom_map_add_points_device", "lom_map_radius_cleanup", "lom_map_size", "lom_map_point_count",
+    "lom_map_export", "lom_match_find_pairs", "lom_match_align", "lom_match_align_device",
+    "lom_map_set_profiling", "lom_map_set_stream", "lom_comm_unique_id", "lom_comm_init",
+    "lom_comm_finalize", "lom_align_with_hooks",
+]
+
+_lib = None
+
+
+def _share_hip_runtime_with_torch():
+    """A PyTorch-ROCm wheel bundles its own libamdhip64.so / libhsa-runtime64.so (same
+    SONAME as /opt/rocm's).  Two HSA runtimes in one process cannot both own the GPU
+    ("No HIP GPUs are available" in whichever comes second), so when such a wheel is
+    installed its copy is loaded first and this library binds to it by SONAME.  torch
+    itself is not imported."""
+    import importlib.util
+    import sys
+
+    if "torch" in sys.modules:
+        return  # torch's runtime is already resident; ours will resolve to it
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
+def lib():
+    """Loads the HIP library; raises (loudly) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C lidar_odometry_demo_amd/csrc`.  There is no CPU fallback.")
+    _share_hip_runtime_with_torch()
+    L = C.CDLL(LIB_PATH)
+    fp, dp, pp, vp = C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(Pose), C.c_void_p
+    L.lom_abi_version.restype = C.c_int
+    L.lom_device_count.restype = C.c_int
+    L.lom_pose_identity.argtypes = [pp]
+    L.lom_pose_compose.argtypes = [pp, pp, pp]
+    L.lom_pose_inverse.argtypes = [pp, pp]
+    L.lom_pose_relative_to.argtypes = [pp, pp, pp]
+    L.lom_pose_rotation_matrix.argtypes = [pp, fp]
+    L.lom_transform_points.argtypes = [pp, vp, vp, C.c_size_t, C.c_size_t, vp, vp, C.c_size_t]
+    L.lom_map_create.argtypes = [C.c_float, C.c_size_t, C.c_size_t, C.c_int, C.POINTER(vp)]
+    L.lom_map_destroy.argtypes = [vp]
+    L.lom_map_destroy.restype = None
+    L.lom_last_error.argtypes = [vp]
+    L.lom_last_error.restype = C.c_char_p
+    L.lom_map_clear.argtypes = [vp, C.c_float]
+    L.lom_map_set_max_points.argtypes = [vp, C.c_size_t]
+    L.lom_map_add_points.argtypes = [vp, vp, vp, C.c_size_t, C.c_size_t]
+    L.lom_map_add_points_device.argtypes = [vp, vp, vp, C.c_size_t, C.c_size_t]
+    L.lom_map_radius_cleanup.argtypes = [vp, fp, C.c_float]
+    L.lom_map_size.argtypes = [vp]
+    L.lom_map_size.restype = C.c_int64
+    L.lom_map_point_count.argtypes = [vp]
+    L.lom_map_point_count.restype = C.c_int64
+    L.lom_map_export.argtypes = [vp, C.c_int, vp, vp, C.c_size_t]
+    L.lom_map_export.restype = C.c_int64
+    L.lom_match_find_pairs.argtypes = [vp, vp, C.c_size_t, C.c_size_t, fp, fp, C.c_float, vp]
+    L.lom_match_find_pairs.restype = C.c_int64
+    L.lom_match_align.argtypes = [vp, vp, C.c_size_t, C.c_size_t, fp, fp, fp, fp, C.POINTER(AlignStats)]
+    L.lom_match_align_device.argtypes = L.lom_match_align.argtypes
+    L.lom_map_set_profiling.argtypes = [vp, C.c_int]
+    L.lom_map_set_stream.argtypes = [vp, vp]
+    L.lom_comm_unique_id.argtypes = [C.c_char_p]
+    L.lom_comm_init.argtypes = [vp, C.c_int, C.c_int, C.c_char_p]
+    L.lom_comm_finalize.argtypes = [vp]
+    L.lom_align_with_hooks.argtypes = [C.POINTER(AlignHooks), fp, fp, fp, fp, C.POINTER(AlignStats)]
+    _lib = L
+    return L
+
+
+def f3(a):
+    return (C.c_float * 3)(*[float(v) for v in a])
+
+
+def f4(a):
+    return (C.c_float * 4)(*[float(v) for v in a])
+
+
+def xyz_array(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if a.ndim != 2 or a.shape[1] != 3:
+        raise ValueError("expected an (n, 3) float32 array")
+    return a
+
+
+def check(rc, handle=None):
+    if rc < 0:
+        text = lib().lom_last_error(handle)
+        raise LomError(int(rc), text.decode() if text else "")
+    return rc

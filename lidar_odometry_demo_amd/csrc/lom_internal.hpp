@@ -1,0 +1,140 @@
+// Internal declarations shared by the HIP translation units.  gfx950 only.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+
+#include "../../include/lidar_odometry_amd.h"
+
+namespace lom {
+
+// ---- open-addressed voxel hash in HBM ---------------------------------------
+// One 16-byte slot per probe: a single dwordx4 load yields key, point count
+// and payload slab (reference: robin_map<Indices, VoxelWithPlanes>,
+// src/voxel_grid.h:256).  Payload lives in slabs [slab][K] of packed 12-byte
+// points and, separately, 12-byte normals (normals are read once per query,
+// for the winner only, so they stay out of the candidate stream).
+struct __attribute__((aligned(16))) Slot {
+    unsigned long long key;  // packed (ix,iy,iz), 21 bits each, biased; kEmptyKey = free
+    uint32_t count;          // stored points (<= K)
+    uint32_t slab;           // creation index of the voxel; kNoSlab until assigned
+};
+static_assert(sizeof(Slot) == 16, "slot must be one dwordx4");
+
+constexpr unsigned long long kEmptyKey = ~0ull;
+constexpr uint32_t kNoSlab = 0xFFFFFFFFu;
+constexpr int kIdxBias = 1 << 20;          // indices in (-2^20, 2^20)
+constexpr float kIdxLimit = 1048576.0f;    // |x / voxel_size| must stay below
+
+__host__ __device__ inline unsigned long long pack_key(int ix, int iy, int iz)
+{
+    return ((unsigned long long)(uint32_t)(ix + kIdxBias) << 42) |
+           ((unsigned long long)(uint32_t)(iy + kIdxBias) << 21) |
+           (unsigned long long)(uint32_t)(iz + kIdxBias);
+}
+
+// Fibonacci hashing: top log2(cap) bits of key * 2^64/phi.  The hash never
+// influences results (reference IndicesHash, voxel_grid.h:31-38, likewise).
+__host__ __device__ inline uint32_t hash_key(unsigned long long key, uint32_t shift)
+{
+    return (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> shift);
+}
+
+// voxel_grid.h:70-72 / :166-168: static_cast<int64_t>(x / voxel_size_), f32
+// division (correctly rounded), truncation toward zero.
+__device__ inline bool voxel_index(float x, float voxel_size, int &out)
+{
+    const float f = __fdiv_rn(x, voxel_size);
+    if (!(f > -kIdxLimit && f < kIdxLimit)) return false;  // also NaN
+    out = (int)f;
+    return true;
+}
+
+struct MapView {
+    const Slot *table;
+    uint32_t mask;   // capacity - 1
+    uint32_t shift;  // 64 - log2(capacity)
+    const float *pts;  // [slab][K][3]
+    const float *nrm;  // [slab][K][3]
+    uint32_t K;
+    float voxel_size;
+};
+
+// pose as the kernels consume it
+struct PoseArgs {
+    double R[9];  // f32 rotationMatrix() widened (voxel_grid.h:212)
+    double t[3];  // f32 translation widened (voxel_grid.h:213)
+    float max_sq; // max_correspondence_distance^2 in f32 (voxel_grid.h:215)
+};
+
+struct EvalArgs {
+    double q[4];  // w,x,y,z
+    double t[3];
+};
+
+// ---- host-side handle ---------------------------------------------------------
+struct DeviceBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+};
+
+}  // namespace lom
+
+struct lom_map {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    float voxel_size = 0.5f;
+    uint32_t K = 10;
+
+    // hash table
+    lom::Slot *d_table = nullptr;
+    uint32_t cap = 0;  // power of two
+    uint32_t min_cap = 0;
+
+    // slabs (creation order)
+    uint32_t n_vox = 0;
+    uint32_t slab_cap = 0;
+    unsigned long long *d_slab_key = nullptr;  // [slab_cap]
+    uint32_t *d_slab_count = nullptr;          // [slab_cap]
+    float *d_pts = nullptr;                    // [slab_cap][K][3]
+    float *d_nrm = nullptr;                    // [slab_cap][K][3]
+    uint64_t n_points = 0;
+
+    // scratch (grown on demand, never shrunk)
+    lom::DeviceBuf scr[12];
+    // per-scan buffers of align/find_pairs
+    lom::DeviceBuf scan_src, scan_idx, scan_on, scan_stats, partials, results;
+
+    // pinned host result buffer
+    double *h_results = nullptr;  // 64 doubles
+    uint32_t *h_flags = nullptr;  // 16 words
+
+    bool profiling = false;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+
+    // RCCL
+    void *comm = nullptr;
+    int rank = 0, nranks = 1;
+    lom::DeviceBuf gather;
+
+    std::string last_error;
+};
+
+namespace lom {
+
+int set_error(lom_map *m, int code, const char *what, hipError_t e = hipSuccess);
+int ensure(lom_map *m, DeviceBuf &b, size_t bytes);  // grow-only device buffer
+MapView view_of(const lom_map *m);
+
+#define LOM_HIP(m, expr)                                                        \
+    do {                                                                        \
+        hipError_t _e = (expr);                                                 \
+        if (_e != hipSuccess) return lom::set_error((m), LOM_ERR_HIP, #expr, _e); \
+    } while (0)
+
+// RCCL (comm.cpp), loaded lazily with dlopen
+int comm_allgather_sums(lom_map *m, const double *d_send, double *d_recv, int count);
+
+}  // namespace lom

@@ -1,0 +1,522 @@
+// Scan-matching kernels: the MI355X counterpart of
+//   VoxelGrid::getCorrespondence / findMatchingPairs  (src/voxel_grid.h:164-234)
+//   PointToPlaneErrorAnalytic::Evaluate               (src/cloud_matcher.cpp:38-103)
+// plus the reduction of the robustified normal equations that Ceres performs
+// inside ceres::Solve (DENSE_QR) for the reference.
+//
+//   k_match   per source point: f64 transform -> f32 query -> 27-neighbour
+//             voxel lookup -> nearest stored point (strict-min, scan order
+//             ix,iy,iz then insertion order) -> winner's point+normal.
+//             HBM/L2-bound gather; no MFMA (nothing here is a contraction).
+//   k_eval    per valid correspondence: r = (q*p + t - o).n, 1x6 tangent
+//             Jacobian, Huber(0.15) IRLS weight; f64 wave reduction of
+//             sum w J J^T (21), sum w J r (6), sum 0.5 rho (1) -> one partial
+//             per workgroup.
+//   k_finish  fixed-order sum of the partials -> LOM_NSUMS doubles.
+//
+// Built with -ffp-contract=off (see voxel_map.hip).
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "lom_internal.hpp"
+#include "pose_math.hpp"
+
+namespace lom {
+
+constexpr int kMatchThreads = 256;             // 4 waves
+constexpr int kGroupsPerBlock = kMatchThreads / 32;  // one query per 32-lane half wave
+constexpr int kEvalThreads = 256;
+
+// per-query device record written by k_match
+struct __attribute__((aligned(8))) QStat {
+    float sq_dist;
+    uint32_t n_cand;
+    uint32_t n_occ;
+    uint32_t pad;
+};
+
+// ---------------------------------------------------------------------------
+// k_match: one query per half wave (32 lanes).
+//   lanes 0..26  probe one neighbour voxel each (voxel_grid.h:175-179)
+//   all 32 lanes stride the stored points of every occupied neighbour
+//   (voxel_grid.h:183-191) and keep a private strict minimum; the half wave
+//   then takes the lexicographic minimum of (sq_dist, scan ordinal), which is
+//   exactly "first encountered wins" of the serial loop.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kMatchThreads) void k_match(MapView map, const char *__restrict__ src, size_t stride,
+                                                         uint32_t n, PoseArgs P, int32_t *__restrict__ out_idx,
+                                                         float *__restrict__ out_on, QStat *__restrict__ out_stat,
+                                                         unsigned long long *__restrict__ counters)
+{
+    __shared__ uint2 s_nb[kGroupsPerBlock][28];  // compacted occupied neighbours: (count, slab)
+    const int lane = threadIdx.x & 63;
+    const int hl = lane & 31;
+    const int half = lane >> 5;
+    const int grp = threadIdx.x >> 5;
+    const uint32_t groups_total = gridDim.x * kGroupsPerBlock;
+    // neighbour offset of this lane, scan order ix (outer), iy, iz (inner)
+    const int dxn = hl / 9 - 1, dyn = (hl / 3) % 3 - 1, dzn = hl % 3 - 1;
+    unsigned long long acc_cand = 0, acc_occ = 0, acc_valid = 0;
+
+    for (uint32_t q = blockIdx.x * kGroupsPerBlock + grp; q < n; q += groups_total) {
+        const float *sp = reinterpret_cast<const float *>(src + (size_t)q * stride);
+        const double p0 = (double)sp[0], p1 = (double)sp[1], p2 = (double)sp[2];
+        // voxel_grid.h:220-223: R*p + t in f64 (Eigen order a0 + (a1 + a2)), cast to f32
+        const float qx = (float)((P.R[0] * p0 + (P.R[1] * p1 + P.R[2] * p2)) + P.t[0]);
+        const float qy = (float)((P.R[3] * p0 + (P.R[4] * p1 + P.R[5] * p2)) + P.t[1]);
+        const float qz = (float)((P.R[6] * p0 + (P.R[7] * p1 + P.R[8] * p2)) + P.t[2]);
+        int ix = 0, iy = 0, iz = 0;
+        const bool inr = voxel_index(qx, map.voxel_size, ix) && voxel_index(qy, map.voxel_size, iy) &&
+                         voxel_index(qz, map.voxel_size, iz);
+        uint32_t cnt = 0, slab = 0;
+        if (inr && hl < 27) {
+            const int nx = ix + dxn, ny = iy + dyn, nz = iz + dzn;
+            // stored indices lie in (-2^20, 2^20); anything outside cannot exist
+            if (nx > -kIdxBias && nx < kIdxBias && ny > -kIdxBias && ny < kIdxBias && nz > -kIdxBias &&
+                nz < kIdxBias) {
+                const unsigned long long key = pack_key(nx, ny, nz);
+                uint32_t h = hash_key(key, map.shift) & map.mask;
+                for (uint32_t probe = 0; probe <= map.mask; probe++) {
+                    const uint4 raw = *reinterpret_cast<const uint4 *>(&map.table[h]);
+                    const unsigned long long k = ((unsigned long long)raw.y << 32) | raw.x;
+                    if (k == key) {
+                        cnt = raw.z;
+                        slab = raw.w;
+                        break;
+                    }
+                    if (k == kEmptyKey) break;
+                    h = (h + 1) & map.mask;
+                }
+            }
+        }
+        // compact the occupied neighbours in scan order
+        const unsigned long long bal = __ballot(cnt > 0);
+        const uint32_t hmask = (uint32_t)(bal >> (half * 32));
+        const uint32_t n_occ = __popc(hmask);
+        if (cnt > 0) s_nb[grp][__popc(hmask & ((1u << hl) - 1u))] = make_uint2(cnt, slab);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        float best = INFINITY;
+        uint32_t best_ord = 0xFFFFFFFFu;
+        uint32_t n_cand = 0;
+        for (uint32_t i = 0; i < n_occ; i++) {
+            const uint2 e = s_nb[grp][i];
+            n_cand += e.x;
+            const float *vp = map.pts + (size_t)e.y * map.K * 3;
+            for (uint32_t j = hl; j < e.x; j += 32) {
+                const float ax = vp[j * 3 + 0], ay = vp[j * 3 + 1], az = vp[j * 3 + 2];
+                const float dx = qx - ax, dy = qy - ay, dz = qz - az;
+                const float d2 = dx * dx + (dy * dy + dz * dz);  // voxel_grid.h:184 f32 squaredNorm
+                if (d2 < P.max_sq && d2 < best) {                // :186-187 strict
+                    best = d2;
+                    best_ord = (i << 16) | j;
+                }
+            }
+        }
+        // lexicographic min over the half wave; d2 >= 0 so its bit pattern orders like the value
+        unsigned long long keyv = ((unsigned long long)__float_as_uint(best) << 32) | best_ord;
+#pragma unroll
+        for (int d = 16; d >= 1; d >>= 1) {
+            const unsigned long long o = __shfl_xor(keyv, d, 32);
+            keyv = o < keyv ? o : keyv;
+        }
+        const uint32_t w_ord = (uint32_t)keyv;
+        const bool valid = w_ord != 0xFFFFFFFFu;
+        if (hl == 0) {
+            int32_t idx = -1;
+            float o0 = 0.f, o1 = 0.f, o2 = 0.f, n0 = 0.f, n1 = 0.f, n2 = 0.f;
+            if (valid) {
+                const uint2 e = s_nb[grp][w_ord >> 16];
+                const size_t pi = (size_t)e.y * map.K + (w_ord & 0xFFFFu);
+                idx = (int32_t)pi;
+                o0 = map.pts[pi * 3 + 0];  // voxel_grid.h:197-198
+                o1 = map.pts[pi * 3 + 1];
+                o2 = map.pts[pi * 3 + 2];
+                n0 = map.nrm[pi * 3 + 0];
+                n1 = map.nrm[pi * 3 + 1];
+                n2 = map.nrm[pi * 3 + 2];
+            }
+            out_idx[q] = idx;
+            float *on = out_on + (size_t)q * 6;
+            on[0] = o0;
+            on[1] = o1;
+            on[2] = o2;
+            on[3] = n0;
+            on[4] = n1;
+            on[5] = n2;
+            if (out_stat) {
+                QStat st;
+                st.sq_dist = valid ? __uint_as_float((uint32_t)(keyv >> 32)) : 0.f;
+                st.n_cand = n_cand;
+                st.n_occ = n_occ;
+                st.pad = 0;
+                out_stat[q] = st;
+            }
+            acc_cand += n_cand;
+            acc_occ += n_occ;
+            acc_valid += valid ? 1 : 0;
+        }
+        // s_nb is rewritten next iteration: all reads above are complete for this wave
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (hl == 0 && (acc_cand | acc_occ | acc_valid)) {
+        atomicAdd(&counters[0], acc_valid);
+        atomicAdd(&counters[1], acc_cand);
+        atomicAdd(&counters[2], acc_occ);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_eval: residual + Jacobian + robust weight + reduction.  One lane per
+// source point, grid-stride; 28 f64 accumulators per lane.
+// ---------------------------------------------------------------------------
+__device__ inline double wave_sum(double v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(kEvalThreads) void k_eval(const char *__restrict__ src, size_t stride, uint32_t n,
+                                                       const int32_t *__restrict__ idx,
+                                                       const float *__restrict__ on, EvalArgs E,
+                                                       double *__restrict__ partials)
+{
+    __shared__ double s_red[kEvalThreads / 64][28];
+    double acc[28];
+#pragma unroll
+    for (int k = 0; k < 28; k++) acc[k] = 0.0;
+    const double q0 = E.q[0], q1 = E.q[1], q2 = E.q[2], q3 = E.q[3];
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        if (idx[i] < 0) continue;
+        const float *sp = reinterpret_cast<const float *>(src + (size_t)i * stride);
+        const double p[3] = {(double)sp[0], (double)sp[1], (double)sp[2]};
+        const float *c = on + (size_t)i * 6;
+        const double o[3] = {(double)c[0], (double)c[1], (double)c[2]};
+        const double nn[3] = {(double)c[3], (double)c[4], (double)c[5]};
+        // cloud_matcher.cpp:54  (rot*local_point + t - plane_origin).dot(plane_normal)
+        double uv0 = q2 * p[2] - q3 * p[1];
+        double uv1 = q3 * p[0] - q1 * p[2];
+        double uv2 = q1 * p[1] - q2 * p[0];
+        uv0 += uv0;
+        uv1 += uv1;
+        uv2 += uv2;
+        const double rp0 = (p[0] + q0 * uv0) + (q2 * uv2 - q3 * uv1);
+        const double rp1 = (p[1] + q0 * uv1) + (q3 * uv0 - q1 * uv2);
+        const double rp2 = (p[2] + q0 * uv2) + (q1 * uv1 - q2 * uv0);
+        const double e0 = rp0 + E.t[0] - o[0], e1 = rp1 + E.t[1] - o[1], e2 = rp2 + E.t[2] - o[2];
+        const double r = e0 * nn[0] + (e1 * nn[1] + e2 * nn[2]);
+        // cloud_matcher.cpp:64-91: ambient d r / d q_i = (dR/dq_i p).n
+        double v0, v1, v2, ja[4];
+        v0 = 2.0 * q0 * p[0] + 2.0 * -q3 * p[1] + 2.0 * q2 * p[2];
+        v1 = 2.0 * q3 * p[0] + 2.0 * q0 * p[1] + 2.0 * -q1 * p[2];
+        v2 = 2.0 * -q2 * p[0] + 2.0 * q1 * p[1] + 2.0 * q0 * p[2];
+        ja[0] = v0 * nn[0] + (v1 * nn[1] + v2 * nn[2]);
+        v0 = 2.0 * q1 * p[0] + 2.0 * q2 * p[1] + 2.0 * q3 * p[2];
+        v1 = 2.0 * q2 * p[0] + 2.0 * -q1 * p[1] + 2.0 * -q0 * p[2];
+        v2 = 2.0 * q3 * p[0] + 2.0 * q0 * p[1] + 2.0 * -q1 * p[2];
+        ja[1] = v0 * nn[0] + (v1 * nn[1] + v2 * nn[2]);
+        v0 = 2.0 * -q2 * p[0] + 2.0 * q1 * p[1] + 2.0 * q0 * p[2];
+        v1 = 2.0 * q1 * p[0] + 2.0 * q2 * p[1] + 2.0 * q3 * p[2];
+        v2 = 2.0 * -q0 * p[0] + 2.0 * q3 * p[1] + 2.0 * -q2 * p[2];
+        ja[2] = v0 * nn[0] + (v1 * nn[1] + v2 * nn[2]);
+        v0 = 2.0 * -q3 * p[0] + 2.0 * -q0 * p[1] + 2.0 * q1 * p[2];
+        v1 = 2.0 * q0 * p[0] + 2.0 * -q3 * p[1] + 2.0 * q2 * p[2];
+        v2 = 2.0 * q1 * p[0] + 2.0 * q2 * p[1] + 2.0 * q3 * p[2];
+        ja[3] = v0 * nn[0] + (v1 * nn[1] + v2 * nn[2]);
+        // Ceres QuaternionManifold plus-Jacobian (4x3): ambient -> tangent
+        double J[6];
+        J[0] = ja[0] * -q1 + ja[1] * q0 + ja[2] * -q3 + ja[3] * q2;
+        J[1] = ja[0] * -q2 + ja[1] * q3 + ja[2] * q0 + ja[3] * -q1;
+        J[2] = ja[0] * -q3 + ja[1] * -q2 + ja[2] * q1 + ja[3] * q0;
+        J[3] = nn[0];  // cloud_matcher.cpp:96-98
+        J[4] = nn[1];
+        J[5] = nn[2];
+        // ceres::HuberLoss(0.15) (cloud_matcher.cpp:134); rho'' <= 0 -> plain IRLS weight rho'
+        const double s = r * r;
+        double rho0 = s, w = 1.0;
+        if (s > 0.15 * 0.15) {
+            const double rr = sqrt(s);
+            rho0 = 2.0 * 0.15 * rr - 0.15 * 0.15;
+            w = fmax(DBL_MIN, 0.15 / rr);
+        }
+        int k = 0;
+#pragma unroll
+        for (int a = 0; a < 6; a++) {
+            const double wa = w * J[a];
+#pragma unroll
+            for (int b = a; b < 6; b++) acc[k++] += wa * J[b];
+        }
+#pragma unroll
+        for (int a = 0; a < 6; a++) acc[21 + a] += w * J[a] * r;
+        acc[27] += 0.5 * rho0;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 28; k++) {
+        const double v = wave_sum(acc[k]);
+        if (lane == 0) s_red[wave][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 28) {
+        double v = 0.0;
+#pragma unroll
+        for (int w = 0; w < kEvalThreads / 64; w++) v += s_red[w][threadIdx.x];
+        partials[(size_t)blockIdx.x * 28 + threadIdx.x] = v;
+    }
+}
+
+// fixed-order final sum -> LOM_NSUMS doubles; counters from the last k_match
+__global__ void k_finish(const double *__restrict__ partials, uint32_t n_blocks,
+                         const unsigned long long *__restrict__ counters, uint32_t n_queries,
+                         double *__restrict__ out)
+{
+    const int k = threadIdx.x;
+    if (k < 28) {
+        double v = 0.0;
+        for (uint32_t b = 0; b < n_blocks; b++) v += partials[(size_t)b * 28 + k];
+        out[k] = v;
+    } else if (k < 31) {
+        out[k] = (double)counters[k - 28];
+    } else if (k == 31) {
+        out[k] = (double)n_queries;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+static void pose_args(const float t[3], const float q[4], float max_dist, PoseArgs &P)
+{
+    float R[9];
+    rotation_matrix(q, R);  // voxel_grid.h:212 transform.rotationMatrix().cast<double>()
+    for (int i = 0; i < 9; i++) P.R[i] = (double)R[i];
+    for (int i = 0; i < 3; i++) P.t[i] = (double)t[i];
+    P.max_sq = max_dist * max_dist;  // voxel_grid.h:215
+}
+
+static uint32_t match_grid(uint32_t n)
+{
+    const uint32_t need = (n + kGroupsPerBlock - 1) / kGroupsPerBlock;
+    return std::max(1u, std::min(need, 256u * 8u));
+}
+
+static uint32_t eval_grid(uint32_t n)
+{
+    const uint32_t need = (n + kEvalThreads - 1) / kEvalThreads;
+    return std::max(1u, std::min(need, 512u));
+}
+
+struct ScanCtx {
+    lom_map *m;
+    const char *d_src;
+    size_t stride;
+    uint32_t n;
+    uint32_t eval_blocks;
+    float match_ms = 0.f, eval_ms = 0.f;
+};
+
+static int scan_buffers(lom_map *m, uint32_t n, bool want_stats)
+{
+    int rc;
+    const size_t nn = std::max<uint32_t>(n, 1);
+    if ((rc = ensure(m, m->scan_idx, nn * 4)) != LOM_OK) return rc;
+    if ((rc = ensure(m, m->scan_on, nn * 24)) != LOM_OK) return rc;
+    if (want_stats && (rc = ensure(m, m->scan_stats, nn * sizeof(QStat))) != LOM_OK) return rc;
+    if ((rc = ensure(m, m->partials, (size_t)512 * 28 * 8)) != LOM_OK) return rc;
+    if ((rc = ensure(m, m->results, 4096)) != LOM_OK) return rc;
+    return LOM_OK;
+}
+
+static unsigned long long *d_counters(lom_map *m) { return (unsigned long long *)((char *)m->results.p + 1024); }
+static double *d_sums(lom_map *m) { return (double *)m->results.p; }
+
+static int launch_match(ScanCtx &c, const float t[3], const float q[4], float max_dist, bool stats)
+{
+    lom_map *m = c.m;
+    PoseArgs P;
+    pose_args(t, q, max_dist, P);
+    LOM_HIP(m, hipMemsetAsync(d_counters(m), 0, 32, m->stream));
+    if (c.n) {
+        if (m->profiling) LOM_HIP(m, hipEventRecord(m->ev[0], m->stream));
+        hipLaunchKernelGGL(k_match, dim3(match_grid(c.n)), dim3(kMatchThreads), 0, m->stream, view_of(m), c.d_src,
+                           c.stride, c.n, P, (int32_t *)m->scan_idx.p, (float *)m->scan_on.p,
+                           stats ? (QStat *)m->scan_stats.p : (QStat *)nullptr, d_counters(m));
+        LOM_HIP(m, hipGetLastError());
+        if (m->profiling) LOM_HIP(m, hipEventRecord(m->ev[1], m->stream));
+    }
+    return LOM_OK;
+}
+
+// evaluation at (q,t) -> host sums (rank-local, or rank-ordered total with a communicator)
+static int launch_eval(ScanCtx &c, const double q[4], const double t[3], double out[LOM_NSUMS])
+{
+    lom_map *m = c.m;
+    EvalArgs E;
+    for (int i = 0; i < 4; i++) E.q[i] = q[i];
+    for (int i = 0; i < 3; i++) E.t[i] = t[i];
+    const uint32_t nb = c.n ? eval_grid(c.n) : 0;
+    if (m->profiling) LOM_HIP(m, hipEventRecord(m->ev[2], m->stream));
+    if (nb) {
+        hipLaunchKernelGGL(k_eval, dim3(nb), dim3(kEvalThreads), 0, m->stream, c.d_src, c.stride, c.n,
+                           (const int32_t *)m->scan_idx.p, (const float *)m->scan_on.p, E, (double *)m->partials.p);
+    }
+    hipLaunchKernelGGL(k_finish, dim3(1), dim3(64), 0, m->stream, (const double *)m->partials.p, nb,
+                       (const unsigned long long *)d_counters(m), c.n, d_sums(m));
+    LOM_HIP(m, hipGetLastError());
+    if (m->profiling) LOM_HIP(m, hipEventRecord(m->ev[3], m->stream));
+    if (m->comm) {
+        int rc = ensure(m, m->gather, (size_t)m->nranks * LOM_NSUMS * 8);
+        if (rc != LOM_OK) return rc;
+        rc = comm_allgather_sums(m, d_sums(m), (double *)m->gather.p, LOM_NSUMS);
+        if (rc != LOM_OK) return rc;
+        LOM_HIP(m, hipMemcpyAsync(m->h_results, m->gather.p, (size_t)m->nranks * LOM_NSUMS * 8,
+                                  hipMemcpyDeviceToHost, m->stream));
+        LOM_HIP(m, hipStreamSynchronize(m->stream));
+        for (int k = 0; k < LOM_NSUMS; k++) {
+            double v = 0.0;
+            for (int r = 0; r < m->nranks; r++) v += m->h_results[(size_t)r * LOM_NSUMS + k];  // rank order
+            out[k] = v;
+        }
+    } else {
+        LOM_HIP(m, hipMemcpyAsync(m->h_results, d_sums(m), LOM_NSUMS * 8, hipMemcpyDeviceToHost, m->stream));
+        LOM_HIP(m, hipStreamSynchronize(m->stream));
+        std::memcpy(out, m->h_results, LOM_NSUMS * 8);
+    }
+    return LOM_OK;
+}
+
+static void add_event_ms(lom_map *m, int a, int b, float &acc)
+{
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, m->ev[a], m->ev[b]) == hipSuccess) acc += ms;
+}
+
+static int hook_match_eval(void *user, const float pt[3], const float pq[4], const double q[4], const double t[3],
+                           double out[LOM_NSUMS])
+{
+    ScanCtx &c = *(ScanCtx *)user;
+    int rc = launch_match(c, pt, pq, 0.3f, false);  // cloud_matcher.cpp:139
+    if (rc != LOM_OK) return rc;
+    rc = launch_eval(c, q, t, out);
+    if (rc != LOM_OK) return rc;
+    if (c.m->profiling) {
+        if (c.n) add_event_ms(c.m, 0, 1, c.match_ms);
+        add_event_ms(c.m, 2, 3, c.eval_ms);
+    }
+    return LOM_OK;
+}
+
+static int hook_eval_fixed(void *user, const double q[4], const double t[3], double out[LOM_NSUMS])
+{
+    ScanCtx &c = *(ScanCtx *)user;
+    int rc = launch_eval(c, q, t, out);
+    if (rc != LOM_OK) return rc;
+    if (c.m->profiling) add_event_ms(c.m, 2, 3, c.eval_ms);
+    return LOM_OK;
+}
+
+static int align_device(lom_map *m, const char *d_src, size_t n, size_t stride, const float guess_t[3],
+                        const float guess_q[4], float out_t[3], float out_q[4], lom_align_stats *stats)
+{
+    if (n >= 0x7FFFFFFFull) return set_error(m, LOM_ERR_ARG, "too many source points");
+    int rc = scan_buffers(m, (uint32_t)n, false);
+    if (rc != LOM_OK) return rc;
+    ScanCtx c{m, d_src, stride, (uint32_t)n, 0};
+    lom_align_hooks hooks;
+    hooks.user = &c;
+    hooks.match_eval = hook_match_eval;
+    hooks.eval_fixed = hook_eval_fixed;
+    hooks.allreduce = nullptr;  // the rank-ordered all-gather sits inside launch_eval
+    lom_align_stats st;
+    rc = lom_align_with_hooks(&hooks, guess_t, guess_q, out_t, out_q, &st);
+    if (rc != LOM_OK) {
+        if (m->last_error.empty()) set_error(m, rc, "align failed");
+        return rc == LOM_ERR_HOOK ? LOM_ERR_HIP : rc;
+    }
+    st.match_kernel_ms = c.match_ms;
+    st.eval_kernel_ms = c.eval_ms;
+    if (stats) *stats = st;
+    return LOM_OK;
+}
+
+static int stage_scan(lom_map *m, const float *src, size_t n, size_t stride, const char **d_src)
+{
+    const size_t bytes = n ? (n - 1) * stride + 12 : 0;
+    int rc = ensure(m, m->scan_src, std::max<size_t>(bytes, 16));
+    if (rc != LOM_OK) return rc;
+    if (bytes) LOM_HIP(m, hipMemcpyAsync(m->scan_src.p, src, bytes, hipMemcpyHostToDevice, m->stream));
+    *d_src = (const char *)m->scan_src.p;
+    return LOM_OK;
+}
+
+}  // namespace lom
+
+using namespace lom;
+
+extern "C" {
+
+int64_t lom_match_find_pairs(lom_map *m, const float *src, size_t n, size_t stride, const float t[3],
+                             const float q[4], float max_dist, lom_correspondence *out)
+{
+    if (!m || (n && (!src || !out)) || !t || !q || stride < 12 || (stride & 3)) return LOM_ERR_ARG;
+    if (n >= 0x7FFFFFFFull) return LOM_ERR_ARG;
+    if (n == 0) return 0;
+    LOM_HIP(m, hipSetDevice(m->device));
+    const char *d_src = nullptr;
+    int rc = stage_scan(m, src, n, stride, &d_src);
+    if (rc != LOM_OK) return rc;
+    if ((rc = scan_buffers(m, (uint32_t)n, true)) != LOM_OK) return rc;
+    ScanCtx c{m, d_src, stride, (uint32_t)n, 0};
+    if ((rc = launch_match(c, t, q, max_dist, true)) != LOM_OK) return rc;
+    std::vector<int32_t> idx(n);
+    std::vector<float> on(n * 6);
+    std::vector<QStat> st(n);
+    LOM_HIP(m, hipMemcpyAsync(idx.data(), m->scan_idx.p, n * 4, hipMemcpyDeviceToHost, m->stream));
+    LOM_HIP(m, hipMemcpyAsync(on.data(), m->scan_on.p, n * 24, hipMemcpyDeviceToHost, m->stream));
+    LOM_HIP(m, hipMemcpyAsync(st.data(), m->scan_stats.p, n * sizeof(QStat), hipMemcpyDeviceToHost, m->stream));
+    LOM_HIP(m, hipStreamSynchronize(m->stream));
+    int64_t valid = 0;
+    for (size_t i = 0; i < n; i++) {
+        lom_correspondence &o = out[i];
+        o.index = idx[i];
+        std::memcpy(o.origin, &on[i * 6], 12);
+        std::memcpy(o.normal, &on[i * 6 + 3], 12);
+        o.sq_dist = st[i].sq_dist;
+        o.n_cand = st[i].n_cand;
+        o.n_occ = st[i].n_occ;
+        valid += idx[i] >= 0;
+    }
+    return valid;
+}
+
+int lom_match_align_device(lom_map *m, const float *d_src, size_t n, size_t stride, const float guess_t[3],
+                           const float guess_q[4], float out_t[3], float out_q[4], lom_align_stats *stats)
+{
+    if (!m || (n && !d_src) || !guess_t || !guess_q || !out_t || !out_q || stride < 12 || (stride & 3))
+        return LOM_ERR_ARG;
+    LOM_HIP(m, hipSetDevice(m->device));
+    m->last_error.clear();
+    return align_device(m, (const char *)d_src, n, stride, guess_t, guess_q, out_t, out_q, stats);
+}
+
+int lom_match_align(lom_map *m, const float *src, size_t n, size_t stride, const float guess_t[3],
+                    const float guess_q[4], float out_t[3], float out_q[4], lom_align_stats *stats)
+{
+    if (!m || (n && !src) || !guess_t || !guess_q || !out_t || !out_q || stride < 12 || (stride & 3))
+        return LOM_ERR_ARG;
+    LOM_HIP(m, hipSetDevice(m->device));
+    m->last_error.clear();
+    const char *d_src = nullptr;
+    int rc = stage_scan(m, src, n, stride, &d_src);
+    if (rc != LOM_OK) return rc;
+    return align_device(m, d_src, n, stride, guess_t, guess_q, out_t, out_q, stats);
+}
+
+}  // extern "C"

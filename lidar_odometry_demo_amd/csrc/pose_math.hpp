@@ -1,0 +1,112 @@
+// f32 SE(3) algebra of the boundary type Pose3D (reference src/pose_3d.h:10-59)
+// and the f64 manifold step used by the host solver.  Host code; compiled with
+// -ffp-contract=off so the f32 rotation matrix that feeds the device search is
+// rounded exactly like the reference's Eigen expressions on x86-64.
+#pragma once
+#include <cmath>
+
+#include "../../include/lidar_odometry_amd.h"
+
+namespace lom {
+
+// Eigen reduces fixed-size-3 expressions as a0 + (a1 + a2).
+inline float sum3(float a, float b, float c) { return a + (b + c); }
+inline double sum3(double a, double b, double c) { return a + (b + c); }
+
+// Quaternion * vector as Eigen evaluates it: v + w*2(u x v) + u x 2(u x v).
+template <typename T>
+inline void quat_rotate(const T q[4], const T v[3], T out[3])
+{
+    const T w = q[0], x = q[1], y = q[2], z = q[3];
+    T a0 = y * v[2] - z * v[1];
+    T a1 = z * v[0] - x * v[2];
+    T a2 = x * v[1] - y * v[0];
+    a0 += a0;
+    a1 += a1;
+    a2 += a2;
+    const T c0 = y * a2 - z * a1;
+    const T c1 = z * a0 - x * a2;
+    const T c2 = x * a1 - y * a0;
+    out[0] = (v[0] + w * a0) + c0;
+    out[1] = (v[1] + w * a1) + c1;
+    out[2] = (v[2] + w * a2) + c2;
+}
+
+template <typename T>
+inline void quat_mul(const T a[4], const T b[4], T out[4])
+{
+    const T r0 = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+    const T r1 = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+    const T r2 = a[0] * b[2] + a[2] * b[0] + a[3] * b[1] - a[1] * b[3];
+    const T r3 = a[0] * b[3] + a[3] * b[0] + a[1] * b[2] - a[2] * b[1];
+    out[0] = r0;
+    out[1] = r1;
+    out[2] = r2;
+    out[3] = r3;
+}
+
+// Quaternionf::toRotationMatrix (pose_3d.h:43), row-major.
+inline void rotation_matrix(const float q[4], float R[9])
+{
+    const float w = q[0], x = q[1], y = q[2], z = q[3];
+    const float tx = 2.f * x, ty = 2.f * y, tz = 2.f * z;
+    const float twx = tx * w, twy = ty * w, twz = tz * w;
+    const float txx = tx * x, txy = ty * x, txz = tz * x;
+    const float tyy = ty * y, tyz = tz * y, tzz = tz * z;
+    R[0] = 1.f - (tyy + tzz);
+    R[1] = txy - twz;
+    R[2] = txz + twy;
+    R[3] = txy + twz;
+    R[4] = 1.f - (txx + tzz);
+    R[5] = tyz - twx;
+    R[6] = txz - twy;
+    R[7] = tyz + twx;
+    R[8] = 1.f - (txx + tyy);
+}
+
+inline void pose_compose(const lom_pose &a, const lom_pose &b, lom_pose &out)
+{
+    lom_pose r;
+    float rt[3];
+    quat_rotate<float>(a.q, b.t, rt);
+    for (int i = 0; i < 3; i++) r.t[i] = a.t[i] + rt[i];
+    quat_mul<float>(a.q, b.q, r.q);
+    out = r;
+}
+
+inline void pose_inverse(const lom_pose &a, lom_pose &out)
+{
+    lom_pose r;
+    const float n2 = (a.q[0] * a.q[0] + a.q[1] * a.q[1]) + (a.q[2] * a.q[2] + a.q[3] * a.q[3]);
+    if (n2 > 0.f) {
+        r.q[0] = a.q[0] / n2;
+        r.q[1] = -a.q[1] / n2;
+        r.q[2] = -a.q[2] / n2;
+        r.q[3] = -a.q[3] / n2;
+    } else {
+        r.q[0] = r.q[1] = r.q[2] = r.q[3] = 0.f;
+    }
+    const float nt[3] = {-a.t[0], -a.t[1], -a.t[2]};
+    quat_rotate<float>(r.q, nt, r.t);
+    out = r;
+}
+
+// Ceres QuaternionManifold::Plus on [w,x,y,z] (delta = half-angle vector applied
+// on the left) followed by the Euclidean translation update.
+inline void manifold_plus(const double x[7], const double d[6], double out[7])
+{
+    const double nd = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    if (nd == 0.0) {
+        for (int i = 0; i < 4; i++) out[i] = x[i];
+    } else {
+        const double s = std::sin(nd) / nd;
+        const double z[4] = {std::cos(nd), s * d[0], s * d[1], s * d[2]};
+        out[0] = z[0] * x[0] - z[1] * x[1] - z[2] * x[2] - z[3] * x[3];
+        out[1] = z[0] * x[1] + z[1] * x[0] + z[2] * x[3] - z[3] * x[2];
+        out[2] = z[0] * x[2] - z[1] * x[3] + z[2] * x[0] + z[3] * x[1];
+        out[3] = z[0] * x[3] + z[1] * x[2] - z[2] * x[1] + z[3] * x[0];
+    }
+    for (int i = 0; i < 3; i++) out[4 + i] = x[4 + i] + d[3 + i];
+}
+
+}  // namespace lom

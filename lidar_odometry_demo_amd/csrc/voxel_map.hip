@@ -1,0 +1,858 @@
+// Device-resident voxel map: the MI355X counterpart of the reference's
+// VoxelGrid container (src/voxel_grid.h:17-257) and VoxelWithPlanes payload
+// (src/voxel_with_planes.h:10-36).
+//
+//   addCloud / addCloudWithoutNormals (:77-110)  -> lom_map_add_points[_device]
+//   radiusCleanup (:236-246)                     -> lom_map_radius_cleanup
+//   getCloud / getCloudWithoutNormals /
+//   getSparseCloudWithoutNormals (:112-162)      -> lom_map_export
+//   setVoxelSize / setMaxPoints / size (:56-66, :248-251)
+//
+// The reference inserts serially; a voxel keeps the first max_points points in
+// call order and that order is the nearest-neighbour tie-break order.  The
+// insert below is data-parallel but a pure function of the input order:
+// hash slots are claimed with a 64-bit CAS (which voxel gets which slot does
+// not matter), creation order comes from a prefix scan over "first point of a
+// new voxel" flags, and a point's position inside its voxel is its rank among
+// the batch's points of that voxel by input index -- no result depends on the
+// order in which atomics land.
+//
+// Built with -ffp-contract=off: the f32 index and distance expressions must
+// round like the reference's (plain -O3 x86-64 build, no FMA contraction).
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "lom_internal.hpp"
+
+namespace lom {
+
+// ---------------------------------------------------------------------------
+// error handling / buffers
+// ---------------------------------------------------------------------------
+static thread_local std::string g_create_error;
+
+int set_error(lom_map *m, int code, const char *what, hipError_t e)
+{
+    std::string s = what ? what : "";
+    if (e != hipSuccess) {
+        s += ": ";
+        s += hipGetErrorString(e);
+    }
+    if (m)
+        m->last_error = s;
+    else
+        g_create_error = s;
+    return code;
+}
+
+int ensure(lom_map *m, DeviceBuf &b, size_t bytes)
+{
+    if (bytes <= b.bytes) return LOM_OK;
+    size_t nb = std::max(bytes, b.bytes + b.bytes / 2);
+    nb = (nb + 255) & ~size_t(255);
+    if (b.p) {
+        LOM_HIP(m, hipStreamSynchronize(m->stream));
+        LOM_HIP(m, hipFree(b.p));
+        b.p = nullptr;
+        b.bytes = 0;
+    }
+    hipError_t e = hipMalloc(&b.p, nb);
+    if (e != hipSuccess) {
+        b.p = nullptr;
+        return set_error(m, LOM_ERR_OOM, "hipMalloc", e);
+    }
+    b.bytes = nb;
+    return LOM_OK;
+}
+
+MapView view_of(const lom_map *m)
+{
+    MapView v;
+    v.table = m->d_table;
+    v.mask = m->cap - 1;
+    v.shift = 64 - (uint32_t)__builtin_ctz(m->cap);
+    v.pts = m->d_pts;
+    v.nrm = m->d_nrm;
+    v.K = m->K;
+    v.voxel_size = m->voxel_size;
+    return v;
+}
+
+enum {
+    S_IN_XYZ = 0,
+    S_IN_NRM,
+    S_PT_SLOT,
+    S_PT_POS,
+    S_FLAG,
+    S_RANK,
+    S_BKT_CNT,
+    S_BKT_HEAD,
+    S_BKT_OFF,
+    S_ITEMS,
+    S_SCAN,
+    S_MISC
+};
+
+constexpr int kThreads = 256;
+static inline uint32_t blocks_for(size_t n, int t = kThreads) { return (uint32_t)((n + t - 1) / t); }
+
+// ---------------------------------------------------------------------------
+// exclusive prefix scan of uint32 (tile = 256 threads x 8 items)
+// ---------------------------------------------------------------------------
+constexpr int kScanItems = 8;
+constexpr int kScanTile = kThreads * kScanItems;
+
+__global__ __launch_bounds__(kThreads) void k_scan_tile(const uint32_t *__restrict__ in,
+                                                        uint32_t *__restrict__ out,
+                                                        uint32_t *__restrict__ tile_sums, uint32_t n)
+{
+    __shared__ uint32_t s_wave[kThreads / 64];
+    const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
+    uint32_t v[kScanItems];
+    uint32_t sum = 0;
+#pragma unroll
+    for (int k = 0; k < kScanItems; k++) {
+        v[k] = (base + k < n) ? in[base + k] : 0u;
+        sum += v[k];
+    }
+    // inclusive scan of per-thread sums inside the wave
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t inc = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    uint32_t wave_off = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < kThreads / 64; w++) {
+        if (w < wave) wave_off += s_wave[w];
+        total += s_wave[w];
+    }
+    uint32_t run = wave_off + inc - sum;
+#pragma unroll
+    for (int k = 0; k < kScanItems; k++) {
+        if (base + k < n) out[base + k] = run;
+        run += v[k];
+    }
+    if (threadIdx.x == 0) tile_sums[blockIdx.x] = total;
+}
+
+__global__ void k_scan_add(uint32_t *__restrict__ out, const uint32_t *__restrict__ tile_prefix, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] += tile_prefix[i / kScanTile];
+}
+
+// out[i] = sum in[0..i), *d_total = sum of all.  tmp must hold 2*(n/tile + 2) words per level.
+static int scan_exclusive(lom_map *m, const uint32_t *in, uint32_t *out, uint32_t n, uint32_t *d_total,
+                          uint32_t *tmp)
+{
+    const uint32_t nt = (n + kScanTile - 1) / kScanTile;
+    if (nt <= 1) {
+        hipLaunchKernelGGL(k_scan_tile, dim3(1), dim3(kThreads), 0, m->stream, in, out, d_total, n);
+        LOM_HIP(m, hipGetLastError());
+        return LOM_OK;
+    }
+    uint32_t *sums = tmp, *prefix = tmp + nt;
+    hipLaunchKernelGGL(k_scan_tile, dim3(nt), dim3(kThreads), 0, m->stream, in, out, sums, n);
+    LOM_HIP(m, hipGetLastError());
+    int rc = scan_exclusive(m, sums, prefix, nt, d_total, tmp + 2 * (size_t)nt);
+    if (rc != LOM_OK) return rc;
+    hipLaunchKernelGGL(k_scan_add, dim3(blocks_for(n)), dim3(kThreads), 0, m->stream, out, prefix, n);
+    LOM_HIP(m, hipGetLastError());
+    return LOM_OK;
+}
+
+static size_t scan_tmp_words(uint32_t n)
+{
+    size_t w = 0;
+    while (n > (uint32_t)kScanTile) {
+        n = (n + kScanTile - 1) / kScanTile;
+        w += 2 * (size_t)n;
+    }
+    return w + 16;
+}
+
+// ---------------------------------------------------------------------------
+// table kernels
+// ---------------------------------------------------------------------------
+__global__ void k_table_init(Slot *table, uint32_t cap)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < cap) {
+        Slot s;
+        s.key = kEmptyKey;
+        s.count = 0;
+        s.slab = kNoSlab;
+        table[i] = s;
+    }
+}
+
+__device__ inline uint32_t claim_slot(Slot *table, uint32_t mask, uint32_t shift, unsigned long long key)
+{
+    uint32_t h = hash_key(key, shift) & mask;
+    for (;;) {
+        const unsigned long long prev = atomicCAS(&table[h].key, kEmptyKey, key);
+        if (prev == kEmptyKey || prev == key) return h;
+        h = (h + 1) & mask;
+    }
+}
+
+// rebuild the table from the slab arrays (after rehash / cleanup)
+__global__ void k_rebuild(Slot *table, uint32_t mask, uint32_t shift, const unsigned long long *slab_key,
+                          const uint32_t *slab_count, uint32_t n_vox, unsigned long long *n_points)
+{
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_vox) return;
+    const uint32_t h = claim_slot(table, mask, shift, slab_key[s]);
+    table[h].count = slab_count[s];
+    table[h].slab = s;
+    if (n_points) atomicAdd(n_points, (unsigned long long)slab_count[s]);
+}
+
+// ---------------------------------------------------------------------------
+// insert kernels
+// ---------------------------------------------------------------------------
+__device__ inline const float *point_at(const char *base, size_t i, size_t stride)
+{
+    return reinterpret_cast<const float *>(base + i * stride);
+}
+
+__global__ void k_validate(const char *xyz, size_t stride, uint32_t n, float vs, uint32_t *bad)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float *p = point_at(xyz, i, stride);
+    int a;
+    if (!voxel_index(p[0], vs, a) || !voxel_index(p[1], vs, a) || !voxel_index(p[2], vs, a)) *bad = 1u;
+}
+
+// voxel_grid.h:80-82: index + find; claims a slot for a voxel seen for the first time
+__global__ void k_ins_claim(Slot *table, uint32_t mask, uint32_t shift, const char *xyz, size_t stride,
+                            uint32_t n, float vs, uint32_t *pt_slot, uint32_t *pt_pos, uint32_t *bkt_cnt,
+                            uint32_t *bkt_head)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float *p = point_at(xyz, i, stride);
+    int ix = 0, iy = 0, iz = 0;
+    voxel_index(p[0], vs, ix);
+    voxel_index(p[1], vs, iy);
+    voxel_index(p[2], vs, iz);
+    const uint32_t h = claim_slot(table, mask, shift, pack_key(ix, iy, iz));
+    pt_slot[i] = h;
+    pt_pos[i] = atomicAdd(&bkt_cnt[h], 1u);  // arbitrary order; fixed up by rank below
+    atomicMin(&bkt_head[h], i);              // earliest input index touching the voxel
+}
+
+__global__ void k_ins_heads(const Slot *table, uint32_t n, const uint32_t *pt_slot, const uint32_t *bkt_cnt,
+                            const uint32_t *bkt_head, uint32_t *bkt_off, uint32_t *cursor, uint32_t *flag_new)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t h = pt_slot[i];
+    uint32_t fn = 0;
+    if (bkt_head[h] == i) {
+        bkt_off[h] = atomicAdd(cursor, bkt_cnt[h]);  // scratch placement only
+        fn = table[h].slab == kNoSlab;               // voxel_grid.h:83 it == end()
+    }
+    flag_new[i] = fn;
+}
+
+// creation order = order of first appearance in the input (voxel_grid.h:83-87)
+__global__ void k_ins_assign(Slot *table, uint32_t n, const uint32_t *pt_slot, const uint32_t *flag_new,
+                             const uint32_t *rank, uint32_t n_vox_before, unsigned long long *slab_key)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !flag_new[i]) return;
+    const uint32_t h = pt_slot[i];
+    const uint32_t slab = n_vox_before + rank[i];
+    table[h].slab = slab;
+    slab_key[slab] = table[h].key;
+}
+
+__global__ void k_ins_scatter(uint32_t n, const uint32_t *pt_slot, const uint32_t *pt_pos,
+                              const uint32_t *bkt_off, uint32_t *items)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    items[bkt_off[pt_slot[i]] + pt_pos[i]] = i;
+}
+
+// voxel_grid.h:86,89-90: append while size() < max_points_, in input order
+__global__ void k_ins_place(const Slot *table, uint32_t n, const uint32_t *pt_slot, const uint32_t *bkt_cnt,
+                            const uint32_t *bkt_off, const uint32_t *items, const char *xyz, const char *nrm,
+                            size_t stride, uint32_t K, float *pts, float *nrm_out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t h = pt_slot[i];
+    const Slot s = table[h];
+    if (s.count >= K) return;
+    const uint32_t room = K - s.count;
+    const uint32_t m = bkt_cnt[h];
+    const uint32_t *it = items + bkt_off[h];
+    uint32_t rank = 0;
+    for (uint32_t j = 0; j < m && rank < room; j++) rank += it[j] < i;
+    if (rank >= room) return;
+    const size_t dst = ((size_t)s.slab * K + s.count + rank) * 3;
+    const float *p = point_at(xyz, i, stride);
+    pts[dst + 0] = p[0];
+    pts[dst + 1] = p[1];
+    pts[dst + 2] = p[2];
+    if (nrm) {
+        const float *q = point_at(nrm, i, stride);
+        nrm_out[dst + 0] = q[0];
+        nrm_out[dst + 1] = q[1];
+        nrm_out[dst + 2] = q[2];
+    } else {  // voxel_grid.h:103,107
+        nrm_out[dst + 0] = 0.f;
+        nrm_out[dst + 1] = 0.f;
+        nrm_out[dst + 2] = 0.f;
+    }
+}
+
+__global__ void k_ins_finalize(Slot *table, uint32_t n, const uint32_t *pt_slot, const uint32_t *bkt_cnt,
+                               const uint32_t *bkt_head, uint32_t K, uint32_t *slab_count,
+                               unsigned long long *n_points)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t h = pt_slot[i];
+    if (bkt_head[h] != i) return;
+    const Slot s = table[h];
+    const uint32_t want = s.count + bkt_cnt[h];
+    const uint32_t nc = want < K ? want : K;
+    table[h].count = nc;
+    slab_count[s.slab] = nc;
+    atomicAdd(n_points, (unsigned long long)(nc - s.count));
+}
+
+// ---------------------------------------------------------------------------
+// cleanup / export kernels
+// ---------------------------------------------------------------------------
+// voxel_grid.h:238-241: erase iff (getOrigin() - point).squaredNorm() > radius_sq (f32, strict)
+__global__ void k_cleanup_flag(const float *pts, uint32_t K, uint32_t n_vox, float cx, float cy, float cz,
+                               float r2, uint32_t *keep)
+{
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_vox) return;
+    const float *o = pts + (size_t)s * K * 3;  // voxel_with_planes.h:32-35 front()
+    const float dx = o[0] - cx, dy = o[1] - cy, dz = o[2] - cz;
+    const float d2 = dx * dx + (dy * dy + dz * dz);
+    keep[s] = (d2 > r2) ? 0u : 1u;
+}
+
+__global__ void k_compact(const uint32_t *keep, const uint32_t *newid, uint32_t n_vox, uint32_t K,
+                          const unsigned long long *key_in, const uint32_t *cnt_in, const float *pts_in,
+                          const float *nrm_in, unsigned long long *key_out, uint32_t *cnt_out, float *pts_out,
+                          float *nrm_out)
+{
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)n_vox * K) return;
+    const uint32_t s = (uint32_t)(idx / K), j = (uint32_t)(idx % K);
+    if (!keep[s]) return;
+    const uint32_t d = newid[s];
+    const uint32_t c = cnt_in[s];
+    if (j == 0) {
+        key_out[d] = key_in[s];
+        cnt_out[d] = c;
+    }
+    if (j < c) {
+        const size_t a = ((size_t)s * K + j) * 3, b = ((size_t)d * K + j) * 3;
+        pts_out[b] = pts_in[a];
+        pts_out[b + 1] = pts_in[a + 1];
+        pts_out[b + 2] = pts_in[a + 2];
+        nrm_out[b] = nrm_in[a];
+        nrm_out[b + 1] = nrm_in[a + 1];
+        nrm_out[b + 2] = nrm_in[a + 2];
+    }
+}
+
+__global__ void k_export_counts(const uint32_t *slab_count, uint32_t n_vox, int mode, uint32_t *out)
+{
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < n_vox) out[s] = (mode == LOM_EXPORT_FIRST_PER_VOXEL) ? 1u : slab_count[s];
+}
+
+__global__ void k_export_write(const uint32_t *off, const uint32_t *slab_count, uint32_t n_vox, uint32_t K,
+                               int mode, const float *pts, const float *nrm, float *out_xyz, float *out_nrm)
+{
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)n_vox * K) return;
+    const uint32_t s = (uint32_t)(idx / K), j = (uint32_t)(idx % K);
+    const uint32_t c = (mode == LOM_EXPORT_FIRST_PER_VOXEL) ? 1u : slab_count[s];
+    if (j >= c) return;
+    const size_t a = ((size_t)s * K + j) * 3, b = ((size_t)off[s] + j) * 3;
+    out_xyz[b] = pts[a];
+    out_xyz[b + 1] = pts[a + 1];
+    out_xyz[b + 2] = pts[a + 2];
+    if (out_nrm) {
+        out_nrm[b] = nrm[a];
+        out_nrm[b + 1] = nrm[a + 1];
+        out_nrm[b + 2] = nrm[a + 2];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// host-side management
+// ---------------------------------------------------------------------------
+static uint32_t next_pow2(uint64_t v)
+{
+    uint64_t p = 1024;
+    while (p < v) p <<= 1;
+    return (uint32_t)std::min<uint64_t>(p, 1ull << 31);
+}
+
+static int table_alloc(lom_map *m, uint32_t cap, Slot **out)
+{
+    Slot *t = nullptr;
+    hipError_t e = hipMalloc(&t, (size_t)cap * sizeof(Slot));
+    if (e != hipSuccess) return set_error(m, LOM_ERR_OOM, "hipMalloc(table)", e);
+    hipLaunchKernelGGL(k_table_init, dim3(blocks_for(cap)), dim3(kThreads), 0, m->stream, t, cap);
+    LOM_HIP(m, hipGetLastError());
+    *out = t;
+    return LOM_OK;
+}
+
+// counters: [0] n_points (u64), then u32 words: [2] flag, [3] cursor, [4] total
+static unsigned long long *d_npoints(lom_map *m) { return (unsigned long long *)m->scr[S_MISC].p; }
+static uint32_t *d_word(lom_map *m, int i) { return (uint32_t *)m->scr[S_MISC].p + i; }
+
+static int rehash(lom_map *m, uint32_t new_cap)
+{
+    Slot *t = nullptr;
+    int rc = table_alloc(m, new_cap, &t);
+    if (rc != LOM_OK) return rc;
+    Slot *old = m->d_table;
+    m->d_table = t;
+    m->cap = new_cap;
+    if (m->n_vox) {
+        const MapView v = view_of(m);
+        hipLaunchKernelGGL(k_rebuild, dim3(blocks_for(m->n_vox)), dim3(kThreads), 0, m->stream, m->d_table,
+                           v.mask, v.shift, m->d_slab_key, m->d_slab_count, m->n_vox,
+                           (unsigned long long *)nullptr);
+        LOM_HIP(m, hipGetLastError());
+    }
+    if (old) {
+        LOM_HIP(m, hipStreamSynchronize(m->stream));
+        LOM_HIP(m, hipFree(old));
+    }
+    return LOM_OK;
+}
+
+struct Slabs {
+    unsigned long long *key = nullptr;
+    uint32_t *count = nullptr;
+    float *pts = nullptr, *nrm = nullptr;
+};
+
+static void slabs_free(Slabs &s)
+{
+    if (s.key) (void)hipFree(s.key);
+    if (s.count) (void)hipFree(s.count);
+    if (s.pts) (void)hipFree(s.pts);
+    if (s.nrm) (void)hipFree(s.nrm);
+    s = Slabs();
+}
+
+static int slabs_alloc(lom_map *m, uint32_t cap, Slabs &s)
+{
+    const size_t pb = (size_t)cap * m->K * 3 * sizeof(float);
+    if (hipMalloc(&s.key, (size_t)cap * 8) != hipSuccess || hipMalloc(&s.count, (size_t)cap * 4) != hipSuccess ||
+        hipMalloc(&s.pts, pb) != hipSuccess || hipMalloc(&s.nrm, pb) != hipSuccess) {
+        (void)hipGetLastError();
+        slabs_free(s);
+        return set_error(m, LOM_ERR_OOM, "hipMalloc(slabs)");
+    }
+    return LOM_OK;
+}
+
+static int ensure_slabs(lom_map *m, uint64_t want)
+{
+    if (want <= m->slab_cap) return LOM_OK;
+    if (want > 0x7FFFFFFFull / std::max<uint32_t>(1, m->K)) return set_error(m, LOM_ERR_OOM, "map too large");
+    uint32_t nc = std::max<uint32_t>(4096, m->slab_cap);
+    while (nc < want) nc *= 2;
+    Slabs s;
+    int rc = slabs_alloc(m, nc, s);
+    if (rc != LOM_OK) return rc;
+    if (m->n_vox) {
+        const size_t pb = (size_t)m->n_vox * m->K * 3 * sizeof(float);
+        LOM_HIP(m, hipMemcpyAsync(s.key, m->d_slab_key, (size_t)m->n_vox * 8, hipMemcpyDeviceToDevice, m->stream));
+        LOM_HIP(m, hipMemcpyAsync(s.count, m->d_slab_count, (size_t)m->n_vox * 4, hipMemcpyDeviceToDevice, m->stream));
+        LOM_HIP(m, hipMemcpyAsync(s.pts, m->d_pts, pb, hipMemcpyDeviceToDevice, m->stream));
+        LOM_HIP(m, hipMemcpyAsync(s.nrm, m->d_nrm, pb, hipMemcpyDeviceToDevice, m->stream));
+    }
+    LOM_HIP(m, hipStreamSynchronize(m->stream));
+    Slabs old{m->d_slab_key, m->d_slab_count, m->d_pts, m->d_nrm};
+    slabs_free(old);
+    m->d_slab_key = s.key;
+    m->d_slab_count = s.count;
+    m->d_pts = s.pts;
+    m->d_nrm = s.nrm;
+    m->slab_cap = nc;
+    return LOM_OK;
+}
+
+static int read_words(lom_map *m, int first, int n)
+{
+    LOM_HIP(m, hipMemcpyAsync(m->h_flags, d_word(m, first), (size_t)n * 4, hipMemcpyDeviceToHost, m->stream));
+    LOM_HIP(m, hipStreamSynchronize(m->stream));
+    return LOM_OK;
+}
+
+static int add_points_device(lom_map *m, const char *d_xyz, const char *d_nrm, size_t n, size_t stride)
+{
+    if (n == 0) return LOM_OK;
+    if (n >= 0x7FFFFFFFull) return set_error(m, LOM_ERR_ARG, "too many points in one call");
+    const uint32_t N = (uint32_t)n;
+    int rc;
+    // 1. validate (a failing call inserts nothing)
+    LOM_HIP(m, hipMemsetAsync(d_word(m, 2), 0, 12, m->stream));  // flag, cursor, total
+    hipLaunchKernelGGL(k_validate, dim3(blocks_for(N)), dim3(kThreads), 0, m->stream, d_xyz, stride, N,
+                       m->voxel_size, d_word(m, 2));
+    LOM_HIP(m, hipGetLastError());
+    if ((rc = read_words(m, 2, 1)) != LOM_OK) return rc;
+    if (m->h_flags[0]) return set_error(m, LOM_ERR_RANGE, "coordinate / voxel_size out of range or not finite");
+    // 2. table capacity for the worst case (every point a new voxel); shrunk afterwards
+    const uint64_t worst = (uint64_t)m->n_vox + N;
+    if ((uint64_t)m->cap < 2 * worst) {
+        if ((rc = rehash(m, next_pow2(4 * worst))) != LOM_OK) return rc;
+    }
+    // 3. scratch
+    if ((rc = ensure(m, m->scr[S_PT_SLOT], (size_t)N * 4)) != LOM_OK) return rc;
+    if ((rc = ensure(m, m->scr[S_PT_POS], (size_t)N * 4)) != LOM_OK) return rc;
+    if ((rc = ensure(m, m->scr[S_FLAG], (size_t)N * 4)) != LOM_OK) return rc;
+    if ((rc = ensure(m, m->scr[S_RANK], (size_t)N * 4)) != LOM_OK) return rc;
+    if ((rc = ensure(m, m->scr[S_ITEMS], (size_t)N * 4)) != LOM_OK) return rc;
+    if ((rc = ensure(m, m->scr[S_BKT_CNT], (size_t)m->cap * 4)) != LOM_OK) return rc;
+    if ((rc = ensure(m, m->scr[S_BKT_HEAD], (size_t)m->cap * 4)) != LOM_OK) return rc;
+    if ((rc = ensure(m, m->scr[S_BKT_OFF], (size_t)m->cap * 4)) != LOM_OK) return rc;
+    if ((rc = ensure(m, m->scr[S_SCAN], scan_tmp_words(N) * 4)) != LOM_OK) return rc;
+    uint32_t *pt_slot = (uint32_t *)m->scr[S_PT_SLOT].p, *pt_pos = (uint32_t *)m->scr[S_PT_POS].p;
+    uint32_t *flag = (uint32_t *)m->scr[S_FLAG].p, *rank = (uint32_t *)m->scr[S_RANK].p;
+    uint32_t *items = (uint32_t *)m->scr[S_ITEMS].p;
+    uint32_t *bcnt = (uint32_t *)m->scr[S_BKT_CNT].p, *bhead = (uint32_t *)m->scr[S_BKT_HEAD].p;
+    uint32_t *boff = (uint32_t *)m->scr[S_BKT_OFF].p;
+    LOM_HIP(m, hipMemsetAsync(bcnt, 0, (size_t)m->cap * 4, m->stream));
+    LOM_HIP(m, hipMemsetAsync(bhead, 0xFF, (size_t)m->cap * 4, m->stream));
+    const MapView v = view_of(m);
+    const dim3 g(blocks_for(N)), b(kThreads);
+    hipLaunchKernelGGL(k_ins_claim, g, b, 0, m->stream, m->d_table, v.mask, v.shift, d_xyz, stride, N,
+                       m->voxel_size, pt_slot, pt_pos, bcnt, bhead);
+    hipLaunchKernelGGL(k_ins_heads, g, b, 0, m->stream, m->d_table, N, pt_slot, bcnt, bhead, boff, d_word(m, 3), flag);
+    LOM_HIP(m, hipGetLastError());
+    if ((rc = scan_exclusive(m, flag, rank, N, d_word(m, 4), (uint32_t *)m->scr[S_SCAN].p)) != LOM_OK) return rc;
+    if ((rc = read_words(m, 4, 1)) != LOM_OK) return rc;
+    const uint32_t n_new = m->h_flags[0];
+    if ((rc = ensure_slabs(m, (uint64_t)m->n_vox + n_new)) != LOM_OK) return rc;
+    hipLaunchKernelGGL(k_ins_assign, g, b, 0, m->stream, m->d_table, N, pt_slot, flag, rank, m->n_vox, m->d_slab_key);
+    hipLaunchKernelGGL(k_ins_scatter, g, b, 0, m->stream, N, pt_slot, pt_pos, boff, items);
+    hipLaunchKernelGGL(k_ins_place, g, b, 0, m->stream, m->d_table, N, pt_slot, bcnt, boff, items, d_xyz, d_nrm,
+                       stride, m->K, m->d_pts, m->d_nrm);
+    hipLaunchKernelGGL(k_ins_finalize, g, b, 0, m->stream, m->d_table, N, pt_slot, bcnt, bhead, m->K,
+                       m->d_slab_count, d_npoints(m));
+    LOM_HIP(m, hipGetLastError());
+    m->n_vox += n_new;
+    // 4. keep the table dense enough to stay cache-resident: load factor in (1/16, 1/2]
+    const uint32_t target = std::max(m->min_cap, next_pow2(4ull * m->n_vox));
+    if (m->cap > 4 * target) {
+        if ((rc = rehash(m, target)) != LOM_OK) return rc;
+    }
+    return LOM_OK;
+}
+
+static int stage_host_points(lom_map *m, const float *xyz, const float *nrm, size_t n, size_t stride,
+                             const char **d_xyz, const char **d_nrm)
+{
+    // Copy the caller's (possibly interleaved) records as they are; the kernels
+    // read them with the caller's stride, so PCL structs need no repacking.
+    int rc;
+    const size_t bytes = (n - 1) * stride + 12;
+    const char *hx = (const char *)xyz, *hn = (const char *)nrm;
+    *d_nrm = nullptr;
+    if (nrm && hn >= hx && (size_t)(hn - hx) + 12 <= stride) {  // normals inside the same record
+        const size_t all = (n - 1) * stride + (size_t)(hn - hx) + 12;
+        if ((rc = ensure(m, m->scr[S_IN_XYZ], all)) != LOM_OK) return rc;
+        LOM_HIP(m, hipMemcpyAsync(m->scr[S_IN_XYZ].p, hx, all, hipMemcpyHostToDevice, m->stream));
+        *d_xyz = (const char *)m->scr[S_IN_XYZ].p;
+        *d_nrm = *d_xyz + (hn - hx);
+        return LOM_OK;
+    }
+    if ((rc = ensure(m, m->scr[S_IN_XYZ], bytes)) != LOM_OK) return rc;
+    LOM_HIP(m, hipMemcpyAsync(m->scr[S_IN_XYZ].p, hx, bytes, hipMemcpyHostToDevice, m->stream));
+    *d_xyz = (const char *)m->scr[S_IN_XYZ].p;
+    if (nrm) {
+        if ((rc = ensure(m, m->scr[S_IN_NRM], bytes)) != LOM_OK) return rc;
+        LOM_HIP(m, hipMemcpyAsync(m->scr[S_IN_NRM].p, hn, bytes, hipMemcpyHostToDevice, m->stream));
+        *d_nrm = (const char *)m->scr[S_IN_NRM].p;
+    }
+    return LOM_OK;
+}
+
+}  // namespace lom
+
+using namespace lom;
+
+// ---------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------
+extern "C" {
+
+int lom_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+const char *lom_last_error(const lom_map *m) { return m ? m->last_error.c_str() : g_create_error.c_str(); }
+
+int lom_map_create(float voxel_size, size_t max_points, size_t capacity_hint, int device, lom_map **out)
+{
+    if (!out) return LOM_ERR_ARG;
+    *out = nullptr;
+    if (!(voxel_size > 0.f) || max_points == 0 || max_points > 65535)
+        return set_error(nullptr, LOM_ERR_ARG, "voxel_size must be > 0 and 1 <= max_points <= 65535");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        (void)hipGetLastError();
+        return set_error(nullptr, LOM_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU fallback)");
+    }
+    if (device < 0 || device >= ndev) return set_error(nullptr, LOM_ERR_ARG, "device index out of range");
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess)
+        return set_error(nullptr, LOM_ERR_NO_DEVICE, "hipGetDeviceProperties failed");
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        std::string s = std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only";
+        return set_error(nullptr, LOM_ERR_NO_DEVICE, s.c_str());
+    }
+    lom_map *m = new (std::nothrow) lom_map();
+    if (!m) return set_error(nullptr, LOM_ERR_OOM, "host allocation");
+    m->device = device;
+    m->voxel_size = voxel_size;
+    m->K = (uint32_t)max_points;
+    hipError_t e;
+    if ((e = hipSetDevice(device)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipHostMalloc((void **)&m->h_results, 1024 * sizeof(double), hipHostMallocDefault)) != hipSuccess ||
+        (e = hipHostMalloc((void **)&m->h_flags, 64 * sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess) {
+        set_error(nullptr, LOM_ERR_HIP, "handle setup", e);
+        lom_map_destroy(m);
+        return LOM_ERR_HIP;
+    }
+    m->stream = m->own_stream;
+    for (int i = 0; i < 4; i++)
+        if ((e = hipEventCreate(&m->ev[i])) != hipSuccess) {
+            set_error(nullptr, LOM_ERR_HIP, "hipEventCreate", e);
+            lom_map_destroy(m);
+            return LOM_ERR_HIP;
+        }
+    m->min_cap = next_pow2(4ull * std::max<size_t>(capacity_hint, 256));
+    int rc = ensure(m, m->scr[S_MISC], 256);
+    if (rc == LOM_OK) {
+        if (hipMemsetAsync(m->scr[S_MISC].p, 0, 256, m->stream) != hipSuccess) rc = LOM_ERR_HIP;
+    }
+    if (rc == LOM_OK) rc = table_alloc(m, m->min_cap, &m->d_table);
+    if (rc == LOM_OK) m->cap = m->min_cap;
+    if (rc == LOM_OK && hipStreamSynchronize(m->stream) != hipSuccess) rc = LOM_ERR_HIP;
+    if (rc != LOM_OK) {
+        g_create_error = m->last_error.empty() ? "map setup failed" : m->last_error;
+        lom_map_destroy(m);
+        return rc;
+    }
+    *out = m;
+    return LOM_OK;
+}
+
+void lom_map_destroy(lom_map *m)
+{
+    if (!m) return;
+    (void)hipSetDevice(m->device);
+    if (m->stream) (void)hipStreamSynchronize(m->stream);
+    if (m->comm) lom_comm_finalize(m);
+    if (m->d_table) (void)hipFree(m->d_table);
+    Slabs s{m->d_slab_key, m->d_slab_count, m->d_pts, m->d_nrm};
+    slabs_free(s);
+    for (auto &b : m->scr)
+        if (b.p) (void)hipFree(b.p);
+    for (DeviceBuf *b : {&m->scan_src, &m->scan_idx, &m->scan_on, &m->scan_stats, &m->partials, &m->results, &m->gather})
+        if (b->p) (void)hipFree(b->p);
+    if (m->h_results) (void)hipHostFree(m->h_results);
+    if (m->h_flags) (void)hipHostFree(m->h_flags);
+    for (auto &e : m->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (m->own_stream) (void)hipStreamDestroy(m->own_stream);
+    delete m;
+}
+
+int lom_map_set_stream(lom_map *m, void *hip_stream)
+{
+    if (!m) return LOM_ERR_ARG;
+    (void)hipSetDevice(m->device);
+    LOM_HIP(m, hipStreamSynchronize(m->stream));
+    m->stream = hip_stream ? (hipStream_t)hip_stream : m->own_stream;
+    return LOM_OK;
+}
+
+int lom_map_set_profiling(lom_map *m, int enabled)
+{
+    if (!m) return LOM_ERR_ARG;
+    m->profiling = enabled != 0;
+    return LOM_OK;
+}
+
+int lom_map_clear(lom_map *m, float voxel_size)
+{
+    if (!m || !(voxel_size > 0.f)) return LOM_ERR_ARG;
+    LOM_HIP(m, hipSetDevice(m->device));
+    m->voxel_size = voxel_size;
+    m->n_vox = 0;
+    m->n_points = 0;
+    hipLaunchKernelGGL(k_table_init, dim3(blocks_for(m->cap)), dim3(kThreads), 0, m->stream, m->d_table, m->cap);
+    LOM_HIP(m, hipGetLastError());
+    LOM_HIP(m, hipMemsetAsync(d_npoints(m), 0, 8, m->stream));
+    return LOM_OK;
+}
+
+int lom_map_set_max_points(lom_map *m, size_t max_points)
+{
+    if (!m || max_points == 0 || max_points > 65535) return LOM_ERR_ARG;
+    if (max_points == m->K) return LOM_OK;
+    if (m->n_vox != 0) return set_error(m, LOM_ERR_STATE, "max_points can only change while the map is empty");
+    LOM_HIP(m, hipSetDevice(m->device));
+    LOM_HIP(m, hipStreamSynchronize(m->stream));
+    Slabs s{m->d_slab_key, m->d_slab_count, m->d_pts, m->d_nrm};
+    slabs_free(s);
+    m->d_slab_key = nullptr;
+    m->d_slab_count = nullptr;
+    m->d_pts = m->d_nrm = nullptr;
+    m->slab_cap = 0;
+    m->K = (uint32_t)max_points;
+    return LOM_OK;
+}
+
+int lom_map_add_points_device(lom_map *m, const float *d_xyz, const float *d_nrm, size_t n, size_t stride)
+{
+    if (!m || (n && !d_xyz) || stride < 12 || (stride & 3)) return LOM_ERR_ARG;
+    LOM_HIP(m, hipSetDevice(m->device));
+    return add_points_device(m, (const char *)d_xyz, (const char *)d_nrm, n, stride);
+}
+
+int lom_map_add_points(lom_map *m, const float *xyz, const float *nrm, size_t n, size_t stride)
+{
+    if (!m || (n && !xyz) || stride < 12 || (stride & 3)) return LOM_ERR_ARG;
+    if (n == 0) return LOM_OK;
+    LOM_HIP(m, hipSetDevice(m->device));
+    const char *dx = nullptr, *dn = nullptr;
+    int rc = stage_host_points(m, xyz, nrm, n, stride, &dx, &dn);
+    if (rc != LOM_OK) return rc;
+    rc = add_points_device(m, dx, dn, n, stride);
+    // the staging copy reads the caller's buffer asynchronously: finish before returning
+    hipError_t e = hipStreamSynchronize(m->stream);
+    if (rc == LOM_OK && e != hipSuccess) return set_error(m, LOM_ERR_HIP, "hipStreamSynchronize", e);
+    return rc;
+}
+
+int lom_map_radius_cleanup(lom_map *m, const float center[3], float radius)
+{
+    if (!m || !center) return LOM_ERR_ARG;
+    if (m->n_vox == 0) return LOM_OK;
+    LOM_HIP(m, hipSetDevice(m->device));
+    int rc;
+    const uint32_t nv = m->n_vox;
+    if ((rc = ensure(m, m->scr[S_FLAG], (size_t)nv * 4)) != LOM_OK) return rc;
+    if ((rc = ensure(m, m->scr[S_RANK], (size_t)nv * 4)) != LOM_OK) return rc;
+    if ((rc = ensure(m, m->scr[S_SCAN], scan_tmp_words(nv) * 4)) != LOM_OK) return rc;
+    uint32_t *keep = (uint32_t *)m->scr[S_FLAG].p, *newid = (uint32_t *)m->scr[S_RANK].p;
+    const float r2 = radius * radius;  // voxel_grid.h:238
+    hipLaunchKernelGGL(k_cleanup_flag, dim3(blocks_for(nv)), dim3(kThreads), 0, m->stream, m->d_pts, m->K, nv,
+                       center[0], center[1], center[2], r2, keep);
+    LOM_HIP(m, hipGetLastError());
+    if ((rc = scan_exclusive(m, keep, newid, nv, d_word(m, 4), (uint32_t *)m->scr[S_SCAN].p)) != LOM_OK) return rc;
+    if ((rc = read_words(m, 4, 1)) != LOM_OK) return rc;
+    const uint32_t n_keep = m->h_flags[0];
+    if (n_keep == nv) return LOM_OK;
+    // stable compaction into a second set of slab arrays, then rebuild the table
+    Slabs dst;
+    if ((rc = slabs_alloc(m, m->slab_cap, dst)) != LOM_OK) return rc;
+    const size_t work = (size_t)nv * m->K;
+    hipLaunchKernelGGL(k_compact, dim3(blocks_for(work)), dim3(kThreads), 0, m->stream, keep, newid, nv, m->K,
+                       m->d_slab_key, m->d_slab_count, m->d_pts, m->d_nrm, dst.key, dst.count, dst.pts, dst.nrm);
+    LOM_HIP(m, hipGetLastError());
+    LOM_HIP(m, hipStreamSynchronize(m->stream));
+    Slabs old{m->d_slab_key, m->d_slab_count, m->d_pts, m->d_nrm};
+    slabs_free(old);
+    m->d_slab_key = dst.key;
+    m->d_slab_count = dst.count;
+    m->d_pts = dst.pts;
+    m->d_nrm = dst.nrm;
+    m->n_vox = n_keep;
+    const MapView v = view_of(m);
+    hipLaunchKernelGGL(k_table_init, dim3(blocks_for(m->cap)), dim3(kThreads), 0, m->stream, m->d_table, m->cap);
+    LOM_HIP(m, hipMemsetAsync(d_npoints(m), 0, 8, m->stream));
+    if (n_keep) {
+        hipLaunchKernelGGL(k_rebuild, dim3(blocks_for(n_keep)), dim3(kThreads), 0, m->stream, m->d_table, v.mask,
+                           v.shift, m->d_slab_key, m->d_slab_count, n_keep, d_npoints(m));
+    }
+    LOM_HIP(m, hipGetLastError());
+    return LOM_OK;
+}
+
+int64_t lom_map_size(const lom_map *m) { return m ? (int64_t)m->n_vox : LOM_ERR_ARG; }
+
+int64_t lom_map_point_count(const lom_map *cm)
+{
+    lom_map *m = const_cast<lom_map *>(cm);
+    if (!m) return LOM_ERR_ARG;
+    if (hipSetDevice(m->device) != hipSuccess) return LOM_ERR_HIP;
+    unsigned long long v = 0;
+    if (hipMemcpyAsync(m->h_flags, d_npoints(m), 8, hipMemcpyDeviceToHost, m->stream) != hipSuccess ||
+        hipStreamSynchronize(m->stream) != hipSuccess)
+        return set_error(m, LOM_ERR_HIP, "point count readback");
+    std::memcpy(&v, m->h_flags, 8);
+    return (int64_t)v;
+}
+
+int64_t lom_map_export(lom_map *m, int mode, float *xyz_out, float *nrm_out, size_t cap)
+{
+    if (!m || mode < 0 || mode > 2) return LOM_ERR_ARG;
+    if (m->n_vox == 0) return 0;
+    LOM_HIP(m, hipSetDevice(m->device));
+    int rc;
+    const uint32_t nv = m->n_vox;
+    if ((rc = ensure(m, m->scr[S_FLAG], (size_t)nv * 4)) != LOM_OK) return rc;
+    if ((rc = ensure(m, m->scr[S_RANK], (size_t)nv * 4)) != LOM_OK) return rc;
+    if ((rc = ensure(m, m->scr[S_SCAN], scan_tmp_words(nv) * 4)) != LOM_OK) return rc;
+    uint32_t *cnt = (uint32_t *)m->scr[S_FLAG].p, *off = (uint32_t *)m->scr[S_RANK].p;
+    hipLaunchKernelGGL(k_export_counts, dim3(blocks_for(nv)), dim3(kThreads), 0, m->stream, m->d_slab_count, nv, mode, cnt);
+    LOM_HIP(m, hipGetLastError());
+    if ((rc = scan_exclusive(m, cnt, off, nv, d_word(m, 4), (uint32_t *)m->scr[S_SCAN].p)) != LOM_OK) return rc;
+    if ((rc = read_words(m, 4, 1)) != LOM_OK) return rc;
+    const size_t total = m->h_flags[0];
+    if (!xyz_out || cap == 0) return (int64_t)total;
+    const bool want_n = nrm_out && mode == LOM_EXPORT_FULL;
+    if ((rc = ensure(m, m->scr[S_IN_XYZ], total * 12)) != LOM_OK) return rc;
+    if (want_n && (rc = ensure(m, m->scr[S_IN_NRM], total * 12)) != LOM_OK) return rc;
+    const size_t work = (size_t)nv * m->K;
+    hipLaunchKernelGGL(k_export_write, dim3(blocks_for(work)), dim3(kThreads), 0, m->stream, off, m->d_slab_count, nv,
+                       m->K, mode, m->d_pts, m->d_nrm, (float *)m->scr[S_IN_XYZ].p,
+                       want_n ? (float *)m->scr[S_IN_NRM].p : (float *)nullptr);
+    LOM_HIP(m, hipGetLastError());
+    const size_t take = std::min(total, cap);
+    LOM_HIP(m, hipMemcpyAsync(xyz_out, m->scr[S_IN_XYZ].p, take * 12, hipMemcpyDeviceToHost, m->stream));
+    if (want_n) LOM_HIP(m, hipMemcpyAsync(nrm_out, m->scr[S_IN_NRM].p, take * 12, hipMemcpyDeviceToHost, m->stream));
+    LOM_HIP(m, hipStreamSynchronize(m->stream));
+    return (int64_t)total;
+}
+
+}  // extern "C"

@@ -1005,6 +1005,7 @@ static void shard_sums(const orc_shard *s, const double q[4], const double t[3],
     out[28] = (double)s->nm;
     out[29] = s->cand;
     out[30] = s->occ;
+    out[31] = (double)s->n;
 }
 
 int orc_shard_match_eval(void *shard, const float pose_t[3], const float pose_q[4],

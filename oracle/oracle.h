@@ -98,7 +98,7 @@ int64_t orc_find_pairs(const orc_map *m, const float *src_xyz, size_t n, size_t 
 /* ---- reduced normal equations for fixed / fresh correspondences --------- */
 /* layout shared with the product's C ABI (include/lidar_odometry_amd.h):
  * [0..20] upper triangle of J^T W J (row-major, a<=b), [21..26] J^T W r,
- * [27] sum 0.5*rho(r^2), [28] n_valid, [29] n_cand, [30] n_occ, [31] 0.
+ * [27] sum 0.5*rho(r^2), [28] n_valid, [29] n_cand, [30] n_occ, [31] n_queries.
  * Tangent order: rotation(3) then translation(3).  Prior NOT included. */
 #define ORC_NSUMS 32
 

@@ -1,0 +1,369 @@
+"""Parity tests proper: the HIP path, called through the C ABI, against the CPU
+oracle on the same seeded inputs and against the committed golden fixtures.
+
+Bars: bit-exact for the integer/index work (voxel membership, order, winner
+index, counters) and for copied f32 payloads; 1e-4 m / 1e-4 rad for poses
+(BASELINE.json north_star)."""
+import ctypes as C
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from tests import scenes
+from tests.conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+POSE_TOL_M = 1e-4
+POSE_TOL_RAD = 1e-4
+
+
+def _both(lom, oracle, voxel, K):
+    return lom.VoxelGrid(voxel, K), oracle.VoxelGrid(voxel, K)
+
+
+def _assert_same_map(g, og):
+    assert g.size() == og.size()
+    assert g.pointCount() == og.pointCount()
+    xyz, nrm = g.getCloud()
+    oxyz, onrm = og.getCloud()
+    assert xyz.tobytes() == oxyz.tobytes()
+    assert nrm.tobytes() == onrm.tobytes()
+    assert g.getSparseCloudWithoutNormals().tobytes() == og.getSparseCloudWithoutNormals().tobytes()
+    assert g.getCloudWithoutNormals().tobytes() == oxyz.tobytes()
+
+
+def _assert_same_pairs(c, oc):
+    assert np.array_equal(c["index"], oc["index"])
+    assert c["origin"].tobytes() == oc["origin"].tobytes()
+    assert c["normal"].tobytes() == oc["normal"].tobytes()
+    assert c["sq_dist"].tobytes() == oc["sq_dist"].tobytes()
+    assert np.array_equal(c["n_cand"], oc["n_cand"])
+    assert np.array_equal(c["n_occ"], oc["n_occ"])
+
+
+# ---- reference unit tests through the product (test.cpp:26-75) -------------
+
+def test_unique_points(lom):
+    g = lom.VoxelGrid(0.5, 1)
+    g.addCloud(scenes.UNIQUE_POINTS, np.zeros_like(scenes.UNIQUE_POINTS))
+    assert g.size() == 7
+    xyz, _ = g.getCloud()
+    left = [tuple(p) for p in scenes.UNIQUE_POINTS]
+    for p in xyz:
+        left.remove(tuple(p))
+    assert not left
+
+
+def test_duplicate_points(lom):
+    g = lom.VoxelGrid(0.5, 1)
+    g.addCloud(scenes.DUPLICATE_POINTS, np.zeros_like(scenes.DUPLICATE_POINTS))
+    assert g.size() == 2
+    xyz, _ = g.getCloud()
+    assert len(xyz) == 2 and tuple(xyz[0]) != tuple(xyz[1])
+
+
+# ---- insert / export / cleanup parity ---------------------------------------
+
+def test_insert_semantics_small(lom, oracle):
+    pts = np.array([[-0.4, 0, 0], [0.4, 0, 0], [0.1, 0, 0], [0.2, 0, 0], [-0.6, 0, 0]], np.float32)
+    g, og = _both(lom, oracle, 0.5, 3)
+    g.addCloudWithoutNormals(pts)
+    og.addCloudWithoutNormals(pts)
+    _assert_same_map(g, og)
+    assert g.size() == 2 and g.pointCount() == 4
+
+
+def test_empty_inputs(lom):
+    g = lom.VoxelGrid(0.5, 20)
+    g.addCloudWithoutNormals(np.zeros((0, 3), np.float32))
+    assert g.size() == 0 and g.pointCount() == 0
+    assert len(g.getCloudWithoutNormals()) == 0
+    c = g.findMatchingPairs(scenes.UNIQUE_POINTS, lom.Pose3D(), 0.3)
+    assert (c["index"] == -1).all()
+    g.radiusCleanup((0, 0, 0), 1.0)
+    pose = lom.CloudMatcher().align(g, np.zeros((0, 3), np.float32), lom.Pose3D((1, 2, 3), (1, 0, 0, 0)))
+    assert np.allclose(pose.translation, (1, 2, 3))
+
+
+@pytest.mark.parametrize("voxel,K", [(0.25, 20), (0.5, 1), (0.1, 1), (0.2, 20), (0.5, 3)])
+def test_insert_parity_fixture(lom, oracle, fixture_cloud, voxel, K):
+    xyz, xyzn = fixture_cloud
+    g, og = _both(lom, oracle, voxel, K)
+    # several calls: later calls must append to voxels created by earlier ones, up to the cap
+    n = len(xyzn)
+    cuts = [0, n // 3, n // 3 + 1, 2 * n // 3, n]
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        g.addCloud(xyzn[a:b, :3], xyzn[a:b, 3:])
+        og.addCloud(xyzn[a:b, :3], xyzn[a:b, 3:])
+    _assert_same_map(g, og)
+
+
+def test_insert_interleaved_records(lom, oracle, fixture_cloud):
+    """pcl::PointNormal-shaped 48-byte records passed without repacking."""
+    _, xyzn = fixture_cloud
+    n = 5000
+    rec = np.zeros((n, 12), np.float32)
+    rec[:, 0:3] = xyzn[:n, :3]
+    rec[:, 4:7] = xyzn[:n, 3:]
+    g, og = _both(lom, oracle, 0.25, 20)
+    g.addCloudInterleaved(rec, 48, 16)
+    og.addCloud(xyzn[:n, :3], xyzn[:n, 3:])
+    _assert_same_map(g, og)
+
+
+def test_insert_heavy_duplicates_and_order(lom, oracle):
+    """Many points per voxel, shuffled: the kept set is the first K in input order."""
+    rng = np.random.default_rng(7)
+    pts = (rng.random((20000, 3)) * 2.0 - 1.0).astype(np.float32)   # 4^3..5^3 voxels of 0.5 m
+    nrm = rng.standard_normal((20000, 3)).astype(np.float32)
+    g, og = _both(lom, oracle, 0.5, 20)
+    g.addCloud(pts, nrm)
+    og.addCloud(pts, nrm)
+    _assert_same_map(g, og)
+    g.addCloud(pts[::-1].copy(), nrm)          # all voxels already full: no change
+    og.addCloud(pts[::-1].copy(), nrm)
+    _assert_same_map(g, og)
+
+
+def test_out_of_range_rejected_and_nothing_inserted(lom):
+    g = lom.VoxelGrid(0.5, 20)
+    g.addCloudWithoutNormals(scenes.UNIQUE_POINTS)
+    bad = np.array([[0.3, 0.3, 0.3], [1e9, 0, 0]], np.float32)
+    with pytest.raises(lom.LomError) as e:
+        g.addCloudWithoutNormals(bad)
+    assert e.value.code == lom.capi.ERR_RANGE
+    nanp = np.array([[np.nan, 0, 0]], np.float32)
+    with pytest.raises(lom.LomError):
+        g.addCloudWithoutNormals(nanp)
+    assert g.size() == 7 and g.pointCount() == 7
+
+
+def test_set_voxel_size_clears_and_set_max_points(lom):
+    g = lom.VoxelGrid(0.5, 1)
+    g.addCloudWithoutNormals(scenes.UNIQUE_POINTS)
+    with pytest.raises(lom.LomError):
+        g.setMaxPoints(5)                      # only while empty
+    g.setVoxelSize(0.25)                       # voxel_grid.h:61-66
+    assert g.size() == 0 and g.pointCount() == 0
+    g.setMaxPoints(5)
+    g.addCloudWithoutNormals(np.repeat(scenes.UNIQUE_POINTS, 7, axis=0))
+    assert g.size() == 7 and g.pointCount() == 35
+
+
+def test_radius_cleanup_parity(lom, oracle, fixture_cloud):
+    _, xyzn = fixture_cloud
+    g, og = _both(lom, oracle, 0.25, 20)
+    g.addCloud(xyzn[:, :3], xyzn[:, 3:])
+    og.addCloud(xyzn[:, :3], xyzn[:, 3:])
+    for center, r in (((0, 5, 0), 80.0), ((10, 5, -20), 40.0), ((10, 5, -20), 40.0), ((0, 0, 0), 5.0)):
+        g.radiusCleanup(center, r)
+        og.radiusCleanup(center, r)
+        _assert_same_map(g, og)
+    # insert after cleanup: slabs were compacted, creation order continues
+    g.addCloud(xyzn[:3000, :3], xyzn[:3000, 3:])
+    og.addCloud(xyzn[:3000, :3], xyzn[:3000, 3:])
+    _assert_same_map(g, og)
+    c = g.findMatchingPairs(xyzn[:2000, :3], lom.Pose3D(), 0.3)
+    oc = og.findMatchingPairs(xyzn[:2000, :3], oracle.Pose3D(), 0.3)
+    _assert_same_pairs(c, oc)
+
+
+# ---- correspondence parity ----------------------------------------------------
+
+def test_strict_min_first_wins(lom, oracle):
+    pts = np.array([[0.6, 0.1, 0.1], [-0.1, 0.1, 0.1]], np.float32)
+    nrm = np.array([[1, 0, 0], [0, 1, 0]], np.float32)
+    g, og = _both(lom, oracle, 0.5, 20)
+    g.addCloud(pts, nrm)
+    og.addCloud(pts, nrm)
+    q = np.array([[0.25, 0.1, 0.1]], np.float32)
+    for d in (0.5, 0.35, 0.3):
+        _assert_same_pairs(g.findMatchingPairs(q, lom.Pose3D(), d), og.findMatchingPairs(q, oracle.Pose3D(), d))
+    assert g.findMatchingPairs(q, lom.Pose3D(), 0.5)["index"][0] == 20
+
+
+def test_find_pairs_parity_fixture(lom, oracle, fixture_cloud):
+    xyz, xyzn = fixture_cloud
+    g, og = _both(lom, oracle, 0.25, 20)
+    g.addCloud(xyzn[:, :3], xyzn[:, 3:])
+    og.addCloud(xyzn[:, :3], xyzn[:, 3:])
+    vf = oracle.VoxelGrid(0.5, 1)
+    vf.addCloudWithoutNormals(xyz)
+    sub = vf.getCloudWithoutNormals()
+    valid = []
+    for t, q in scenes.matching_guess_poses():
+        c = g.findMatchingPairs(sub, lom.Pose3D(t, q), 0.3)
+        oc = og.findMatchingPairs(sub, oracle.Pose3D(t, q), 0.3)
+        _assert_same_pairs(c, oc)
+        valid.append(int((c["index"] >= 0).sum()))
+    assert valid[0] > 5000 and min(valid) > 1000
+
+
+def test_find_pairs_parity_synth_and_golden(lom, oracle):
+    with open(os.path.join(GOLDEN, "synth_small.json")) as f:
+        gold = json.load(f)
+    sm = scenes.small_synth_case()
+    g, og = _both(lom, oracle, 0.5, 20)
+    g.addCloud(sm["map_xyz"], sm["map_nrm"])
+    og.addCloud(sm["map_xyz"], sm["map_nrm"])
+    _assert_same_map(g, og)
+    c = g.findMatchingPairs(sm["scan"], lom.Pose3D(), 0.3)
+    _assert_same_pairs(c, og.findMatchingPairs(sm["scan"], oracle.Pose3D(), 0.3))
+    idx = c["index"].astype("<i8")
+    assert hashlib.sha256(idx.tobytes()).hexdigest() == gold["winner_sha256"]
+    assert int(c["n_cand"].sum()) == gold["cand_total"] and int(c["n_occ"].sum()) == gold["occ_total"]
+    # a rotated / translated pose exercises the f64 transform + f32 cast path
+    pose = (0.31, -0.2, 0.05), scenes.angle_axis_q(0.03, scenes._unit((0.1, 0.2, 1.0)))
+    _assert_same_pairs(g.findMatchingPairs(sm["scan"], lom.Pose3D(*pose), 0.3),
+                       og.findMatchingPairs(sm["scan"], oracle.Pose3D(*pose), 0.3))
+
+
+def test_zero_normals_are_valid_matches(lom):
+    g = lom.VoxelGrid(0.5, 20)
+    g.addCloudWithoutNormals(scenes.UNIQUE_POINTS)
+    c = g.findMatchingPairs(scenes.UNIQUE_POINTS + np.float32(0.01), lom.Pose3D(), 0.3)
+    assert (c["index"] >= 0).all() and not c["normal"].any()
+
+
+# ---- align parity ---------------------------------------------------------------
+
+def test_matching_test_protocol_and_golden(lom, oracle, fixture_cloud):
+    """test/test.cpp:191-264 through the product; tolerances of the reference test, then the
+    1e-4 bar against the oracle's golden poses."""
+    xyz, xyzn = fixture_cloud
+    res = scenes.run_matching_test(lom, xyz, xyzn)
+    with open(os.path.join(GOLDEN, "c1_matching_test.json")) as f:
+        gold = json.load(f)
+    assert res["source_points"] == gold["source_points"] == 9043
+    assert res["keyframe_voxels"] == gold["keyframe_voxels"]
+    assert res["keyframe_points"] == gold["keyframe_points"]
+    for c, gcase in zip(res["cases"], gold["cases"]):
+        assert c["err_t_norm"] < 0.05 and c["rot_err"] < 0.01          # test.cpp:261-262
+        dt, dr = scenes.pose_delta(c["final_t"], c["final_q_wxyz"], gcase["final_t"], gcase["final_q_wxyz"])
+        assert dt < POSE_TOL_M and dr < POSE_TOL_RAD, (dt, dr)
+        assert c["stats"]["outer_iterations"] == gcase["stats"]["outer_iterations"]
+        assert c["stats"]["cand_total"] == gcase["stats"]["cand_total"]
+        assert c["stats"]["valid_last"] == gcase["stats"]["valid_last"]
+
+
+def test_align_parity_synth(lom, oracle):
+    with open(os.path.join(GOLDEN, "synth_small.json")) as f:
+        gold = json.load(f)
+    sm = scenes.small_synth_case()
+    g, og = _both(lom, oracle, 0.5, 20)
+    g.addCloud(sm["map_xyz"], sm["map_nrm"])
+    og.addCloud(sm["map_xyz"], sm["map_nrm"])
+    m, om = lom.CloudMatcher(), oracle.CloudMatcher()
+    for guess in (((0, 0, 0), (1, 0, 0, 0)), ((0.08, -0.03, 0.0), scenes.angle_axis_q(0.012, (0, 0, 1)))):
+        p = m.align(g, sm["scan"], lom.Pose3D(*guess))
+        o = om.align(og, sm["scan"], oracle.Pose3D(*guess))
+        dt, dr = scenes.pose_delta(p.translation, p.rotation, o.translation, o.rotation)
+        assert dt < POSE_TOL_M and dr < POSE_TOL_RAD, (dt, dr)
+        assert m.stats["outer_iterations"] == om.stats["outer_iterations"]
+        assert m.stats["queries"] == om.stats["queries"]
+        assert m.stats["cand_total"] == om.stats["cand_total"]
+    p = m.align(g, sm["scan"], lom.Pose3D())
+    dt, dr = scenes.pose_delta(p.translation, p.rotation, gold["final_t"], gold["final_q_wxyz"])
+    assert dt < POSE_TOL_M and dr < POSE_TOL_RAD
+
+
+def test_zero_matches_returns_guess(lom):
+    g = lom.VoxelGrid(0.5, 20)
+    g.addCloudWithoutNormals(np.array([[50, 50, 50]], np.float32))
+    m = lom.CloudMatcher()
+    gq = scenes.angle_axis_q(0.1, (0, 0, 1))
+    out = m.align(g, scenes.UNIQUE_POINTS, lom.Pose3D((1, 2, 3), gq))
+    assert np.allclose(out.translation, (1, 2, 3), atol=1e-6)
+    assert abs(abs(float(np.dot(out.rotation, gq))) - 1) < 1e-6
+    assert m.stats["outer_iterations"] == 5 and m.stats["valid_last"] == 0
+
+
+def test_align_device_resident_source(lom):
+    """Source cloud handed over as a device pointer (torch is only the allocator here)."""
+    import torch
+
+    sm = scenes.small_synth_case()
+    g = lom.VoxelGrid(0.5, 20)
+    g.addCloud(sm["map_xyz"], sm["map_nrm"])
+    m = lom.CloudMatcher()
+    host = m.align(g, sm["scan"], lom.Pose3D())
+    d = torch.from_numpy(sm["scan"]).to("cuda:0")
+    torch.cuda.synchronize()
+    dev = m.alignDevice(g, d.data_ptr(), d.shape[0], lom.Pose3D())
+    assert host.translation.tobytes() == dev.translation.tobytes()
+    assert host.rotation.tobytes() == dev.rotation.tobytes()
+    # device-resident insert
+    mp = torch.from_numpy(sm["map_xyz"]).to("cuda:0")
+    mn = torch.from_numpy(sm["map_nrm"]).to("cuda:0")
+    torch.cuda.synchronize()
+    g2 = lom.VoxelGrid(0.5, 20)
+    g2.addCloudDevice(mp.data_ptr(), mn.data_ptr(), mp.shape[0])
+    assert g2.getCloud()[0].tobytes() == g.getCloud()[0].tobytes()
+
+
+# ---- full BASELINE.json sizes: size-independent properties ----------------------
+
+@pytest.fixture(scope="module")
+def c2_case():
+    return scenes.synth_case(16, 1800, 500_000)
+
+
+def test_c2_full_size_properties(lom, oracle, c2_case):
+    """C2 (VLP16 ~30k-pt scan vs 500k-pt map, 0.5 m voxels).  The oracle still finishes
+    in seconds at this size, so: exact map parity, exact winners, pose bar; plus
+    properties: determinism (bitwise repeatable), idempotence of insert, sharding
+    linearity of the reduced sums."""
+    c = c2_case
+    g, og = _both(lom, oracle, 0.5, 20)
+    g.addCloud(c["map_xyz"], c["map_nrm"])
+    og.addCloud(c["map_xyz"], c["map_nrm"])
+    assert g.size() == og.size() and g.pointCount() == og.pointCount()
+    assert g.getCloud()[0].tobytes() == og.getCloud()[0].tobytes()
+    pairs = g.findMatchingPairs(c["scan"], lom.Pose3D(), 0.3)
+    _assert_same_pairs(pairs, og.findMatchingPairs(c["scan"], oracle.Pose3D(), 0.3, nthreads=4))
+    m, om = lom.CloudMatcher(), oracle.CloudMatcher(nthreads=4)
+    p = m.align(g, c["scan"], lom.Pose3D())
+    o = om.align(og, c["scan"], oracle.Pose3D())
+    dt, dr = scenes.pose_delta(p.translation, p.rotation, o.translation, o.rotation)
+    assert dt < POSE_TOL_M and dr < POSE_TOL_RAD, (dt, dr)
+    assert m.stats["outer_iterations"] == om.stats["outer_iterations"]
+    # recovers the simulated motion where the scene constrains it (y: walls, z: ground, yaw)
+    assert abs(p.translation[1] - c["true_t"][1]) < 0.01 and abs(p.translation[2] - c["true_t"][2]) < 0.01
+    assert scenes.pose_delta((0, 0, 0), p.rotation, (0, 0, 0), c["true_q"])[1] < 2e-3
+    # determinism: same call, same bits
+    p2 = m.align(g, c["scan"], lom.Pose3D())
+    assert p.translation.tobytes() == p2.translation.tobytes() and p.rotation.tobytes() == p2.rotation.tobytes()
+    # idempotence: re-inserting the same cloud into full/partial voxels changes nothing for
+    # voxels already at the cap and never reorders existing points
+    before = g.getCloud()[0]
+    g.addCloud(c["map_xyz"], c["map_nrm"])
+    og.addCloud(c["map_xyz"], c["map_nrm"])
+    after = g.getCloud()[0]
+    assert after.tobytes() == og.getCloud()[0].tobytes()
+    assert g.size() == og.size()
+    assert len(after) >= len(before)
+
+
+def test_c3_full_size_properties(lom, oracle):
+    """C3 (64-beam ~130k-pt scan vs 2M-pt map): counts and checksums of winners against the
+    oracle (search only: ~1 s of oracle time), plus align determinism and pose bar."""
+    c = scenes.synth_case(64, 2048, 2_000_000)
+    g, og = _both(lom, oracle, 0.5, 20)
+    g.addCloud(c["map_xyz"], c["map_nrm"])
+    og.addCloud(c["map_xyz"], c["map_nrm"])
+    assert g.size() == og.size() and g.pointCount() == og.pointCount()
+    pairs = g.findMatchingPairs(c["scan"], lom.Pose3D(), 0.3)
+    opairs = og.findMatchingPairs(c["scan"], oracle.Pose3D(), 0.3, nthreads=4)
+    assert np.array_equal(pairs["index"], opairs["index"])
+    assert int(pairs["n_cand"].sum()) == int(opairs["n_cand"].sum())
+    m, om = lom.CloudMatcher(), oracle.CloudMatcher(nthreads=4)
+    p = m.align(g, c["scan"], lom.Pose3D())
+    o = om.align(og, c["scan"], oracle.Pose3D())
+    dt, dr = scenes.pose_delta(p.translation, p.rotation, o.translation, o.rotation)
+    assert dt < POSE_TOL_M and dr < POSE_TOL_RAD, (dt, dr)
+    p2 = m.align(g, c["scan"], lom.Pose3D())
+    assert p.translation.tobytes() == p2.translation.tobytes()
