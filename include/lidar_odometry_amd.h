@@ -138,7 +138,6 @@ typedef struct {
     double final_cost;
     double last_step_norm;
     double match_kernel_ms;    /* HIP-event time of the correspondence launches (profiling on) */
-    double eval_kernel_ms;     /* HIP-event time of the evaluation launches (profiling on)     */
     double algorithmic_bytes;  /* sum over queries of 444 + 12*cand + 12*valid     */
 } lom_align_stats;
 

@@ -47,7 +47,7 @@ class AlignStats(C.Structure):
         ("outer_iterations", C.c_int32), ("lm_iterations", C.c_int32), ("evaluations", C.c_int32),
         ("match_launches", C.c_int32), ("queries", C.c_int64), ("valid_last", C.c_int64),
         ("cand_total", C.c_int64), ("occ_total", C.c_int64), ("final_cost", C.c_double),
-        ("last_step_norm", C.c_double), ("match_kernel_ms", C.c_double), ("eval_kernel_ms", C.c_double),
+        ("last_step_norm", C.c_double), ("match_kernel_ms", C.c_double),
         ("algorithmic_bytes", C.c_double),
     ]
 

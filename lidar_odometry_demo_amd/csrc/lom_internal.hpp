@@ -4,6 +4,7 @@
 
 #include <cstdint>
 #include <string>
+#include <vector>
 
 #include "../../include/lidar_odometry_amd.h"
 
@@ -108,11 +109,18 @@ struct lom_map {
     lom::DeviceBuf scan_src, scan_idx, scan_on, scan_stats, partials, results;
 
     // pinned host result buffer
-    double *h_results = nullptr;  // 64 doubles
-    uint32_t *h_flags = nullptr;  // 16 words
+    double *h_results = nullptr;  // 1024 doubles (rank-ordered gather of up to 32 ranks)
+    uint32_t *h_flags = nullptr;  // 64 words
+    // mailbox: k_finish stores LOM_NSUMS doubles + a sequence word directly into
+    // coherent (fine-grained) pinned host memory; the host polls the word instead of
+    // paying a copy kernel plus hipStreamSynchronize per residual evaluation.
+    double *h_mail = nullptr;             // host view: [0..31] sums, [32] sequence (as u64 bits)
+    double *d_mail = nullptr;             // device view of the same allocation
+    unsigned long long mail_seq = 0;
+    double last_counters[4] = {0, 0, 0, 0};  // valid, cand, occ, queries of the last k_match
 
     bool profiling = false;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    std::vector<hipEvent_t> prof_events;  // pairs around each k_match launch of one align
 
     // RCCL
     void *comm = nullptr;

@@ -49,9 +49,10 @@ struct __attribute__((aligned(8))) QStat {
 __global__ __launch_bounds__(kMatchThreads) void k_match(MapView map, const char *__restrict__ src, size_t stride,
                                                          uint32_t n, PoseArgs P, int32_t *__restrict__ out_idx,
                                                          float *__restrict__ out_on, QStat *__restrict__ out_stat,
-                                                         unsigned long long *__restrict__ counters)
+                                                         uint32_t *__restrict__ block_counters)
 {
     __shared__ uint2 s_nb[kGroupsPerBlock][28];  // compacted occupied neighbours: (count, slab)
+    __shared__ uint32_t s_cnt[kGroupsPerBlock][3];
     const int lane = threadIdx.x & 63;
     const int hl = lane & 31;
     const int half = lane >> 5;
@@ -59,7 +60,7 @@ __global__ __launch_bounds__(kMatchThreads) void k_match(MapView map, const char
     const uint32_t groups_total = gridDim.x * kGroupsPerBlock;
     // neighbour offset of this lane, scan order ix (outer), iy, iz (inner)
     const int dxn = hl / 9 - 1, dyn = (hl / 3) % 3 - 1, dzn = hl % 3 - 1;
-    unsigned long long acc_cand = 0, acc_occ = 0, acc_valid = 0;
+    uint32_t acc_cand = 0, acc_occ = 0, acc_valid = 0;
 
     for (uint32_t q = blockIdx.x * kGroupsPerBlock + grp; q < n; q += groups_total) {
         const float *sp = reinterpret_cast<const float *>(src + (size_t)q * stride);
@@ -165,10 +166,19 @@ __global__ __launch_bounds__(kMatchThreads) void k_match(MapView map, const char
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
-    if (hl == 0 && (acc_cand | acc_occ | acc_valid)) {
-        atomicAdd(&counters[0], acc_valid);
-        atomicAdd(&counters[1], acc_cand);
-        atomicAdd(&counters[2], acc_occ);
+    // per-block counters, summed in fixed order by k_finish (no same-address atomics:
+    // one word saturates at ~88 atomics/us, MI355X_MICROARCH.md "dequeue")
+    if (hl == 0) {
+        s_cnt[grp][0] = acc_valid;
+        s_cnt[grp][1] = acc_cand;
+        s_cnt[grp][2] = acc_occ;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int g = 0; g < kGroupsPerBlock; g++) v += s_cnt[g][threadIdx.x];
+        block_counters[blockIdx.x * 4 + threadIdx.x] = v;
     }
 }
 
@@ -272,20 +282,69 @@ __global__ __launch_bounds__(kEvalThreads) void k_eval(const char *__restrict__ 
     }
 }
 
-// fixed-order final sum -> LOM_NSUMS doubles; counters from the last k_match
-__global__ void k_finish(const double *__restrict__ partials, uint32_t n_blocks,
-                         const unsigned long long *__restrict__ counters, uint32_t n_queries,
-                         double *__restrict__ out)
+// fixed-order final sum -> LOM_NSUMS doubles (bitwise run-to-run reproducible).
+// 1024 threads: 32 strided partial sums per output, then a fixed-order LDS pass.
+// The counters of the last k_match are summed only when asked for (they do not
+// change between the evaluations of one outer iteration).
+// Results go to `out` (device) and, when `mail` is set, straight into coherent
+// pinned host memory followed by a system-scope release store of `seq`.
+constexpr int kFinishThreads = 1024;
+__global__ __launch_bounds__(kFinishThreads) void k_finish(const double *__restrict__ partials, uint32_t n_blocks,
+                                                           const uint32_t *__restrict__ block_counters,
+                                                           uint32_t n_match_blocks, uint32_t n_queries,
+                                                           double *__restrict__ out, double *mail,
+                                                           unsigned long long seq)
 {
-    const int k = threadIdx.x;
-    if (k < 28) {
-        double v = 0.0;
-        for (uint32_t b = 0; b < n_blocks; b++) v += partials[(size_t)b * 28 + k];
-        out[k] = v;
-    } else if (k < 31) {
-        out[k] = (double)counters[k - 28];
-    } else if (k == 31) {
-        out[k] = (double)n_queries;
+    __shared__ double s_part[32][33];
+    __shared__ unsigned long long s_cnt[kFinishThreads / 64][3];
+    const int k = threadIdx.x & 31, part = threadIdx.x >> 5;
+    double v = 0.0;
+    if (k < 28)
+        for (uint32_t b = part; b < n_blocks; b += 32) v += partials[(size_t)b * 28 + k];
+    s_part[part][k] = v;
+    unsigned long long c0 = 0, c1 = 0, c2 = 0;
+    for (uint32_t b = threadIdx.x; b < n_match_blocks; b += kFinishThreads) {
+        const uint4 r = *reinterpret_cast<const uint4 *>(block_counters + (size_t)b * 4);
+        c0 += r.x;
+        c1 += r.y;
+        c2 += r.z;
+    }
+    if (n_match_blocks) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            c0 += __shfl_xor(c0, d, 64);
+            c1 += __shfl_xor(c1, d, 64);
+            c2 += __shfl_xor(c2, d, 64);
+        }
+        if ((threadIdx.x & 63) == 0) {
+            s_cnt[threadIdx.x >> 6][0] = c0;
+            s_cnt[threadIdx.x >> 6][1] = c1;
+            s_cnt[threadIdx.x >> 6][2] = c2;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        double t = 0.0;
+        if (threadIdx.x < 28) {
+#pragma unroll
+            for (int p = 0; p < 32; p++) t += s_part[p][threadIdx.x];
+        } else if (threadIdx.x < 31) {
+            unsigned long long c = 0;
+            if (n_match_blocks)
+                for (int w = 0; w < kFinishThreads / 64; w++) c += s_cnt[w][threadIdx.x - 28];
+            t = (double)c;
+        } else {
+            t = (double)n_queries;
+        }
+        out[threadIdx.x] = t;
+        if (mail) {
+            mail[threadIdx.x] = t;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // system scope: payload before the flag
+            // all 32 lanes are one wave: lane 0 publishes after the wave's stores
+            if (threadIdx.x == 0)
+                __hip_atomic_store(reinterpret_cast<unsigned long long *>(mail + 32), seq, __ATOMIC_RELEASE,
+                                   __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
@@ -301,10 +360,11 @@ static void pose_args(const float t[3], const float q[4], float max_dist, PoseAr
     P.max_sq = max_dist * max_dist;  // voxel_grid.h:215
 }
 
+constexpr uint32_t kMaxMatchBlocks = 256u * 8u;
 static uint32_t match_grid(uint32_t n)
 {
     const uint32_t need = (n + kGroupsPerBlock - 1) / kGroupsPerBlock;
-    return std::max(1u, std::min(need, 256u * 8u));
+    return std::max(1u, std::min(need, kMaxMatchBlocks));
 }
 
 static uint32_t eval_grid(uint32_t n)
@@ -318,8 +378,8 @@ struct ScanCtx {
     const char *d_src;
     size_t stride;
     uint32_t n;
-    uint32_t eval_blocks;
-    float match_ms = 0.f, eval_ms = 0.f;
+    uint32_t match_blocks;
+    int prof_used = 0;
 };
 
 static int scan_buffers(lom_map *m, uint32_t n, bool want_stats)
@@ -330,11 +390,11 @@ static int scan_buffers(lom_map *m, uint32_t n, bool want_stats)
     if ((rc = ensure(m, m->scan_on, nn * 24)) != LOM_OK) return rc;
     if (want_stats && (rc = ensure(m, m->scan_stats, nn * sizeof(QStat))) != LOM_OK) return rc;
     if ((rc = ensure(m, m->partials, (size_t)512 * 28 * 8)) != LOM_OK) return rc;
-    if ((rc = ensure(m, m->results, 4096)) != LOM_OK) return rc;
+    if ((rc = ensure(m, m->results, 1024 + (size_t)kMaxMatchBlocks * 16)) != LOM_OK) return rc;
     return LOM_OK;
 }
 
-static unsigned long long *d_counters(lom_map *m) { return (unsigned long long *)((char *)m->results.p + 1024); }
+static uint32_t *d_block_counters(lom_map *m) { return (uint32_t *)((char *)m->results.p + 1024); }
 static double *d_sums(lom_map *m) { return (double *)m->results.p; }
 
 static int launch_match(ScanCtx &c, const float t[3], const float q[4], float max_dist, bool stats)
@@ -342,36 +402,49 @@ static int launch_match(ScanCtx &c, const float t[3], const float q[4], float ma
     lom_map *m = c.m;
     PoseArgs P;
     pose_args(t, q, max_dist, P);
-    LOM_HIP(m, hipMemsetAsync(d_counters(m), 0, 32, m->stream));
+    c.match_blocks = c.n ? match_grid(c.n) : 0;
     if (c.n) {
-        if (m->profiling) LOM_HIP(m, hipEventRecord(m->ev[0], m->stream));
-        hipLaunchKernelGGL(k_match, dim3(match_grid(c.n)), dim3(kMatchThreads), 0, m->stream, view_of(m), c.d_src,
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (m->profiling) {
+            // one event pair per launch, read back once at the end of the align
+            while (m->prof_events.size() < (size_t)(c.prof_used + 1) * 2) {
+                hipEvent_t e;
+                LOM_HIP(m, hipEventCreate(&e));
+                m->prof_events.push_back(e);
+            }
+            e0 = m->prof_events[(size_t)c.prof_used * 2];
+            e1 = m->prof_events[(size_t)c.prof_used * 2 + 1];
+            c.prof_used++;
+            LOM_HIP(m, hipEventRecord(e0, m->stream));
+        }
+        hipLaunchKernelGGL(k_match, dim3(c.match_blocks), dim3(kMatchThreads), 0, m->stream, view_of(m), c.d_src,
                            c.stride, c.n, P, (int32_t *)m->scan_idx.p, (float *)m->scan_on.p,
-                           stats ? (QStat *)m->scan_stats.p : (QStat *)nullptr, d_counters(m));
+                           stats ? (QStat *)m->scan_stats.p : (QStat *)nullptr, d_block_counters(m));
         LOM_HIP(m, hipGetLastError());
-        if (m->profiling) LOM_HIP(m, hipEventRecord(m->ev[1], m->stream));
+        if (m->profiling) LOM_HIP(m, hipEventRecord(e1, m->stream));
     }
     return LOM_OK;
 }
 
 // evaluation at (q,t) -> host sums (rank-local, or rank-ordered total with a communicator)
-static int launch_eval(ScanCtx &c, const double q[4], const double t[3], double out[LOM_NSUMS])
+static int launch_eval(ScanCtx &c, const double q[4], const double t[3], bool fresh_match, double out[LOM_NSUMS])
 {
     lom_map *m = c.m;
     EvalArgs E;
     for (int i = 0; i < 4; i++) E.q[i] = q[i];
     for (int i = 0; i < 3; i++) E.t[i] = t[i];
     const uint32_t nb = c.n ? eval_grid(c.n) : 0;
-    if (m->profiling) LOM_HIP(m, hipEventRecord(m->ev[2], m->stream));
+    const bool mailbox = (m->comm == nullptr);
+    const unsigned long long seq = ++m->mail_seq;
     if (nb) {
         hipLaunchKernelGGL(k_eval, dim3(nb), dim3(kEvalThreads), 0, m->stream, c.d_src, c.stride, c.n,
                            (const int32_t *)m->scan_idx.p, (const float *)m->scan_on.p, E, (double *)m->partials.p);
     }
-    hipLaunchKernelGGL(k_finish, dim3(1), dim3(64), 0, m->stream, (const double *)m->partials.p, nb,
-                       (const unsigned long long *)d_counters(m), c.n, d_sums(m));
+    hipLaunchKernelGGL(k_finish, dim3(1), dim3(kFinishThreads), 0, m->stream, (const double *)m->partials.p, nb,
+                       (const uint32_t *)d_block_counters(m), fresh_match ? c.match_blocks : 0u, c.n, d_sums(m),
+                       mailbox ? m->d_mail : (double *)nullptr, seq);
     LOM_HIP(m, hipGetLastError());
-    if (m->profiling) LOM_HIP(m, hipEventRecord(m->ev[3], m->stream));
-    if (m->comm) {
+    if (!mailbox) {
         int rc = ensure(m, m->gather, (size_t)m->nranks * LOM_NSUMS * 8);
         if (rc != LOM_OK) return rc;
         rc = comm_allgather_sums(m, d_sums(m), (double *)m->gather.p, LOM_NSUMS);
@@ -385,17 +458,31 @@ static int launch_eval(ScanCtx &c, const double q[4], const double t[3], double 
             out[k] = v;
         }
     } else {
-        LOM_HIP(m, hipMemcpyAsync(m->h_results, d_sums(m), LOM_NSUMS * 8, hipMemcpyDeviceToHost, m->stream));
-        LOM_HIP(m, hipStreamSynchronize(m->stream));
-        std::memcpy(out, m->h_results, LOM_NSUMS * 8);
+        // poll the mailbox; fall back to the stream's status so a failed launch cannot hang us
+        volatile unsigned long long *flag = reinterpret_cast<volatile unsigned long long *>(m->h_mail + 32);
+        uint64_t spins = 0;
+        while (*flag != seq) {
+            __builtin_ia32_pause();
+            if ((++spins & 0xFFFF) == 0) {
+                const hipError_t e = hipStreamQuery(m->stream);
+                if (e == hipSuccess) {
+                    if (*flag == seq) break;
+                    if (spins > (1ull << 26)) return set_error(m, LOM_ERR_HIP, "mailbox not written by k_finish");
+                } else if (e != hipErrorNotReady) {
+                    return set_error(m, LOM_ERR_HIP, "stream failed while waiting for k_finish", e);
+                }
+            }
+        }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        std::memcpy(out, (const void *)m->h_mail, LOM_NSUMS * 8);
+    }
+    // counters of the last k_match are summed on its first evaluation only
+    if (fresh_match) {
+        for (int k = 0; k < 4; k++) m->last_counters[k] = out[28 + k];
+    } else {
+        for (int k = 0; k < 3; k++) out[28 + k] = m->last_counters[k];
     }
     return LOM_OK;
-}
-
-static void add_event_ms(lom_map *m, int a, int b, float &acc)
-{
-    float ms = 0.f;
-    if (hipEventElapsedTime(&ms, m->ev[a], m->ev[b]) == hipSuccess) acc += ms;
 }
 
 static int hook_match_eval(void *user, const float pt[3], const float pq[4], const double q[4], const double t[3],
@@ -404,22 +491,13 @@ static int hook_match_eval(void *user, const float pt[3], const float pq[4], con
     ScanCtx &c = *(ScanCtx *)user;
     int rc = launch_match(c, pt, pq, 0.3f, false);  // cloud_matcher.cpp:139
     if (rc != LOM_OK) return rc;
-    rc = launch_eval(c, q, t, out);
-    if (rc != LOM_OK) return rc;
-    if (c.m->profiling) {
-        if (c.n) add_event_ms(c.m, 0, 1, c.match_ms);
-        add_event_ms(c.m, 2, 3, c.eval_ms);
-    }
-    return LOM_OK;
+    return launch_eval(c, q, t, true, out);
 }
 
 static int hook_eval_fixed(void *user, const double q[4], const double t[3], double out[LOM_NSUMS])
 {
     ScanCtx &c = *(ScanCtx *)user;
-    int rc = launch_eval(c, q, t, out);
-    if (rc != LOM_OK) return rc;
-    if (c.m->profiling) add_event_ms(c.m, 2, 3, c.eval_ms);
-    return LOM_OK;
+    return launch_eval(c, q, t, false, out);
 }
 
 static int align_device(lom_map *m, const char *d_src, size_t n, size_t stride, const float guess_t[3],
@@ -440,8 +518,14 @@ static int align_device(lom_map *m, const char *d_src, size_t n, size_t stride, 
         if (m->last_error.empty()) set_error(m, rc, "align failed");
         return rc == LOM_ERR_HOOK ? LOM_ERR_HIP : rc;
     }
-    st.match_kernel_ms = c.match_ms;
-    st.eval_kernel_ms = c.eval_ms;
+    if (m->profiling && c.prof_used) {
+        LOM_HIP(m, hipStreamSynchronize(m->stream));
+        for (int i = 0; i < c.prof_used; i++) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, m->prof_events[(size_t)i * 2], m->prof_events[(size_t)i * 2 + 1]) == hipSuccess)
+                st.match_kernel_ms += ms;
+        }
+    }
     if (stats) *stats = st;
     return LOM_OK;
 }

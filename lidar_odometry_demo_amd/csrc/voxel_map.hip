@@ -645,18 +645,16 @@ int lom_map_create(float voxel_size, size_t max_points, size_t capacity_hint, in
     if ((e = hipSetDevice(device)) != hipSuccess ||
         (e = hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipHostMalloc((void **)&m->h_results, 1024 * sizeof(double), hipHostMallocDefault)) != hipSuccess ||
-        (e = hipHostMalloc((void **)&m->h_flags, 64 * sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess) {
+        (e = hipHostMalloc((void **)&m->h_flags, 64 * sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess ||
+        (e = hipHostMalloc((void **)&m->h_mail, 64 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent)) !=
+            hipSuccess ||
+        (e = hipHostGetDevicePointer((void **)&m->d_mail, m->h_mail, 0)) != hipSuccess) {
         set_error(nullptr, LOM_ERR_HIP, "handle setup", e);
         lom_map_destroy(m);
         return LOM_ERR_HIP;
     }
     m->stream = m->own_stream;
-    for (int i = 0; i < 4; i++)
-        if ((e = hipEventCreate(&m->ev[i])) != hipSuccess) {
-            set_error(nullptr, LOM_ERR_HIP, "hipEventCreate", e);
-            lom_map_destroy(m);
-            return LOM_ERR_HIP;
-        }
+    std::memset(m->h_mail, 0, 64 * sizeof(double));
     m->min_cap = next_pow2(4ull * std::max<size_t>(capacity_hint, 256));
     int rc = ensure(m, m->scr[S_MISC], 256);
     if (rc == LOM_OK) {
@@ -689,7 +687,8 @@ void lom_map_destroy(lom_map *m)
         if (b->p) (void)hipFree(b->p);
     if (m->h_results) (void)hipHostFree(m->h_results);
     if (m->h_flags) (void)hipHostFree(m->h_flags);
-    for (auto &e : m->ev)
+    if (m->h_mail) (void)hipHostFree(m->h_mail);
+    for (auto &e : m->prof_events)
         if (e) (void)hipEventDestroy(e);
     if (m->own_stream) (void)hipStreamDestroy(m->own_stream);
     delete m;
