@@ -12,7 +12,8 @@
 //             Jacobian, Huber(0.15) IRLS weight; f64 wave reduction of
 //             sum w J J^T (21), sum w J r (6), sum 0.5 rho (1) -> one partial
 //             per workgroup.
-//   k_finish  fixed-order sum of the partials -> LOM_NSUMS doubles.
+//             The last workgroup to arrive sums the partials in fixed order and
+//             publishes LOM_NSUMS doubles straight into pinned host memory.
 //
 // Built with -ffp-contract=off (see voxel_map.hip).
 #include <algorithm>
@@ -27,7 +28,8 @@
 namespace lom {
 
 constexpr int kMatchThreads = 256;             // 4 waves
-constexpr int kGroupsPerBlock = kMatchThreads / 32;  // one query per 32-lane half wave
+constexpr int kMatchG = 16;                    // lanes per query: four queries per wave
+constexpr int kGroupsPerBlock = kMatchThreads / kMatchG;
 constexpr int kEvalThreads = 256;
 
 // per-query device record written by k_match
@@ -39,30 +41,51 @@ struct __attribute__((aligned(8))) QStat {
 };
 
 // ---------------------------------------------------------------------------
-// k_match: one query per half wave (32 lanes).
-//   lanes 0..26  probe one neighbour voxel each (voxel_grid.h:175-179)
-//   all 32 lanes stride the stored points of every occupied neighbour
-//   (voxel_grid.h:183-191) and keep a private strict minimum; the half wave
-//   then takes the lexicographic minimum of (sq_dist, scan ordinal), which is
-//   exactly "first encountered wins" of the serial loop.
+// k_match<G>: one query per group of G lanes (G = 16: four queries per wave).
+//
+//  1. probe    lane l takes neighbours b = l, l+G, ... < 27 in the reference's scan
+//              order ix, iy, iz (voxel_grid.h:175-179): one 16-byte slot load each.
+//  2. prune    a neighbour voxel whose nearest possible coordinate is provably
+//              farther than max_dist cannot hold a point with d2 < max_sq
+//              (voxel_grid.h:186), so its points are not read.  Exact: such points
+//              never win in the reference either.  Counts stay the reference's.
+//  3. flatten  the remaining voxels' points form one candidate sequence in scan
+//              order (inclusive prefix of the counts in LDS); lane l takes
+//              candidates l, l+G, ... and finds each one's voxel by a 5-step
+//              binary search -- every load of a query is in flight at once instead
+//              of one dependent round trip per occupied voxel.
+//  4. select   private strict minimum per lane (candidates arrive in scan order),
+//              then the lexicographic minimum of (sq_dist, candidate ordinal) over
+//              the group == "first encountered wins" of voxel_grid.h:183-191.
 // ---------------------------------------------------------------------------
+__device__ inline float axis_gap(float q, int i, float vs)
+{
+    // coordinates x with (int)(x / vs) == i lie in [lo, hi] (truncation: index 0 is
+    // double width); returns a lower bound of |q - x| over that range
+    const float lo = (i > 0) ? (float)i * vs : (float)(i - 1) * vs;
+    const float hi = (i < 0) ? (float)i * vs : (float)(i + 1) * vs;
+    const float g = fmaxf(fmaxf(lo - q, q - hi), 0.f);
+    // slack for the f32 rounding of x / vs at the voxel faces and of the distance itself
+    return fmaxf(g - (1e-4f * vs + 1e-6f * fabsf(q)), 0.f);
+}
+
+template <int G>
 __global__ __launch_bounds__(kMatchThreads) void k_match(MapView map, const char *__restrict__ src, size_t stride,
                                                          uint32_t n, PoseArgs P, int32_t *__restrict__ out_idx,
                                                          float *__restrict__ out_on, QStat *__restrict__ out_stat,
                                                          uint32_t *__restrict__ block_counters)
 {
-    __shared__ uint2 s_nb[kGroupsPerBlock][28];  // compacted occupied neighbours: (count, slab)
-    __shared__ uint32_t s_cnt[kGroupsPerBlock][3];
-    const int lane = threadIdx.x & 63;
-    const int hl = lane & 31;
-    const int half = lane >> 5;
-    const int grp = threadIdx.x >> 5;
-    const uint32_t groups_total = gridDim.x * kGroupsPerBlock;
-    // neighbour offset of this lane, scan order ix (outer), iy, iz (inner)
-    const int dxn = hl / 9 - 1, dyn = (hl / 3) % 3 - 1, dzn = hl % 3 - 1;
+    constexpr int kGroups = kMatchThreads / G;
+    constexpr int kSets = (27 + G - 1) / G;
+    __shared__ uint32_t s_pref[kGroups][32];  // inclusive prefix of scanned counts, scan order; padded with total
+    __shared__ uint32_t s_base[kGroups][32];  // slab * K - exclusive prefix: point index = s_base[b] + c
+    __shared__ uint32_t s_cnt[kGroups][3];
+    const int gl = threadIdx.x % G;
+    const int grp = threadIdx.x / G;
+    const uint32_t groups_total = gridDim.x * kGroups;
     uint32_t acc_cand = 0, acc_occ = 0, acc_valid = 0;
 
-    for (uint32_t q = blockIdx.x * kGroupsPerBlock + grp; q < n; q += groups_total) {
+    for (uint32_t q = blockIdx.x * kGroups + grp; q < n; q += groups_total) {
         const float *sp = reinterpret_cast<const float *>(src + (size_t)q * stride);
         const double p0 = (double)sp[0], p1 = (double)sp[1], p2 = (double)sp[2];
         // voxel_grid.h:220-223: R*p + t in f64 (Eigen order a0 + (a1 + a2)), cast to f32
@@ -72,68 +95,108 @@ __global__ __launch_bounds__(kMatchThreads) void k_match(MapView map, const char
         int ix = 0, iy = 0, iz = 0;
         const bool inr = voxel_index(qx, map.voxel_size, ix) && voxel_index(qy, map.voxel_size, iy) &&
                          voxel_index(qz, map.voxel_size, iz);
-        uint32_t cnt = 0, slab = 0;
-        if (inr && hl < 27) {
-            const int nx = ix + dxn, ny = iy + dyn, nz = iz + dzn;
-            // stored indices lie in (-2^20, 2^20); anything outside cannot exist
-            if (nx > -kIdxBias && nx < kIdxBias && ny > -kIdxBias && ny < kIdxBias && nz > -kIdxBias &&
-                nz < kIdxBias) {
-                const unsigned long long key = pack_key(nx, ny, nz);
-                uint32_t h = hash_key(key, map.shift) & map.mask;
-                for (uint32_t probe = 0; probe <= map.mask; probe++) {
-                    const uint4 raw = *reinterpret_cast<const uint4 *>(&map.table[h]);
-                    const unsigned long long k = ((unsigned long long)raw.y << 32) | raw.x;
-                    if (k == key) {
-                        cnt = raw.z;
-                        slab = raw.w;
-                        break;
+        uint32_t cnt[kSets], scan_cnt[kSets], slab[kSets];
+#pragma unroll
+        for (int s = 0; s < kSets; s++) {
+            cnt[s] = 0;
+            scan_cnt[s] = 0;
+            slab[s] = 0;
+            const int b = gl + s * G;
+            if (inr && b < 27) {
+                const int nx = ix + b / 9 - 1, ny = iy + (b / 3) % 3 - 1, nz = iz + b % 3 - 1;
+                // stored indices lie in (-2^20, 2^20); anything outside cannot exist
+                if (nx > -kIdxBias && nx < kIdxBias && ny > -kIdxBias && ny < kIdxBias && nz > -kIdxBias &&
+                    nz < kIdxBias) {
+                    const unsigned long long key = pack_key(nx, ny, nz);
+                    uint32_t h = hash_key(key, map.shift) & map.mask;
+                    for (uint32_t probe = 0; probe <= map.mask; probe++) {
+                        const uint4 raw = *reinterpret_cast<const uint4 *>(&map.table[h]);
+                        const unsigned long long k = ((unsigned long long)raw.y << 32) | raw.x;
+                        if (k == key) {
+                            cnt[s] = raw.z;
+                            slab[s] = raw.w;
+                            break;
+                        }
+                        if (k == kEmptyKey) break;
+                        h = (h + 1) & map.mask;
                     }
-                    if (k == kEmptyKey) break;
-                    h = (h + 1) & map.mask;
+                    if (cnt[s]) {
+                        const float gx = axis_gap(qx, nx, map.voxel_size);
+                        const float gy = axis_gap(qy, ny, map.voxel_size);
+                        const float gz = axis_gap(qz, nz, map.voxel_size);
+                        const float lower = gx * gx + (gy * gy + gz * gz);
+                        scan_cnt[s] = (lower > P.max_sq * 1.0001f) ? 0u : cnt[s];
+                    }
                 }
             }
         }
-        // compact the occupied neighbours in scan order
-        const unsigned long long bal = __ballot(cnt > 0);
-        const uint32_t hmask = (uint32_t)(bal >> (half * 32));
-        const uint32_t n_occ = __popc(hmask);
-        if (cnt > 0) s_nb[grp][__popc(hmask & ((1u << hl) - 1u))] = make_uint2(cnt, slab);
+        // group-wide prefix over the neighbours in scan order (set 0 = b < G, set 1 = b >= G)
+        uint32_t n_occ = 0, n_cand = 0, run = 0;
+#pragma unroll
+        for (int s = 0; s < kSets; s++) {
+            uint32_t inc = scan_cnt[s], all = cnt[s], occ = cnt[s] ? 1u : 0u;
+#pragma unroll
+            for (int d = 1; d < G; d <<= 1) {
+                const uint32_t o = __shfl_up(inc, d, G);
+                if (gl >= d) inc += o;
+                all += __shfl_xor(all, d, G);
+                occ += __shfl_xor(occ, d, G);
+            }
+            const uint32_t set_total = __shfl(inc, G - 1, G);
+            const int b = gl + s * G;
+            if (b < 32) {
+                s_pref[grp][b] = (b < 27) ? run + inc : 0xFFFFFFFFu;
+                s_base[grp][b] = slab[s] * map.K - (run + inc - scan_cnt[s]);
+            }
+            run += set_total;
+            n_cand += all;
+            n_occ += occ;
+        }
+        if (kSets * G < 32) {  // G = 16 covers b < 32 with two sets; other G: pad the tail
+            for (int b = kSets * G + gl; b < 32; b += G) s_pref[grp][b] = 0xFFFFFFFFu;
+        }
+        const uint32_t T = run;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
         float best = INFINITY;
-        uint32_t best_ord = 0xFFFFFFFFu;
-        uint32_t n_cand = 0;
-        for (uint32_t i = 0; i < n_occ; i++) {
-            const uint2 e = s_nb[grp][i];
-            n_cand += e.x;
-            const float *vp = map.pts + (size_t)e.y * map.K * 3;
-            for (uint32_t j = hl; j < e.x; j += 32) {
-                const float ax = vp[j * 3 + 0], ay = vp[j * 3 + 1], az = vp[j * 3 + 2];
-                const float dx = qx - ax, dy = qy - ay, dz = qz - az;
-                const float d2 = dx * dx + (dy * dy + dz * dz);  // voxel_grid.h:184 f32 squaredNorm
-                if (d2 < P.max_sq && d2 < best) {                // :186-187 strict
-                    best = d2;
-                    best_ord = (i << 16) | j;
-                }
+        uint32_t best_c = 0xFFFFFFFFu, best_idx = 0;
+        const uint32_t *pref = s_pref[grp];
+        for (uint32_t c = gl; c < T; c += G) {
+            // smallest b with pref[b] > c
+            uint32_t b = 0;
+            b += (pref[b + 15] <= c) ? 16u : 0u;
+            b += (pref[b + 7] <= c) ? 8u : 0u;
+            b += (pref[b + 3] <= c) ? 4u : 0u;
+            b += (pref[b + 1] <= c) ? 2u : 0u;
+            b += (pref[b] <= c) ? 1u : 0u;
+            const uint32_t pi = s_base[grp][b] + c;
+            const float *vp = map.pts + (size_t)pi * 3;
+            const float ax = vp[0], ay = vp[1], az = vp[2];
+            const float dx = qx - ax, dy = qy - ay, dz = qz - az;
+            const float d2 = dx * dx + (dy * dy + dz * dz);  // voxel_grid.h:184 f32 squaredNorm
+            if (d2 < P.max_sq && d2 < best) {                // :186-187 strict
+                best = d2;
+                best_c = c;
+                best_idx = pi;
             }
         }
-        // lexicographic min over the half wave; d2 >= 0 so its bit pattern orders like the value
-        unsigned long long keyv = ((unsigned long long)__float_as_uint(best) << 32) | best_ord;
+        // lexicographic min over the group; d2 >= 0 so its bit pattern orders like the value
+        unsigned long long keyv = ((unsigned long long)__float_as_uint(best) << 32) | best_c;
 #pragma unroll
-        for (int d = 16; d >= 1; d >>= 1) {
-            const unsigned long long o = __shfl_xor(keyv, d, 32);
+        for (int d = G / 2; d >= 1; d >>= 1) {
+            const unsigned long long o = __shfl_xor(keyv, d, G);
             keyv = o < keyv ? o : keyv;
         }
-        const uint32_t w_ord = (uint32_t)keyv;
-        const bool valid = w_ord != 0xFFFFFFFFu;
-        if (hl == 0) {
+        const uint32_t w_c = (uint32_t)keyv;
+        const bool valid = w_c != 0xFFFFFFFFu;
+        const uint32_t w_idx = __shfl(best_idx, valid ? (int)(w_c % G) : 0, G);  // the lane that scanned it
+        if (gl == 0) {
             int32_t idx = -1;
             float o0 = 0.f, o1 = 0.f, o2 = 0.f, n0 = 0.f, n1 = 0.f, n2 = 0.f;
             if (valid) {
-                const uint2 e = s_nb[grp][w_ord >> 16];
-                const size_t pi = (size_t)e.y * map.K + (w_ord & 0xFFFFu);
+                const size_t pi = w_idx;
                 idx = (int32_t)pi;
                 o0 = map.pts[pi * 3 + 0];  // voxel_grid.h:197-198
                 o1 = map.pts[pi * 3 + 1];
@@ -162,13 +225,13 @@ __global__ __launch_bounds__(kMatchThreads) void k_match(MapView map, const char
             acc_occ += n_occ;
             acc_valid += valid ? 1 : 0;
         }
-        // s_nb is rewritten next iteration: all reads above are complete for this wave
+        // the LDS tables are rewritten next iteration: all reads above are complete for this wave
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
     // per-block counters, summed in fixed order by k_finish (no same-address atomics:
     // one word saturates at ~88 atomics/us, MI355X_MICROARCH.md "dequeue")
-    if (hl == 0) {
+    if (gl == 0) {
         s_cnt[grp][0] = acc_valid;
         s_cnt[grp][1] = acc_cand;
         s_cnt[grp][2] = acc_occ;
@@ -176,15 +239,25 @@ __global__ __launch_bounds__(kMatchThreads) void k_match(MapView map, const char
     __syncthreads();
     if (threadIdx.x < 3) {
         uint32_t v = 0;
-#pragma unroll
-        for (int g = 0; g < kGroupsPerBlock; g++) v += s_cnt[g][threadIdx.x];
+        for (int g = 0; g < kGroups; g++) v += s_cnt[g][threadIdx.x];
         block_counters[blockIdx.x * 4 + threadIdx.x] = v;
     }
 }
 
 // ---------------------------------------------------------------------------
-// k_eval: residual + Jacobian + robust weight + reduction.  One lane per
-// source point, grid-stride; 28 f64 accumulators per lane.
+// k_eval: residual + Jacobian + robust weight + reduction + in-launch finish.
+// One lane per source point, grid-stride; 28 f64 accumulators per lane; one
+// partial per workgroup.  The workgroup that takes the last ticket sums the
+// partials in workgroup order (bitwise run-to-run reproducible, independent of
+// arrival order) and publishes LOM_NSUMS doubles: to `out` in HBM and, when
+// `mail` is set, straight into coherent pinned host memory followed by a
+// system-scope release store of `seq` (the host polls that word; no copy kernel,
+// no stream synchronisation per residual evaluation).
+//
+// Inter-workgroup hand-off follows cdna_hip_programming.md Guideline 16:
+// producer stores -> s_waitcnt vmcnt(0) -> barrier -> one lane: agent release,
+// s_waitcnt vmcnt(0), returning ticket atomic; last arriver: agent acquire,
+// s_waitcnt vmcnt(0), barrier, plain loads.
 // ---------------------------------------------------------------------------
 __device__ inline double wave_sum(double v)
 {
@@ -196,20 +269,30 @@ __device__ inline double wave_sum(double v)
 __global__ __launch_bounds__(kEvalThreads) void k_eval(const char *__restrict__ src, size_t stride, uint32_t n,
                                                        const int32_t *__restrict__ idx,
                                                        const float *__restrict__ on, EvalArgs E,
-                                                       double *__restrict__ partials)
+                                                       double *partials, uint32_t *ticket,
+                                                       const uint32_t *__restrict__ block_counters,
+                                                       uint32_t n_match_blocks, double *__restrict__ out,
+                                                       double *mail, unsigned long long seq)
 {
     __shared__ double s_red[kEvalThreads / 64][28];
+    __shared__ double s_part[8][33];
+    __shared__ unsigned long long s_cnt[kEvalThreads / 64][3];
+    __shared__ uint32_t s_last;
     double acc[28];
 #pragma unroll
     for (int k = 0; k < 28; k++) acc[k] = 0.0;
     const double q0 = E.q[0], q1 = E.q[1], q2 = E.q[2], q3 = E.q[3];
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        if (idx[i] < 0) continue;
+        // all three streams are issued before anything depends on them
+        const int32_t ci = idx[i];
         const float *sp = reinterpret_cast<const float *>(src + (size_t)i * stride);
-        const double p[3] = {(double)sp[0], (double)sp[1], (double)sp[2]};
+        const float s0 = sp[0], s1 = sp[1], s2 = sp[2];
         const float *c = on + (size_t)i * 6;
-        const double o[3] = {(double)c[0], (double)c[1], (double)c[2]};
-        const double nn[3] = {(double)c[3], (double)c[4], (double)c[5]};
+        const float c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3], c4 = c[4], c5 = c[5];
+        if (ci < 0) continue;
+        const double p[3] = {(double)s0, (double)s1, (double)s2};
+        const double o[3] = {(double)c0, (double)c1, (double)c2};
+        const double nn[3] = {(double)c3, (double)c4, (double)c5};
         // cloud_matcher.cpp:54  (rot*local_point + t - plane_origin).dot(plane_normal)
         double uv0 = q2 * p[2] - q3 * p[1];
         double uv1 = q3 * p[0] - q1 * p[2];
@@ -280,30 +363,41 @@ __global__ __launch_bounds__(kEvalThreads) void k_eval(const char *__restrict__ 
         for (int w = 0; w < kEvalThreads / 64; w++) v += s_red[w][threadIdx.x];
         partials[(size_t)blockIdx.x * 28 + threadIdx.x] = v;
     }
-}
-
-// fixed-order final sum -> LOM_NSUMS doubles (bitwise run-to-run reproducible).
-// 1024 threads: 32 strided partial sums per output, then a fixed-order LDS pass.
-// The counters of the last k_match are summed only when asked for (they do not
-// change between the evaluations of one outer iteration).
-// Results go to `out` (device) and, when `mail` is set, straight into coherent
-// pinned host memory followed by a system-scope release store of `seq`.
-constexpr int kFinishThreads = 1024;
-__global__ __launch_bounds__(kFinishThreads) void k_finish(const double *__restrict__ partials, uint32_t n_blocks,
-                                                           const uint32_t *__restrict__ block_counters,
-                                                           uint32_t n_match_blocks, uint32_t n_queries,
-                                                           double *__restrict__ out, double *mail,
-                                                           unsigned long long seq)
-{
-    __shared__ double s_part[32][33];
-    __shared__ unsigned long long s_cnt[kFinishThreads / 64][3];
-    const int k = threadIdx.x & 31, part = threadIdx.x >> 5;
-    double v = 0.0;
-    if (k < 28)
-        for (uint32_t b = part; b < n_blocks; b += 32) v += partials[(size_t)b * 28 + k];
-    s_part[part][k] = v;
+    // ---- hand-off: publish this workgroup's partial, take a ticket ----------------
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the storing wave's stores have left
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint32_t t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (t == gridDim.x - 1) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // ---- last arriver: fixed-order final sum ---------------------------------------
+    const uint32_t nb = gridDim.x;
+    {
+        const int k = threadIdx.x & 31, part = threadIdx.x >> 5;  // 8 strided parts per output
+        double v = 0.0;
+        if (k < 28) {
+            uint32_t b = part;
+            for (; b + 24 < nb; b += 32) {  // four independent loads in flight
+                const double a0 = partials[(size_t)b * 28 + k], a1 = partials[(size_t)(b + 8) * 28 + k];
+                const double a2 = partials[(size_t)(b + 16) * 28 + k], a3 = partials[(size_t)(b + 24) * 28 + k];
+                v += a0;
+                v += a1;
+                v += a2;
+                v += a3;
+            }
+            for (; b < nb; b += 8) v += partials[(size_t)b * 28 + k];
+        }
+        s_part[part][k] = v;
+    }
     unsigned long long c0 = 0, c1 = 0, c2 = 0;
-    for (uint32_t b = threadIdx.x; b < n_match_blocks; b += kFinishThreads) {
+    for (uint32_t b = threadIdx.x; b < n_match_blocks; b += kEvalThreads) {
         const uint4 r = *reinterpret_cast<const uint4 *>(block_counters + (size_t)b * 4);
         c0 += r.x;
         c1 += r.y;
@@ -316,10 +410,10 @@ __global__ __launch_bounds__(kFinishThreads) void k_finish(const double *__restr
             c1 += __shfl_xor(c1, d, 64);
             c2 += __shfl_xor(c2, d, 64);
         }
-        if ((threadIdx.x & 63) == 0) {
-            s_cnt[threadIdx.x >> 6][0] = c0;
-            s_cnt[threadIdx.x >> 6][1] = c1;
-            s_cnt[threadIdx.x >> 6][2] = c2;
+        if (lane == 0) {
+            s_cnt[wave][0] = c0;
+            s_cnt[wave][1] = c1;
+            s_cnt[wave][2] = c2;
         }
     }
     __syncthreads();
@@ -327,20 +421,21 @@ __global__ __launch_bounds__(kFinishThreads) void k_finish(const double *__restr
         double t = 0.0;
         if (threadIdx.x < 28) {
 #pragma unroll
-            for (int p = 0; p < 32; p++) t += s_part[p][threadIdx.x];
+            for (int p = 0; p < 8; p++) t += s_part[p][threadIdx.x];
         } else if (threadIdx.x < 31) {
             unsigned long long c = 0;
             if (n_match_blocks)
-                for (int w = 0; w < kFinishThreads / 64; w++) c += s_cnt[w][threadIdx.x - 28];
+                for (int w = 0; w < kEvalThreads / 64; w++) c += s_cnt[w][threadIdx.x - 28];
             t = (double)c;
         } else {
-            t = (double)n_queries;
+            t = (double)n;
         }
         out[threadIdx.x] = t;
+        if (threadIdx.x == 0) *ticket = 0u;  // every workgroup has arrived: re-arm for the next launch
         if (mail) {
             mail[threadIdx.x] = t;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // system scope: payload before the flag
-            // all 32 lanes are one wave: lane 0 publishes after the wave's stores
+            // the 32 lanes are one wave: lane 0 publishes after the wave's stores
             if (threadIdx.x == 0)
                 __hip_atomic_store(reinterpret_cast<unsigned long long *>(mail + 32), seq, __ATOMIC_RELEASE,
                                    __HIP_MEMORY_SCOPE_SYSTEM);
@@ -390,12 +485,16 @@ static int scan_buffers(lom_map *m, uint32_t n, bool want_stats)
     if ((rc = ensure(m, m->scan_on, nn * 24)) != LOM_OK) return rc;
     if (want_stats && (rc = ensure(m, m->scan_stats, nn * sizeof(QStat))) != LOM_OK) return rc;
     if ((rc = ensure(m, m->partials, (size_t)512 * 28 * 8)) != LOM_OK) return rc;
+    const void *before = m->results.p;
     if ((rc = ensure(m, m->results, 1024 + (size_t)kMaxMatchBlocks * 16)) != LOM_OK) return rc;
+    if (m->results.p != before)  // new allocation: sums and the hand-off ticket start at zero
+        LOM_HIP(m, hipMemsetAsync(m->results.p, 0, 1024, m->stream));
     return LOM_OK;
 }
 
 static uint32_t *d_block_counters(lom_map *m) { return (uint32_t *)((char *)m->results.p + 1024); }
 static double *d_sums(lom_map *m) { return (double *)m->results.p; }
+static uint32_t *d_ticket(lom_map *m) { return (uint32_t *)((char *)m->results.p + 512); }
 
 static int launch_match(ScanCtx &c, const float t[3], const float q[4], float max_dist, bool stats)
 {
@@ -417,7 +516,7 @@ static int launch_match(ScanCtx &c, const float t[3], const float q[4], float ma
             c.prof_used++;
             LOM_HIP(m, hipEventRecord(e0, m->stream));
         }
-        hipLaunchKernelGGL(k_match, dim3(c.match_blocks), dim3(kMatchThreads), 0, m->stream, view_of(m), c.d_src,
+        hipLaunchKernelGGL(k_match<kMatchG>, dim3(c.match_blocks), dim3(kMatchThreads), 0, m->stream, view_of(m), c.d_src,
                            c.stride, c.n, P, (int32_t *)m->scan_idx.p, (float *)m->scan_on.p,
                            stats ? (QStat *)m->scan_stats.p : (QStat *)nullptr, d_block_counters(m));
         LOM_HIP(m, hipGetLastError());
@@ -435,15 +534,23 @@ static int launch_eval(ScanCtx &c, const double q[4], const double t[3], bool fr
     for (int i = 0; i < 3; i++) E.t[i] = t[i];
     const uint32_t nb = c.n ? eval_grid(c.n) : 0;
     const bool mailbox = (m->comm == nullptr);
+    if (nb == 0) {
+        // nothing to evaluate on this rank: all sums are zero
+        if (mailbox) {
+            std::memset(out, 0, LOM_NSUMS * 8);
+            for (int k = 0; k < 4; k++) m->last_counters[k] = 0.0;
+            return LOM_OK;
+        }
+        LOM_HIP(m, hipMemsetAsync(d_sums(m), 0, LOM_NSUMS * 8, m->stream));
+    }
     const unsigned long long seq = ++m->mail_seq;
     if (nb) {
         hipLaunchKernelGGL(k_eval, dim3(nb), dim3(kEvalThreads), 0, m->stream, c.d_src, c.stride, c.n,
-                           (const int32_t *)m->scan_idx.p, (const float *)m->scan_on.p, E, (double *)m->partials.p);
+                           (const int32_t *)m->scan_idx.p, (const float *)m->scan_on.p, E, (double *)m->partials.p,
+                           d_ticket(m), (const uint32_t *)d_block_counters(m), fresh_match ? c.match_blocks : 0u,
+                           d_sums(m), mailbox ? m->d_mail : (double *)nullptr, seq);
+        LOM_HIP(m, hipGetLastError());
     }
-    hipLaunchKernelGGL(k_finish, dim3(1), dim3(kFinishThreads), 0, m->stream, (const double *)m->partials.p, nb,
-                       (const uint32_t *)d_block_counters(m), fresh_match ? c.match_blocks : 0u, c.n, d_sums(m),
-                       mailbox ? m->d_mail : (double *)nullptr, seq);
-    LOM_HIP(m, hipGetLastError());
     if (!mailbox) {
         int rc = ensure(m, m->gather, (size_t)m->nranks * LOM_NSUMS * 8);
         if (rc != LOM_OK) return rc;
@@ -467,9 +574,9 @@ static int launch_eval(ScanCtx &c, const double q[4], const double t[3], bool fr
                 const hipError_t e = hipStreamQuery(m->stream);
                 if (e == hipSuccess) {
                     if (*flag == seq) break;
-                    if (spins > (1ull << 26)) return set_error(m, LOM_ERR_HIP, "mailbox not written by k_finish");
+                    if (spins > (1ull << 26)) return set_error(m, LOM_ERR_HIP, "mailbox not written by k_eval");
                 } else if (e != hipErrorNotReady) {
-                    return set_error(m, LOM_ERR_HIP, "stream failed while waiting for k_finish", e);
+                    return set_error(m, LOM_ERR_HIP, "stream failed while waiting for k_eval", e);
                 }
             }
         }
