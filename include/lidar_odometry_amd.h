@@ -139,6 +139,8 @@ typedef struct {
     double last_step_norm;
     double match_kernel_ms;    /* HIP-event time of the correspondence launches (profiling on) */
     double algorithmic_bytes;  /* sum over queries of 444 + 12*cand + 12*valid     */
+    double host_launch_ms;     /* host time spent inside kernel-launch calls                   */
+    double host_wait_ms;       /* host time spent waiting for evaluation results               */
 } lom_align_stats;
 
 int lom_match_align(lom_map *m, const float *src_xyz, size_t n, size_t stride_bytes,
@@ -149,8 +151,15 @@ int lom_match_align_device(lom_map *m, const float *d_src_xyz, size_t n, size_t 
                            const float guess_t[3], const float guess_q_wxyz[4], float out_t[3],
                            float out_q_wxyz[4], lom_align_stats *stats_or_null);
 
-/* record HIP events around the kernels of lom_match_align* (stats->*_kernel_ms) */
+/* record HIP events around the correspondence launches of lom_match_align* (stats->match_kernel_ms) */
 int lom_map_set_profiling(lom_map *m, int enabled);
+/* Roofline probe: `reps` back-to-back launches of the correspondence kernel on a device-resident
+ * scan at pose (t,q), bracketed by ONE HIP event pair on the handle's stream, so the per-event
+ * packet overhead is amortised.  Returns the average launch duration in microseconds and the
+ * algorithmic bytes of one launch (SURVEY.md 8d formula, counted by the kernel). */
+int lom_profile_match(lom_map *m, const float *d_src_xyz, size_t n, size_t stride_bytes, const float t[3],
+                      const float q_wxyz[4], float max_dist, int reps, double *avg_us_out,
+                      double *algorithmic_bytes_out);
 /* run the handle's work on a caller-owned hipStream_t (NULL = handle's own stream) */
 int lom_map_set_stream(lom_map *m, void *hip_stream);
 

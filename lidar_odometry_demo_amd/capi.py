@@ -48,7 +48,7 @@ class AlignStats(C.Structure):
         ("match_launches", C.c_int32), ("queries", C.c_int64), ("valid_last", C.c_int64),
         ("cand_total", C.c_int64), ("occ_total", C.c_int64), ("final_cost", C.c_double),
         ("last_step_norm", C.c_double), ("match_kernel_ms", C.c_double),
-        ("algorithmic_bytes", C.c_double),
+        ("algorithmic_bytes", C.c_double), ("host_launch_ms", C.c_double), ("host_wait_ms", C.c_double),
     ]
 
     def asdict(self):
@@ -74,7 +74,7 @@ EXPORTED = [
     "lom_map_destroy", "lom_last_error", "lom_map_clear", "lom_map_set_max_points", "lom_map_add_points",
     "lom_map_add_points_device", "lom_map_radius_cleanup", "lom_map_size", "lom_map_point_count",
     "lom_map_export", "lom_match_find_pairs", "lom_match_align", "lom_match_align_device",
-    "lom_map_set_profiling", "lom_map_set_stream", "lom_comm_unique_id", "lom_comm_init",
+    "lom_map_set_profiling", "lom_profile_match", "lom_map_set_stream", "lom_comm_unique_id", "lom_comm_init",
     "lom_comm_finalize", "lom_align_with_hooks",
 ]
 
@@ -145,6 +145,7 @@ def lib():
     L.lom_match_align_device.argtypes = L.lom_match_align.argtypes
     L.lom_map_set_profiling.argtypes = [vp, C.c_int]
     L.lom_map_set_stream.argtypes = [vp, vp]
+    L.lom_profile_match.argtypes = [vp, vp, C.c_size_t, C.c_size_t, fp, fp, C.c_float, C.c_int, dp, dp]
     L.lom_comm_unique_id.argtypes = [C.c_char_p]
     L.lom_comm_init.argtypes = [vp, C.c_int, C.c_int, C.c_char_p]
     L.lom_comm_finalize.argtypes = [vp]

@@ -111,10 +111,11 @@ struct lom_map {
     // pinned host result buffer
     double *h_results = nullptr;  // 1024 doubles (rank-ordered gather of up to 32 ranks)
     uint32_t *h_flags = nullptr;  // 64 words
-    // mailbox: k_finish stores LOM_NSUMS doubles + a sequence word directly into
-    // coherent (fine-grained) pinned host memory; the host polls the word instead of
-    // paying a copy kernel plus hipStreamSynchronize per residual evaluation.
-    double *h_mail = nullptr;             // host view: [0..31] sums, [32] sequence (as u64 bits)
+    // mailbox: every k_eval workgroup stores one 32-double record (sums, counters,
+    // sequence word) directly into coherent (fine-grained) pinned host memory; the host
+    // polls the sequence words instead of paying a copy kernel plus
+    // hipStreamSynchronize per residual evaluation.
+    double *h_mail = nullptr;             // host view: 64 records x 32 doubles
     double *d_mail = nullptr;             // device view of the same allocation
     unsigned long long mail_seq = 0;
     double last_counters[4] = {0, 0, 0, 0};  // valid, cand, occ, queries of the last k_match

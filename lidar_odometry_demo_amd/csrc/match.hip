@@ -12,14 +12,15 @@
 //             Jacobian, Huber(0.15) IRLS weight; f64 wave reduction of
 //             sum w J J^T (21), sum w J r (6), sum 0.5 rho (1) -> one partial
 //             per workgroup.
-//             The last workgroup to arrive sums the partials in fixed order and
-//             publishes LOM_NSUMS doubles straight into pinned host memory.
+//             Single GPU: the <= 64 records land in pinned host memory and the host
+//             adds them in workgroup order (no second kernel, no copy, no sync).
 //
 // Built with -ffp-contract=off (see voxel_map.hip).
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
 #include <cstring>
+#include <ctime>
 #include <vector>
 
 #include "lom_internal.hpp"
@@ -30,9 +31,18 @@ namespace lom {
 constexpr int kMatchThreads = 256;             // 4 waves
 constexpr int kMatchG = 16;                    // lanes per query: four queries per wave
 constexpr int kGroupsPerBlock = kMatchThreads / kMatchG;
-constexpr int kEvalThreads = 256;
+constexpr int kEvalThreads = 512;
 
-// per-query device record written by k_match
+// what k_match leaves behind for the evaluations of one outer iteration: source point,
+// winner's stored point and normal, 48 bytes = three dwordx4 (coalesced for k_eval)
+struct __attribute__((aligned(16))) MatchRec {
+    float px, py, pz, valid;  // source_point_local (voxel_grid.h:226); valid = 1.0f / 0.0f
+    float ox, oy, oz, nx;     // plane_origin, plane_normal.x
+    float ny, nz, pad0, pad1;
+};
+static_assert(sizeof(MatchRec) == 48, "three dwordx4");
+
+// per-query debug record written by k_match for lom_match_find_pairs
 struct __attribute__((aligned(8))) QStat {
     float sq_dist;
     uint32_t n_cand;
@@ -72,7 +82,8 @@ __device__ inline float axis_gap(float q, int i, float vs)
 template <int G>
 __global__ __launch_bounds__(kMatchThreads) void k_match(MapView map, const char *__restrict__ src, size_t stride,
                                                          uint32_t n, PoseArgs P, int32_t *__restrict__ out_idx,
-                                                         float *__restrict__ out_on, QStat *__restrict__ out_stat,
+                                                         MatchRec *__restrict__ out_rec,
+                                                         QStat *__restrict__ out_stat,
                                                          uint32_t *__restrict__ block_counters)
 {
     constexpr int kGroups = kMatchThreads / G;
@@ -206,13 +217,10 @@ __global__ __launch_bounds__(kMatchThreads) void k_match(MapView map, const char
                 n2 = map.nrm[pi * 3 + 2];
             }
             out_idx[q] = idx;
-            float *on = out_on + (size_t)q * 6;
-            on[0] = o0;
-            on[1] = o1;
-            on[2] = o2;
-            on[3] = n0;
-            on[4] = n1;
-            on[5] = n2;
+            float4 *rec = reinterpret_cast<float4 *>(out_rec + q);
+            rec[0] = make_float4(sp[0], sp[1], sp[2], valid ? 1.f : 0.f);
+            rec[1] = make_float4(o0, o1, o2, n0);
+            rec[2] = make_float4(n1, n2, 0.f, 0.f);
             if (out_stat) {
                 QStat st;
                 st.sq_dist = valid ? __uint_as_float((uint32_t)(keyv >> 32)) : 0.f;
@@ -245,20 +253,20 @@ __global__ __launch_bounds__(kMatchThreads) void k_match(MapView map, const char
 }
 
 // ---------------------------------------------------------------------------
-// k_eval: residual + Jacobian + robust weight + reduction + in-launch finish.
-// One lane per source point, grid-stride; 28 f64 accumulators per lane; one
-// partial per workgroup.  The workgroup that takes the last ticket sums the
-// partials in workgroup order (bitwise run-to-run reproducible, independent of
-// arrival order) and publishes LOM_NSUMS doubles: to `out` in HBM and, when
-// `mail` is set, straight into coherent pinned host memory followed by a
-// system-scope release store of `seq` (the host polls that word; no copy kernel,
-// no stream synchronisation per residual evaluation).
+// k_eval: residual + Jacobian + robust weight + reduction.  One lane per
+// source point, grid-stride; 28 f64 accumulators per lane; each workgroup
+// publishes ONE 256-byte record: [0..27] its sums, [28..30] its slice of the
+// counters k_match left per workgroup, [31] the launch's sequence number (bits).
 //
-// Inter-workgroup hand-off follows cdna_hip_programming.md Guideline 16:
-// producer stores -> s_waitcnt vmcnt(0) -> barrier -> one lane: agent release,
-// s_waitcnt vmcnt(0), returning ticket atomic; last arriver: agent acquire,
-// s_waitcnt vmcnt(0), barrier, plain loads.
+// Single GPU: the records go straight into coherent pinned host memory (payload,
+// system-scope release, then the sequence word); the host polls the <= 64 words
+// and adds the records in workgroup order -- bitwise reproducible, no second
+// kernel, no inter-workgroup hand-off, no copy, no stream synchronisation.
+// Multi GPU: the records stay in HBM and k_sum_records folds them for the RCCL
+// all-gather.
 // ---------------------------------------------------------------------------
+constexpr int kRecWords = 32;  // doubles per record
+
 __device__ inline double wave_sum(double v)
 {
 #pragma unroll
@@ -266,33 +274,25 @@ __device__ inline double wave_sum(double v)
     return v;
 }
 
-__global__ __launch_bounds__(kEvalThreads) void k_eval(const char *__restrict__ src, size_t stride, uint32_t n,
-                                                       const int32_t *__restrict__ idx,
-                                                       const float *__restrict__ on, EvalArgs E,
-                                                       double *partials, uint32_t *ticket,
+__global__ __launch_bounds__(kEvalThreads) void k_eval(const MatchRec *__restrict__ rec, uint32_t n, EvalArgs E,
                                                        const uint32_t *__restrict__ block_counters,
-                                                       uint32_t n_match_blocks, double *__restrict__ out,
-                                                       double *mail, unsigned long long seq)
+                                                       uint32_t n_match_blocks, double *out_rec,
+                                                       unsigned long long seq, int to_host)
 {
-    __shared__ double s_red[kEvalThreads / 64][28];
-    __shared__ double s_part[8][33];
-    __shared__ unsigned long long s_cnt[kEvalThreads / 64][3];
-    __shared__ uint32_t s_last;
+    constexpr int kWaves = kEvalThreads / 64;
+    __shared__ double s_red[kWaves][28];
+    __shared__ unsigned long long s_cnt[3];
     double acc[28];
 #pragma unroll
     for (int k = 0; k < 28; k++) acc[k] = 0.0;
     const double q0 = E.q[0], q1 = E.q[1], q2 = E.q[2], q3 = E.q[3];
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        // all three streams are issued before anything depends on them
-        const int32_t ci = idx[i];
-        const float *sp = reinterpret_cast<const float *>(src + (size_t)i * stride);
-        const float s0 = sp[0], s1 = sp[1], s2 = sp[2];
-        const float *c = on + (size_t)i * 6;
-        const float c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3], c4 = c[4], c5 = c[5];
-        if (ci < 0) continue;
-        const double p[3] = {(double)s0, (double)s1, (double)s2};
-        const double o[3] = {(double)c0, (double)c1, (double)c2};
-        const double nn[3] = {(double)c3, (double)c4, (double)c5};
+        const float4 *r4 = reinterpret_cast<const float4 *>(rec + i);
+        const float4 ra = r4[0], rb = r4[1], rc = r4[2];
+        if (ra.w == 0.f) continue;
+        const double p[3] = {(double)ra.x, (double)ra.y, (double)ra.z};
+        const double o[3] = {(double)rb.x, (double)rb.y, (double)rb.z};
+        const double nn[3] = {(double)rb.w, (double)rc.x, (double)rc.y};
         // cloud_matcher.cpp:54  (rot*local_point + t - plane_origin).dot(plane_normal)
         double uv0 = q2 * p[2] - q3 * p[1];
         double uv1 = q3 * p[0] - q1 * p[2];
@@ -356,54 +356,19 @@ __global__ __launch_bounds__(kEvalThreads) void k_eval(const char *__restrict__ 
         const double v = wave_sum(acc[k]);
         if (lane == 0) s_red[wave][k] = v;
     }
-    __syncthreads();
-    if (threadIdx.x < 28) {
-        double v = 0.0;
-#pragma unroll
-        for (int w = 0; w < kEvalThreads / 64; w++) v += s_red[w][threadIdx.x];
-        partials[(size_t)blockIdx.x * 28 + threadIdx.x] = v;
-    }
-    // ---- hand-off: publish this workgroup's partial, take a ticket ----------------
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the storing wave's stores have left
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const uint32_t t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = (t == gridDim.x - 1) ? 1u : 0u;
-    }
-    __syncthreads();
-    if (!s_last) return;
-    if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    // ---- last arriver: fixed-order final sum ---------------------------------------
-    const uint32_t nb = gridDim.x;
-    {
-        const int k = threadIdx.x & 31, part = threadIdx.x >> 5;  // 8 strided parts per output
-        double v = 0.0;
-        if (k < 28) {
-            uint32_t b = part;
-            for (; b + 24 < nb; b += 32) {  // four independent loads in flight
-                const double a0 = partials[(size_t)b * 28 + k], a1 = partials[(size_t)(b + 8) * 28 + k];
-                const double a2 = partials[(size_t)(b + 16) * 28 + k], a3 = partials[(size_t)(b + 24) * 28 + k];
-                v += a0;
-                v += a1;
-                v += a2;
-                v += a3;
-            }
-            for (; b < nb; b += 8) v += partials[(size_t)b * 28 + k];
+    // this workgroup's slice of k_match's per-workgroup counters (first evaluation of an
+    // outer iteration only), folded by its first wave
+    if (wave == 0 && n_match_blocks) {
+        const uint32_t chunk = (n_match_blocks + gridDim.x - 1) / gridDim.x;
+        const uint32_t lo = blockIdx.x * chunk;
+        const uint32_t hi = min(lo + chunk, n_match_blocks);
+        unsigned long long c0 = 0, c1 = 0, c2 = 0;
+        for (uint32_t b = lo + lane; b < hi; b += 64) {
+            const uint4 r = *reinterpret_cast<const uint4 *>(block_counters + (size_t)b * 4);
+            c0 += r.x;
+            c1 += r.y;
+            c2 += r.z;
         }
-        s_part[part][k] = v;
-    }
-    unsigned long long c0 = 0, c1 = 0, c2 = 0;
-    for (uint32_t b = threadIdx.x; b < n_match_blocks; b += kEvalThreads) {
-        const uint4 r = *reinterpret_cast<const uint4 *>(block_counters + (size_t)b * 4);
-        c0 += r.x;
-        c1 += r.y;
-        c2 += r.z;
-    }
-    if (n_match_blocks) {
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) {
             c0 += __shfl_xor(c0, d, 64);
@@ -411,36 +376,53 @@ __global__ __launch_bounds__(kEvalThreads) void k_eval(const char *__restrict__ 
             c2 += __shfl_xor(c2, d, 64);
         }
         if (lane == 0) {
-            s_cnt[wave][0] = c0;
-            s_cnt[wave][1] = c1;
-            s_cnt[wave][2] = c2;
+            s_cnt[0] = c0;
+            s_cnt[1] = c1;
+            s_cnt[2] = c2;
         }
     }
     __syncthreads();
-    if (threadIdx.x < 32) {
-        double t = 0.0;
+    if (threadIdx.x < 32) {  // one wave writes the whole 256-byte record
+        double v = 0.0;
         if (threadIdx.x < 28) {
 #pragma unroll
-            for (int p = 0; p < 8; p++) t += s_part[p][threadIdx.x];
+            for (int w = 0; w < kWaves; w++) v += s_red[w][threadIdx.x];
         } else if (threadIdx.x < 31) {
-            unsigned long long c = 0;
-            if (n_match_blocks)
-                for (int w = 0; w < kEvalThreads / 64; w++) c += s_cnt[w][threadIdx.x - 28];
-            t = (double)c;
-        } else {
-            t = (double)n;
+            v = n_match_blocks ? (double)s_cnt[threadIdx.x - 28] : 0.0;
         }
-        out[threadIdx.x] = t;
-        if (threadIdx.x == 0) *ticket = 0u;  // every workgroup has arrived: re-arm for the next launch
-        if (mail) {
-            mail[threadIdx.x] = t;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // system scope: payload before the flag
-            // the 32 lanes are one wave: lane 0 publishes after the wave's stores
-            if (threadIdx.x == 0)
-                __hip_atomic_store(reinterpret_cast<unsigned long long *>(mail + 32), seq, __ATOMIC_RELEASE,
+        double *dst = out_rec + (size_t)blockIdx.x * kRecWords;
+        if (threadIdx.x < 31) dst[threadIdx.x] = v;
+        if (to_host) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // system scope: payload before the sequence word
+            if (threadIdx.x == 31)
+                __hip_atomic_store(reinterpret_cast<unsigned long long *>(dst + 31), seq, __ATOMIC_RELEASE,
                                    __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
+}
+
+// multi-GPU path: fold the records of one launch in workgroup order -> LOM_NSUMS doubles in HBM
+__global__ __launch_bounds__(64) void k_sum_records(const double *__restrict__ rec, uint32_t n_rec,
+                                                    uint32_t n_queries, double *__restrict__ out)
+{
+    const int k = threadIdx.x;
+    if (k >= LOM_NSUMS) return;
+    double v = 0.0;
+    if (k < 31) {
+        uint32_t b = 0;
+        for (; b + 4 <= n_rec; b += 4) {  // independent loads in flight, fixed summation order
+            const double a0 = rec[(size_t)b * kRecWords + k], a1 = rec[(size_t)(b + 1) * kRecWords + k];
+            const double a2 = rec[(size_t)(b + 2) * kRecWords + k], a3 = rec[(size_t)(b + 3) * kRecWords + k];
+            v += a0;
+            v += a1;
+            v += a2;
+            v += a3;
+        }
+        for (; b < n_rec; b++) v += rec[(size_t)b * kRecWords + k];
+    } else {
+        v = (double)n_queries;
+    }
+    out[k] = v;
 }
 
 // ---------------------------------------------------------------------------
@@ -462,10 +444,11 @@ static uint32_t match_grid(uint32_t n)
     return std::max(1u, std::min(need, kMaxMatchBlocks));
 }
 
+constexpr uint32_t kMaxEvalBlocks = 64;  // records per launch (the host polls this many words)
 static uint32_t eval_grid(uint32_t n)
 {
     const uint32_t need = (n + kEvalThreads - 1) / kEvalThreads;
-    return std::max(1u, std::min(need, 512u));
+    return std::max(1u, std::min(need, kMaxEvalBlocks));
 }
 
 struct ScanCtx {
@@ -475,26 +458,30 @@ struct ScanCtx {
     uint32_t n;
     uint32_t match_blocks;
     int prof_used = 0;
+    double launch_s = 0.0, wait_s = 0.0;  // host time inside launch calls / polling for results
 };
+
+static inline double now_s()
+{
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
 
 static int scan_buffers(lom_map *m, uint32_t n, bool want_stats)
 {
     int rc;
     const size_t nn = std::max<uint32_t>(n, 1);
     if ((rc = ensure(m, m->scan_idx, nn * 4)) != LOM_OK) return rc;
-    if ((rc = ensure(m, m->scan_on, nn * 24)) != LOM_OK) return rc;
+    if ((rc = ensure(m, m->scan_on, nn * sizeof(MatchRec))) != LOM_OK) return rc;
     if (want_stats && (rc = ensure(m, m->scan_stats, nn * sizeof(QStat))) != LOM_OK) return rc;
-    if ((rc = ensure(m, m->partials, (size_t)512 * 28 * 8)) != LOM_OK) return rc;
-    const void *before = m->results.p;
+    if ((rc = ensure(m, m->partials, (size_t)kMaxEvalBlocks * kRecWords * 8)) != LOM_OK) return rc;
     if ((rc = ensure(m, m->results, 1024 + (size_t)kMaxMatchBlocks * 16)) != LOM_OK) return rc;
-    if (m->results.p != before)  // new allocation: sums and the hand-off ticket start at zero
-        LOM_HIP(m, hipMemsetAsync(m->results.p, 0, 1024, m->stream));
     return LOM_OK;
 }
 
 static uint32_t *d_block_counters(lom_map *m) { return (uint32_t *)((char *)m->results.p + 1024); }
 static double *d_sums(lom_map *m) { return (double *)m->results.p; }
-static uint32_t *d_ticket(lom_map *m) { return (uint32_t *)((char *)m->results.p + 512); }
 
 static int launch_match(ScanCtx &c, const float t[3], const float q[4], float max_dist, bool stats)
 {
@@ -502,6 +489,7 @@ static int launch_match(ScanCtx &c, const float t[3], const float q[4], float ma
     PoseArgs P;
     pose_args(t, q, max_dist, P);
     c.match_blocks = c.n ? match_grid(c.n) : 0;
+    const double t_launch = now_s();
     if (c.n) {
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (m->profiling) {
@@ -517,11 +505,12 @@ static int launch_match(ScanCtx &c, const float t[3], const float q[4], float ma
             LOM_HIP(m, hipEventRecord(e0, m->stream));
         }
         hipLaunchKernelGGL(k_match<kMatchG>, dim3(c.match_blocks), dim3(kMatchThreads), 0, m->stream, view_of(m), c.d_src,
-                           c.stride, c.n, P, (int32_t *)m->scan_idx.p, (float *)m->scan_on.p,
+                           c.stride, c.n, P, (int32_t *)m->scan_idx.p, (MatchRec *)m->scan_on.p,
                            stats ? (QStat *)m->scan_stats.p : (QStat *)nullptr, d_block_counters(m));
         LOM_HIP(m, hipGetLastError());
         if (m->profiling) LOM_HIP(m, hipEventRecord(e1, m->stream));
     }
+    c.launch_s += now_s() - t_launch;
     return LOM_OK;
 }
 
@@ -534,24 +523,21 @@ static int launch_eval(ScanCtx &c, const double q[4], const double t[3], bool fr
     for (int i = 0; i < 3; i++) E.t[i] = t[i];
     const uint32_t nb = c.n ? eval_grid(c.n) : 0;
     const bool mailbox = (m->comm == nullptr);
-    if (nb == 0) {
-        // nothing to evaluate on this rank: all sums are zero
-        if (mailbox) {
-            std::memset(out, 0, LOM_NSUMS * 8);
-            for (int k = 0; k < 4; k++) m->last_counters[k] = 0.0;
-            return LOM_OK;
-        }
-        LOM_HIP(m, hipMemsetAsync(d_sums(m), 0, LOM_NSUMS * 8, m->stream));
-    }
     const unsigned long long seq = ++m->mail_seq;
+    std::memset(out, 0, LOM_NSUMS * 8);
+    const double t_launch = now_s();
     if (nb) {
-        hipLaunchKernelGGL(k_eval, dim3(nb), dim3(kEvalThreads), 0, m->stream, c.d_src, c.stride, c.n,
-                           (const int32_t *)m->scan_idx.p, (const float *)m->scan_on.p, E, (double *)m->partials.p,
-                           d_ticket(m), (const uint32_t *)d_block_counters(m), fresh_match ? c.match_blocks : 0u,
-                           d_sums(m), mailbox ? m->d_mail : (double *)nullptr, seq);
+        hipLaunchKernelGGL(k_eval, dim3(nb), dim3(kEvalThreads), 0, m->stream, (const MatchRec *)m->scan_on.p, c.n, E,
+                           (const uint32_t *)d_block_counters(m), fresh_match ? c.match_blocks : 0u,
+                           mailbox ? m->d_mail : (double *)m->partials.p, seq, mailbox ? 1 : 0);
         LOM_HIP(m, hipGetLastError());
     }
+    const double t_wait = now_s();
+    c.launch_s += t_wait - t_launch;
     if (!mailbox) {
+        hipLaunchKernelGGL(k_sum_records, dim3(1), dim3(64), 0, m->stream, (const double *)m->partials.p, nb, c.n,
+                           d_sums(m));
+        LOM_HIP(m, hipGetLastError());
         int rc = ensure(m, m->gather, (size_t)m->nranks * LOM_NSUMS * 8);
         if (rc != LOM_OK) return rc;
         rc = comm_allgather_sums(m, d_sums(m), (double *)m->gather.p, LOM_NSUMS);
@@ -565,24 +551,30 @@ static int launch_eval(ScanCtx &c, const double q[4], const double t[3], bool fr
             out[k] = v;
         }
     } else {
-        // poll the mailbox; fall back to the stream's status so a failed launch cannot hang us
-        volatile unsigned long long *flag = reinterpret_cast<volatile unsigned long long *>(m->h_mail + 32);
+        // poll the records' sequence words in workgroup order and add them up in that order;
+        // the stream's status is consulted now and then so a failed launch cannot hang us
         uint64_t spins = 0;
-        while (*flag != seq) {
-            __builtin_ia32_pause();
-            if ((++spins & 0xFFFF) == 0) {
-                const hipError_t e = hipStreamQuery(m->stream);
-                if (e == hipSuccess) {
-                    if (*flag == seq) break;
-                    if (spins > (1ull << 26)) return set_error(m, LOM_ERR_HIP, "mailbox not written by k_eval");
-                } else if (e != hipErrorNotReady) {
-                    return set_error(m, LOM_ERR_HIP, "stream failed while waiting for k_eval", e);
+        for (uint32_t b = 0; b < nb; b++) {
+            const double *rec = m->h_mail + (size_t)b * kRecWords;
+            volatile const unsigned long long *flag = reinterpret_cast<volatile const unsigned long long *>(rec + 31);
+            while (*flag != seq) {
+                __builtin_ia32_pause();
+                if ((++spins & 0xFFFF) == 0) {
+                    const hipError_t e = hipStreamQuery(m->stream);
+                    if (e == hipSuccess) {
+                        if (*flag == seq) break;
+                        if (spins > (1ull << 26)) return set_error(m, LOM_ERR_HIP, "evaluation record not written");
+                    } else if (e != hipErrorNotReady) {
+                        return set_error(m, LOM_ERR_HIP, "stream failed while waiting for k_eval", e);
+                    }
                 }
             }
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);
+            for (int k = 0; k < 31; k++) out[k] += rec[k];
         }
-        __atomic_thread_fence(__ATOMIC_ACQUIRE);
-        std::memcpy(out, (const void *)m->h_mail, LOM_NSUMS * 8);
+        out[31] = (double)c.n;
     }
+    c.wait_s += now_s() - t_wait;
     // counters of the last k_match are summed on its first evaluation only
     if (fresh_match) {
         for (int k = 0; k < 4; k++) m->last_counters[k] = out[28 + k];
@@ -633,6 +625,8 @@ static int align_device(lom_map *m, const char *d_src, size_t n, size_t stride, 
                 st.match_kernel_ms += ms;
         }
     }
+    st.host_launch_ms = c.launch_s * 1e3;
+    st.host_wait_ms = c.wait_s * 1e3;
     if (stats) *stats = st;
     return LOM_OK;
 }
@@ -667,24 +661,61 @@ int64_t lom_match_find_pairs(lom_map *m, const float *src, size_t n, size_t stri
     ScanCtx c{m, d_src, stride, (uint32_t)n, 0};
     if ((rc = launch_match(c, t, q, max_dist, true)) != LOM_OK) return rc;
     std::vector<int32_t> idx(n);
-    std::vector<float> on(n * 6);
+    std::vector<MatchRec> on(n);
     std::vector<QStat> st(n);
     LOM_HIP(m, hipMemcpyAsync(idx.data(), m->scan_idx.p, n * 4, hipMemcpyDeviceToHost, m->stream));
-    LOM_HIP(m, hipMemcpyAsync(on.data(), m->scan_on.p, n * 24, hipMemcpyDeviceToHost, m->stream));
+    LOM_HIP(m, hipMemcpyAsync(on.data(), m->scan_on.p, n * sizeof(MatchRec), hipMemcpyDeviceToHost, m->stream));
     LOM_HIP(m, hipMemcpyAsync(st.data(), m->scan_stats.p, n * sizeof(QStat), hipMemcpyDeviceToHost, m->stream));
     LOM_HIP(m, hipStreamSynchronize(m->stream));
     int64_t valid = 0;
     for (size_t i = 0; i < n; i++) {
         lom_correspondence &o = out[i];
         o.index = idx[i];
-        std::memcpy(o.origin, &on[i * 6], 12);
-        std::memcpy(o.normal, &on[i * 6 + 3], 12);
+        o.origin[0] = on[i].ox;
+        o.origin[1] = on[i].oy;
+        o.origin[2] = on[i].oz;
+        o.normal[0] = on[i].nx;
+        o.normal[1] = on[i].ny;
+        o.normal[2] = on[i].nz;
         o.sq_dist = st[i].sq_dist;
         o.n_cand = st[i].n_cand;
         o.n_occ = st[i].n_occ;
         valid += idx[i] >= 0;
     }
     return valid;
+}
+
+int lom_profile_match(lom_map *m, const float *d_src, size_t n, size_t stride, const float t[3], const float q[4],
+                      float max_dist, int reps, double *avg_us_out, double *bytes_out)
+{
+    if (!m || !d_src || !n || !t || !q || reps < 1 || !avg_us_out || stride < 12 || (stride & 3)) return LOM_ERR_ARG;
+    if (n >= 0x7FFFFFFFull) return LOM_ERR_ARG;
+    LOM_HIP(m, hipSetDevice(m->device));
+    int rc = scan_buffers(m, (uint32_t)n, false);
+    if (rc != LOM_OK) return rc;
+    ScanCtx c{m, (const char *)d_src, stride, (uint32_t)n, 0};
+    const bool was = m->profiling;
+    m->profiling = false;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    LOM_HIP(m, hipEventCreate(&e0));
+    LOM_HIP(m, hipEventCreate(&e1));
+    rc = launch_match(c, t, q, max_dist, false);  // warm-up
+    if (rc == LOM_OK) rc = hipEventRecord(e0, m->stream) == hipSuccess ? LOM_OK : LOM_ERR_HIP;
+    for (int i = 0; rc == LOM_OK && i < reps; i++) rc = launch_match(c, t, q, max_dist, false);
+    if (rc == LOM_OK) rc = hipEventRecord(e1, m->stream) == hipSuccess ? LOM_OK : LOM_ERR_HIP;
+    double sums[LOM_NSUMS];
+    const double qd[4] = {q[0], q[1], q[2], q[3]}, td[3] = {t[0], t[1], t[2]};
+    if (rc == LOM_OK) rc = launch_eval(c, qd, td, true, sums);  // folds the counters of the last launch
+    if (rc == LOM_OK && hipStreamSynchronize(m->stream) != hipSuccess) rc = LOM_ERR_HIP;
+    float ms = 0.f;
+    if (rc == LOM_OK && hipEventElapsedTime(&ms, e0, e1) != hipSuccess) rc = LOM_ERR_HIP;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    m->profiling = was;
+    if (rc != LOM_OK) return set_error(m, rc, "lom_profile_match failed");
+    *avg_us_out = (double)ms * 1e3 / reps;
+    if (bytes_out) *bytes_out = 444.0 * sums[31] + 12.0 * sums[29] + 12.0 * sums[28];
+    return LOM_OK;
 }
 
 int lom_match_align_device(lom_map *m, const float *d_src, size_t n, size_t stride, const float guess_t[3],

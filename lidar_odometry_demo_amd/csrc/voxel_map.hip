@@ -646,7 +646,7 @@ int lom_map_create(float voxel_size, size_t max_points, size_t capacity_hint, in
         (e = hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipHostMalloc((void **)&m->h_results, 1024 * sizeof(double), hipHostMallocDefault)) != hipSuccess ||
         (e = hipHostMalloc((void **)&m->h_flags, 64 * sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess ||
-        (e = hipHostMalloc((void **)&m->h_mail, 64 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent)) !=
+        (e = hipHostMalloc((void **)&m->h_mail, 64 * 32 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent)) !=
             hipSuccess ||
         (e = hipHostGetDevicePointer((void **)&m->d_mail, m->h_mail, 0)) != hipSuccess) {
         set_error(nullptr, LOM_ERR_HIP, "handle setup", e);
@@ -654,7 +654,7 @@ int lom_map_create(float voxel_size, size_t max_points, size_t capacity_hint, in
         return LOM_ERR_HIP;
     }
     m->stream = m->own_stream;
-    std::memset(m->h_mail, 0, 64 * sizeof(double));
+    std::memset(m->h_mail, 0, 64 * 32 * sizeof(double));
     m->min_cap = next_pow2(4ull * std::max<size_t>(capacity_hint, 256));
     int rc = ensure(m, m->scr[S_MISC], 256);
     if (rc == LOM_OK) {

@@ -1,0 +1,175 @@
+// The reference's gtest cases (test/test.cpp) restated against the header-only mirror
+// include/lidar_odometry_amd.hpp -- same class and method names as the reference, so
+// this file reads like test/test.cpp with `lom::` types in place of Eigen/PCL ones.
+// Built and run by tests/test_cpp_mirror.py on the GPU box (g++, links the C-ABI .so).
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+
+#include "lidar_odometry_amd.hpp"
+
+using namespace lom;
+
+static int g_fail = 0;
+#define EXPECT(cond)                                                       \
+    do {                                                                   \
+        if (!(cond)) {                                                     \
+            std::printf("FAIL %s:%d: %s\n", __FILE__, __LINE__, #cond);   \
+            g_fail++;                                                      \
+        }                                                                  \
+    } while (0)
+
+static Quaternionf angleAxis(float angle, float ax, float ay, float az)
+{
+    const float ha = 0.5f * angle, s = std::sin(ha);
+    return {std::cos(ha), s * ax, s * ay, s * az};
+}
+
+static void VoxelGrid_UniquePoints()  // test.cpp:26-55
+{
+    PointCloud<PointNormal> input_cloud;
+    const float pts[7][3] = {{0, 0, 0}, {1, 0, 0}, {0, 1, 0}, {0, 0, 1}, {-1, 0, 0}, {0, -1, 0}, {0, 0, -1}};
+    for (auto &p : pts) input_cloud.points.emplace_back(p[0], p[1], p[2]);
+    VoxelGrid voxel_grid(0.5, 1);
+    voxel_grid.addCloud(input_cloud);
+    EXPECT(voxel_grid.size() == input_cloud.size());
+    auto output_cloud = voxel_grid.getCloud();
+    EXPECT(input_cloud.size() == output_cloud->size());
+    for (const auto &o : output_cloud->points) {
+        auto it = std::find_if(input_cloud.points.begin(), input_cloud.points.end(),
+                               [&o](const PointNormal &i) { return o.x == i.x && o.y == i.y && o.z == i.z; });
+        EXPECT(it != input_cloud.points.end());
+        if (it != input_cloud.points.end()) input_cloud.points.erase(it);
+    }
+}
+
+static void VoxelGrid_DuplicatePoints()  // test.cpp:57-75
+{
+    PointCloud<PointNormal> input_cloud;
+    input_cloud.points.emplace_back(0, 0, 0);
+    input_cloud.points.emplace_back(1, 0, 0);
+    input_cloud.points.emplace_back(0, 0, 0);
+    input_cloud.points.emplace_back(1, 0, 0);
+    VoxelGrid voxel_grid(0.5, 1);
+    voxel_grid.addCloud(input_cloud);
+    EXPECT(voxel_grid.size() == size_t(2));
+    auto output_cloud = voxel_grid.getCloud();
+    EXPECT(output_cloud->size() == size_t(2));
+    EXPECT(!(output_cloud->points.at(0).x == output_cloud->points.at(1).x &&
+             output_cloud->points.at(0).y == output_cloud->points.at(1).y &&
+             output_cloud->points.at(0).z == output_cloud->points.at(1).z));
+}
+
+static void Pose3D_ComposeRelativeInverse()  // test.cpp:77-149 (group identities)
+{
+    const Pose3D a({1, 0.5f, -0.5f}, angleAxis(0.456f, 0.0976f, 0.1952f, 0.9759f));
+    const Pose3D b({-1, -0.6f, 0}, angleAxis(-0.245f, -1, 0, 0));
+    const Pose3D id = a.compose(a.inverse());
+    EXPECT(std::fabs(id.translation.norm()) < 1e-5f);
+    EXPECT(std::fabs(std::fabs(id.rotation.dot(Quaternionf::Identity())) - 1.f) < 1e-6f);
+    const Pose3D rel = a.relativeTo(b);  // a^-1 * b
+    const Pose3D back = a.compose(rel);
+    EXPECT(std::fabs(back.translation.x() - b.translation.x()) < 1e-5f);
+    EXPECT(std::fabs(back.translation.y() - b.translation.y()) < 1e-5f);
+    EXPECT(std::fabs(back.translation.z() - b.translation.z()) < 1e-5f);
+    EXPECT(std::fabs(std::fabs(back.rotation.dot(b.rotation)) - 1.f) < 1e-6f);
+}
+
+static void CloudTransformer_RigidTransform()  // test.cpp:151-189
+{
+    PointCloud<PointXYZ> sample_cloud;
+    const float pts[7][3] = {{0, 0, 0}, {1, 0, 0}, {-1, 0, 0}, {0, 1, 0}, {0, -1, 0}, {0, 0, 1}, {0, 0, -1}};
+    for (auto &p : pts) sample_cloud.points.emplace_back(p[0], p[1], p[2]);
+    const float d = 3.14159265358979f / 180.f;
+    const Pose3D pose({1, 1, 1}, angleAxis(45.f * d, 0, 0.70710678f, 0.70710678f));
+    auto transformed = CloudTransformer::transform(sample_cloud, pose);
+    float R[9];
+    pose.rotationMatrix(R);
+    for (size_t i = 0; i < sample_cloud.size(); i++) {
+        const PointXYZ &p = sample_cloud.points[i];
+        const float ex = R[0] * p.x + R[1] * p.y + R[2] * p.z + 1.f;
+        const float ey = R[3] * p.x + R[4] * p.y + R[5] * p.z + 1.f;
+        const float ez = R[6] * p.x + R[7] * p.y + R[8] * p.z + 1.f;
+        EXPECT(std::fabs(transformed->at(i).x - ex) < 1e-6f && std::fabs(transformed->at(i).y - ey) < 1e-6f &&
+               std::fabs(transformed->at(i).z - ez) < 1e-6f);
+    }
+}
+
+static void CloudMatcher_MatchingTest()  // protocol of test.cpp:226-262 on a synthetic corner scene
+{
+    // three mutually orthogonal 25 m walls, 60k pseudo-random samples each, exact normals
+    // (enough points that the data term outweighs the translation prior, cloud_matcher.cpp:153)
+    auto full_cloud_with_normals = std::make_shared<PointCloud<PointNormal>>();
+    PointCloud<PointXYZ> full_cloud;
+    auto add = [&](float x, float y, float z, float nx, float ny, float nz) {
+        PointNormal p(x, y, z);
+        p.normal_x = nx, p.normal_y = ny, p.normal_z = nz;
+        full_cloud_with_normals->points.push_back(p);
+        full_cloud.points.emplace_back(x, y, z);
+    };
+    uint32_t lcg = 12345u;
+    auto rnd = [&lcg]() {
+        lcg = lcg * 1664525u + 1013904223u;
+        return (float)((lcg >> 8) / 16777216.0);
+    };
+    for (int w = 0; w < 3; w++)
+        for (int k = 0; k < 60000; k++) {
+            const float u = 1.f + 25.f * rnd(), v = 1.f + 25.f * rnd();
+            if (w == 0) add(u, v, 1.f, 0, 0, 1);
+            if (w == 1) add(u, 1.f, v, 0, 1, 0);
+            if (w == 2) add(1.f, u, v, 1, 0, 0);
+        }
+    VoxelGrid keyframe(0.25, 20);
+    keyframe.addCloud(*full_cloud_with_normals);
+    VoxelGrid voxel_filter(0.5, 1);
+    voxel_filter.addCloudWithoutNormals(full_cloud);
+    auto subsampled_cloud = voxel_filter.getCloudWithoutNormals();
+    EXPECT(subsampled_cloud->size() > 3000);
+
+    CloudMatcher matcher;
+    const float d = 3.14159265358979f / 180.f;
+    const std::vector<Pose3D> guess_poses{
+        Pose3D({0.0f, 0.0f, 0.0f}, Quaternionf::Identity()),
+        Pose3D({0.0f, 0.0f, 0.1f}, Quaternionf::Identity()),
+        Pose3D({0.1f, 0.1f, 0.1f}, Quaternionf::Identity()),
+        Pose3D({-0.1f, -0.1f, -0.1f}, Quaternionf::Identity()),
+        Pose3D({0.1f, -0.1f, 0.f}, Quaternionf::Identity()),
+        Pose3D({0.0f, 0.0f, 0.0f}, angleAxis(-1.0f * d, 0, 0, 1)),
+        Pose3D({-0.2f, 0.0f, 0.0f}, angleAxis(2.0f * d, 0, 0, 1)),
+    };
+    for (const auto &guess_pose : guess_poses) {
+        auto guess_cloud = CloudTransformer::transform(*subsampled_cloud, guess_pose.inverse());
+        auto final_transform = matcher.align(keyframe, *guess_cloud, Pose3D());
+        auto error = final_transform.relativeTo(guess_pose);
+        const double rotation_error = 1.0 - std::fabs(final_transform.rotation.dot(guess_pose.rotation));
+        EXPECT(error.translation.norm() < 0.05);  // test.cpp:261
+        EXPECT(rotation_error < 0.01);            // test.cpp:262
+        EXPECT(matcher.last_stats.outer_iterations >= 5 && matcher.last_stats.outer_iterations <= 35);
+    }
+    // findMatchingPairs / getCorrespondence shapes
+    auto pairs = keyframe.findMatchingPairs(*subsampled_cloud, Pose3D(), 0.3f);
+    EXPECT(!pairs.empty() && pairs.size() <= subsampled_cloud->size());
+    auto c = keyframe.getCorrespondence(Vector3f(12.5f, 12.5f, 1.02f), 0.3f * 0.3f);
+    EXPECT(c.valid && std::fabs(c.plane_normal[2] - 1.0) < 1e-6 && std::fabs(c.plane_origin[2] - 1.0) < 1e-6);
+    // radiusCleanup keeps the voxels whose first point is within the radius (voxel_grid.h:236-246)
+    const size_t before = keyframe.size();
+    keyframe.radiusCleanup(Vector3f(2, 2, 1), 5.0f);
+    EXPECT(keyframe.size() < before && keyframe.size() > 0);
+}
+
+int main()
+{
+    try {
+        VoxelGrid_UniquePoints();
+        VoxelGrid_DuplicatePoints();
+        Pose3D_ComposeRelativeInverse();
+        CloudTransformer_RigidTransform();
+        CloudMatcher_MatchingTest();
+    } catch (const lom::Error &e) {
+        std::printf("lom::Error %d: %s\n", e.code, e.what());
+        return 2;
+    }
+    std::printf(g_fail ? "FAILED (%d)\n" : "ALL PASSED\n", g_fail);
+    return g_fail ? 1 : 0;
+}
