@@ -31,11 +31,18 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def build_workload(n_gpus, rank):
+def build_workload(n_gpus, rank, config="C2"):
     from lidar_odometry_demo_amd import synth
 
     boxes = synth.make_boxes()
     n_beams = 16 * n_gpus
+    if config == "C3":
+        # BASELINE.json configs[2]: 64 beams x 2048 azimuth steps vs a 2M-point map (parity-tested in
+        # tests/test_gpu_parity.py::test_c3_full_size_properties); not the default bench line
+        scan, ring, az, _ = synth.make_scan(64, 2048, boxes=boxes)
+        map_xyz, map_nrm = synth.make_map_points(2_000_000, boxes=boxes)
+        return dict(scan=scan, shard=scan, map_xyz=map_xyz, map_nrm=map_nrm,
+                    name="C3: 64x2048 scan vs 2M-pt map, voxel 0.5 m, cap 20")
     if n_gpus == 1:
         scan, ring, az, _ = synth.make_scan(16, 1800, boxes=boxes)
         shard = scan
@@ -91,6 +98,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--config", choices=["C2", "C3"], default="C2",
+                    help="C2 = BASELINE.json configs[1] (the bench line); C3 = configs[2], single GPU only")
     args = ap.parse_args()
 
     import torch
@@ -110,7 +119,9 @@ def main():
     if n > 1:
         dist.init_process_group("nccl", device_id=dev)
 
-    work = build_workload(n, rank)
+    if args.config != "C2" and n != 1:
+        raise SystemExit("--config C3 is a single-GPU configuration")
+    work = build_workload(n, rank, args.config)
     grid = lom.VoxelGrid(0.5, 20, device=local_rank)
     grid.addCloud(work["map_xyz"], work["map_nrm"])
     grid.setProfiling(True)

@@ -118,6 +118,10 @@ struct lom_map {
     double *h_mail = nullptr;             // host view: 64 records x 32 doubles
     double *d_mail = nullptr;             // device view of the same allocation
     unsigned long long mail_seq = 0;
+    // command word of the resident evaluation server (pinned host memory, host writes, device polls)
+    void *h_cmd = nullptr, *d_cmd = nullptr;
+    bool server_alive = false;
+    bool eval_attr_set = false;
     double last_counters[4] = {0, 0, 0, 0};  // valid, cand, occ, queries of the last k_match
 
     bool profiling = false;

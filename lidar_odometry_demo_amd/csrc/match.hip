@@ -19,6 +19,8 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <ctime>
 #include <vector>
@@ -253,111 +255,116 @@ __global__ __launch_bounds__(kMatchThreads) void k_match(MapView map, const char
 }
 
 // ---------------------------------------------------------------------------
-// k_eval: residual + Jacobian + robust weight + reduction.  One lane per
+// Evaluation: residual + Jacobian + robust weight + reduction.  One lane per
 // source point, grid-stride; 28 f64 accumulators per lane; each workgroup
 // publishes ONE 256-byte record: [0..27] its sums, [28..30] its slice of the
-// counters k_match left per workgroup, [31] the launch's sequence number (bits).
+// counters k_match left per workgroup, [31] the evaluation's sequence number.
 //
-// Single GPU: the records go straight into coherent pinned host memory (payload,
-// system-scope release, then the sequence word); the host polls the <= 64 words
-// and adds the records in workgroup order -- bitwise reproducible, no second
-// kernel, no inter-workgroup hand-off, no copy, no stream synchronisation.
-// Multi GPU: the records stay in HBM and k_sum_records folds them for the RCCL
-// all-gather.
+//   k_eval         one evaluation per launch; records stay in HBM (multi-GPU path:
+//                  k_sum_records folds them for the RCCL all-gather).
+//   k_eval_server  single-GPU path.  Launched once per outer iteration behind
+//                  k_match, it evaluates at the launch pose, then stays resident and
+//                  serves the LM iterations: the host writes {seq, op, pose} into
+//                  pinned host memory, every workgroup polls that word, evaluates,
+//                  and stores its record straight into coherent pinned host memory
+//                  (payload, system-scope release, sequence word).  The host polls the
+//                  <= 64 sequence words and adds the records in workgroup order --
+//                  bitwise reproducible; per LM iteration there is no kernel launch,
+//                  no inter-workgroup hand-off, no copy and no stream synchronisation.
+//                  The first point of every lane stays in registers across
+//                  evaluations.  Workgroups never wait on each other, and every spin
+//                  is bounded by a wall-clock timeout (s_memrealtime), so the grid
+//                  always drains; the host relaunches if a server timed out.
 // ---------------------------------------------------------------------------
-constexpr int kRecWords = 32;  // doubles per record
+constexpr int kRecWords = 32;    // doubles per record
+constexpr int kAccStride = kEvalThreads + 16;  // LDS row stride (doubles): rows k, k+1 land on disjoint banks
 
-__device__ inline double wave_sum(double v)
+struct EvalCmd {  // pinned host memory, written by the host only
+    unsigned long long seq;  // increases with every command
+    unsigned int op;         // kCmdEval / kCmdStop
+    unsigned int pad;
+    double q[4];
+    double t[3];
+};
+constexpr unsigned int kCmdEval = 1, kCmdStop = 2;
+
+// cloud_matcher.cpp:48-102 for one correspondence, accumulated into the 28 sums
+__device__ __forceinline__ void accumulate_point(const float4 ra, const float4 rb, const float4 rc,
+                                                 const double q0, const double q1, const double q2, const double q3,
+                                                 const double t0, const double t1, const double t2, double acc[28])
 {
+    const double p[3] = {(double)ra.x, (double)ra.y, (double)ra.z};
+    const double o[3] = {(double)rb.x, (double)rb.y, (double)rb.z};
+    const double nn[3] = {(double)rb.w, (double)rc.x, (double)rc.y};
+    // cloud_matcher.cpp:54  (rot*local_point + t - plane_origin).dot(plane_normal)
+    double uv0 = q2 * p[2] - q3 * p[1];
+    double uv1 = q3 * p[0] - q1 * p[2];
+    double uv2 = q1 * p[1] - q2 * p[0];
+    uv0 += uv0;
+    uv1 += uv1;
+    uv2 += uv2;
+    const double rp0 = (p[0] + q0 * uv0) + (q2 * uv2 - q3 * uv1);
+    const double rp1 = (p[1] + q0 * uv1) + (q3 * uv0 - q1 * uv2);
+    const double rp2 = (p[2] + q0 * uv2) + (q1 * uv1 - q2 * uv0);
+    const double e0 = rp0 + t0 - o[0], e1 = rp1 + t1 - o[1], e2 = rp2 + t2 - o[2];
+    const double r = e0 * nn[0] + (e1 * nn[1] + e2 * nn[2]);
+    // cloud_matcher.cpp:64-91: ambient d r / d q_i = (dR/dq_i p).n
+    double v0, v1, v2, ja[4];
+    v0 = 2.0 * q0 * p[0] + 2.0 * -q3 * p[1] + 2.0 * q2 * p[2];
+    v1 = 2.0 * q3 * p[0] + 2.0 * q0 * p[1] + 2.0 * -q1 * p[2];
+    v2 = 2.0 * -q2 * p[0] + 2.0 * q1 * p[1] + 2.0 * q0 * p[2];
+    ja[0] = v0 * nn[0] + (v1 * nn[1] + v2 * nn[2]);
+    v0 = 2.0 * q1 * p[0] + 2.0 * q2 * p[1] + 2.0 * q3 * p[2];
+    v1 = 2.0 * q2 * p[0] + 2.0 * -q1 * p[1] + 2.0 * -q0 * p[2];
+    v2 = 2.0 * q3 * p[0] + 2.0 * q0 * p[1] + 2.0 * -q1 * p[2];
+    ja[1] = v0 * nn[0] + (v1 * nn[1] + v2 * nn[2]);
+    v0 = 2.0 * -q2 * p[0] + 2.0 * q1 * p[1] + 2.0 * q0 * p[2];
+    v1 = 2.0 * q1 * p[0] + 2.0 * q2 * p[1] + 2.0 * q3 * p[2];
+    v2 = 2.0 * -q0 * p[0] + 2.0 * q3 * p[1] + 2.0 * -q2 * p[2];
+    ja[2] = v0 * nn[0] + (v1 * nn[1] + v2 * nn[2]);
+    v0 = 2.0 * -q3 * p[0] + 2.0 * -q0 * p[1] + 2.0 * q1 * p[2];
+    v1 = 2.0 * q0 * p[0] + 2.0 * -q3 * p[1] + 2.0 * q2 * p[2];
+    v2 = 2.0 * q1 * p[0] + 2.0 * q2 * p[1] + 2.0 * q3 * p[2];
+    ja[3] = v0 * nn[0] + (v1 * nn[1] + v2 * nn[2]);
+    // Ceres QuaternionManifold plus-Jacobian (4x3): ambient -> tangent
+    double J[6];
+    J[0] = ja[0] * -q1 + ja[1] * q0 + ja[2] * -q3 + ja[3] * q2;
+    J[1] = ja[0] * -q2 + ja[1] * q3 + ja[2] * q0 + ja[3] * -q1;
+    J[2] = ja[0] * -q3 + ja[1] * -q2 + ja[2] * q1 + ja[3] * q0;
+    J[3] = nn[0];  // cloud_matcher.cpp:96-98
+    J[4] = nn[1];
+    J[5] = nn[2];
+    // ceres::HuberLoss(0.15) (cloud_matcher.cpp:134); rho'' <= 0 -> plain IRLS weight rho'
+    const double s = r * r;
+    double rho0 = s, w = 1.0;
+    if (s > 0.15 * 0.15) {
+        const double rr = sqrt(s);
+        rho0 = 2.0 * 0.15 * rr - 0.15 * 0.15;
+        w = fmax(DBL_MIN, 0.15 / rr);
+    }
+    int k = 0;
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-    return v;
+    for (int a = 0; a < 6; a++) {
+        const double wa = w * J[a];
+#pragma unroll
+        for (int b = a; b < 6; b++) acc[k++] += wa * J[b];
+    }
+#pragma unroll
+    for (int a = 0; a < 6; a++) acc[21 + a] += w * J[a] * r;
+    acc[27] += 0.5 * rho0;
 }
 
-__global__ __launch_bounds__(kEvalThreads) void k_eval(const MatchRec *__restrict__ rec, uint32_t n, EvalArgs E,
-                                                       const uint32_t *__restrict__ block_counters,
-                                                       uint32_t n_match_blocks, double *out_rec,
-                                                       unsigned long long seq, int to_host)
+// Workgroup reduction of the 28 per-lane sums through LDS in a fixed order, plus the
+// workgroup's slice of k_match's counters; one wave then writes the 256-byte record.
+// s_acc: dynamic LDS, 28 rows of kAccStride doubles.
+__device__ __forceinline__ void reduce_and_publish(const double acc[28], double *s_acc, unsigned long long *s_cnt,
+                                                   const uint32_t *__restrict__ block_counters,
+                                                   uint32_t n_match_blocks, double *out_rec,
+                                                   unsigned long long seq, int to_host)
 {
-    constexpr int kWaves = kEvalThreads / 64;
-    __shared__ double s_red[kWaves][28];
-    __shared__ unsigned long long s_cnt[3];
-    double acc[28];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #pragma unroll
-    for (int k = 0; k < 28; k++) acc[k] = 0.0;
-    const double q0 = E.q[0], q1 = E.q[1], q2 = E.q[2], q3 = E.q[3];
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const float4 *r4 = reinterpret_cast<const float4 *>(rec + i);
-        const float4 ra = r4[0], rb = r4[1], rc = r4[2];
-        if (ra.w == 0.f) continue;
-        const double p[3] = {(double)ra.x, (double)ra.y, (double)ra.z};
-        const double o[3] = {(double)rb.x, (double)rb.y, (double)rb.z};
-        const double nn[3] = {(double)rb.w, (double)rc.x, (double)rc.y};
-        // cloud_matcher.cpp:54  (rot*local_point + t - plane_origin).dot(plane_normal)
-        double uv0 = q2 * p[2] - q3 * p[1];
-        double uv1 = q3 * p[0] - q1 * p[2];
-        double uv2 = q1 * p[1] - q2 * p[0];
-        uv0 += uv0;
-        uv1 += uv1;
-        uv2 += uv2;
-        const double rp0 = (p[0] + q0 * uv0) + (q2 * uv2 - q3 * uv1);
-        const double rp1 = (p[1] + q0 * uv1) + (q3 * uv0 - q1 * uv2);
-        const double rp2 = (p[2] + q0 * uv2) + (q1 * uv1 - q2 * uv0);
-        const double e0 = rp0 + E.t[0] - o[0], e1 = rp1 + E.t[1] - o[1], e2 = rp2 + E.t[2] - o[2];
-        const double r = e0 * nn[0] + (e1 * nn[1] + e2 * nn[2]);
-        // cloud_matcher.cpp:64-91: ambient d r / d q_i = (dR/dq_i p).n
-        double v0, v1, v2, ja[4];
-        v0 = 2.0 * q0 * p[0] + 2.0 * -q3 * p[1] + 2.0 * q2 * p[2];
-        v1 = 2.0 * q3 * p[0] + 2.0 * q0 * p[1] + 2.0 * -q1 * p[2];
-        v2 = 2.0 * -q2 * p[0] + 2.0 * q1 * p[1] + 2.0 * q0 * p[2];
-        ja[0] = v0 * nn[0] + (v1 * nn[1] + v2 * nn[2]);
-        v0 = 2.0 * q1 * p[0] + 2.0 * q2 * p[1] + 2.0 * q3 * p[2];
-        v1 = 2.0 * q2 * p[0] + 2.0 * -q1 * p[1] + 2.0 * -q0 * p[2];
-        v2 = 2.0 * q3 * p[0] + 2.0 * q0 * p[1] + 2.0 * -q1 * p[2];
-        ja[1] = v0 * nn[0] + (v1 * nn[1] + v2 * nn[2]);
-        v0 = 2.0 * -q2 * p[0] + 2.0 * q1 * p[1] + 2.0 * q0 * p[2];
-        v1 = 2.0 * q1 * p[0] + 2.0 * q2 * p[1] + 2.0 * q3 * p[2];
-        v2 = 2.0 * -q0 * p[0] + 2.0 * q3 * p[1] + 2.0 * -q2 * p[2];
-        ja[2] = v0 * nn[0] + (v1 * nn[1] + v2 * nn[2]);
-        v0 = 2.0 * -q3 * p[0] + 2.0 * -q0 * p[1] + 2.0 * q1 * p[2];
-        v1 = 2.0 * q0 * p[0] + 2.0 * -q3 * p[1] + 2.0 * q2 * p[2];
-        v2 = 2.0 * q1 * p[0] + 2.0 * q2 * p[1] + 2.0 * q3 * p[2];
-        ja[3] = v0 * nn[0] + (v1 * nn[1] + v2 * nn[2]);
-        // Ceres QuaternionManifold plus-Jacobian (4x3): ambient -> tangent
-        double J[6];
-        J[0] = ja[0] * -q1 + ja[1] * q0 + ja[2] * -q3 + ja[3] * q2;
-        J[1] = ja[0] * -q2 + ja[1] * q3 + ja[2] * q0 + ja[3] * -q1;
-        J[2] = ja[0] * -q3 + ja[1] * -q2 + ja[2] * q1 + ja[3] * q0;
-        J[3] = nn[0];  // cloud_matcher.cpp:96-98
-        J[4] = nn[1];
-        J[5] = nn[2];
-        // ceres::HuberLoss(0.15) (cloud_matcher.cpp:134); rho'' <= 0 -> plain IRLS weight rho'
-        const double s = r * r;
-        double rho0 = s, w = 1.0;
-        if (s > 0.15 * 0.15) {
-            const double rr = sqrt(s);
-            rho0 = 2.0 * 0.15 * rr - 0.15 * 0.15;
-            w = fmax(DBL_MIN, 0.15 / rr);
-        }
-        int k = 0;
-#pragma unroll
-        for (int a = 0; a < 6; a++) {
-            const double wa = w * J[a];
-#pragma unroll
-            for (int b = a; b < 6; b++) acc[k++] += wa * J[b];
-        }
-#pragma unroll
-        for (int a = 0; a < 6; a++) acc[21 + a] += w * J[a] * r;
-        acc[27] += 0.5 * rho0;
-    }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int k = 0; k < 28; k++) {
-        const double v = wave_sum(acc[k]);
-        if (lane == 0) s_red[wave][k] = v;
-    }
-    // this workgroup's slice of k_match's per-workgroup counters (first evaluation of an
-    // outer iteration only), folded by its first wave
+    for (int k = 0; k < 28; k++) s_acc[k * kAccStride + tid] = acc[k];
     if (wave == 0 && n_match_blocks) {
         const uint32_t chunk = (n_match_blocks + gridDim.x - 1) / gridDim.x;
         const uint32_t lo = blockIdx.x * chunk;
@@ -382,22 +389,124 @@ __global__ __launch_bounds__(kEvalThreads) void k_eval(const MatchRec *__restric
         }
     }
     __syncthreads();
-    if (threadIdx.x < 32) {  // one wave writes the whole 256-byte record
-        double v = 0.0;
-        if (threadIdx.x < 28) {
+    // thread (k = tid / 16, j = tid % 16) adds row k's elements j, j+16, ... in order
+    const int k = tid >> 4, j = tid & 15;
+    double v = 0.0;
+    if (k < 28) {
+        const double *row = s_acc + k * kAccStride + j;
+#pragma unroll 8
+        for (int i = 0; i < kEvalThreads / 16; i++) v += row[i * 16];
+    }
 #pragma unroll
-            for (int w = 0; w < kWaves; w++) v += s_red[w][threadIdx.x];
-        } else if (threadIdx.x < 31) {
-            v = n_match_blocks ? (double)s_cnt[threadIdx.x - 28] : 0.0;
-        }
+    for (int d = 8; d >= 1; d >>= 1) v += __shfl_xor(v, d, 16);
+    __syncthreads();  // every read of s_acc is done: its first words become the staging row
+    if (j == 0 && k < 28) s_acc[k] = v;
+    __syncthreads();
+    if (tid < 32) {  // one wave writes the whole 256-byte record
+        double o = 0.0;
+        if (tid < 28)
+            o = s_acc[tid];
+        else if (tid < 31)
+            o = n_match_blocks ? (double)s_cnt[tid - 28] : 0.0;
         double *dst = out_rec + (size_t)blockIdx.x * kRecWords;
-        if (threadIdx.x < 31) dst[threadIdx.x] = v;
+        if (tid < 31) dst[tid] = o;
         if (to_host) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // system scope: payload before the sequence word
-            if (threadIdx.x == 31)
+            if (tid == 31)
                 __hip_atomic_store(reinterpret_cast<unsigned long long *>(dst + 31), seq, __ATOMIC_RELEASE,
                                    __HIP_MEMORY_SCOPE_SYSTEM);
         }
+    }
+    __syncthreads();  // s_acc / s_cnt may be rewritten by the next evaluation
+}
+
+__global__ __launch_bounds__(kEvalThreads) void k_eval(const MatchRec *__restrict__ rec, uint32_t n, EvalArgs E,
+                                                       const uint32_t *__restrict__ block_counters,
+                                                       uint32_t n_match_blocks, double *out_rec,
+                                                       unsigned long long seq)
+{
+    extern __shared__ __attribute__((aligned(16))) double s_acc[];
+    __shared__ unsigned long long s_cnt[3];
+    double acc[28];
+#pragma unroll
+    for (int k = 0; k < 28; k++) acc[k] = 0.0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float4 *r4 = reinterpret_cast<const float4 *>(rec + i);
+        const float4 ra = r4[0], rb = r4[1], rc = r4[2];
+        if (ra.w != 0.f) accumulate_point(ra, rb, rc, E.q[0], E.q[1], E.q[2], E.q[3], E.t[0], E.t[1], E.t[2], acc);
+    }
+    reduce_and_publish(acc, s_acc, s_cnt, block_counters, n_match_blocks, out_rec, seq, 0);
+}
+
+__global__ __launch_bounds__(kEvalThreads) void k_eval_server(const MatchRec *__restrict__ rec, uint32_t n,
+                                                              EvalArgs E0, const uint32_t *__restrict__ block_counters,
+                                                              uint32_t n_match_blocks, double *out_rec,
+                                                              unsigned long long seq0, const EvalCmd *cmd,
+                                                              unsigned long long cmd_seen,
+                                                              unsigned long long timeout_ticks)
+{
+    extern __shared__ __attribute__((aligned(16))) double s_acc[];
+    __shared__ unsigned long long s_cnt[3];
+    __shared__ EvalCmd s_cmd;
+    const uint32_t first = blockIdx.x * blockDim.x + threadIdx.x, step = gridDim.x * blockDim.x;
+    // this lane's first point stays in registers for every evaluation of the outer iteration
+    float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra, rc = ra;
+    if (first < n) {
+        const float4 *r4 = reinterpret_cast<const float4 *>(rec + first);
+        ra = r4[0];
+        rb = r4[1];
+        rc = r4[2];
+    }
+    double q0 = E0.q[0], q1 = E0.q[1], q2 = E0.q[2], q3 = E0.q[3], t0 = E0.t[0], t1 = E0.t[1], t2 = E0.t[2];
+    unsigned long long seq = seq0;
+    uint32_t counters_from = n_match_blocks;  // counters are folded by the first evaluation only
+    for (;;) {
+        double acc[28];
+#pragma unroll
+        for (int k = 0; k < 28; k++) acc[k] = 0.0;
+        if (ra.w != 0.f) accumulate_point(ra, rb, rc, q0, q1, q2, q3, t0, t1, t2, acc);
+        for (uint32_t i = first + step; i < n; i += step) {
+            const float4 *r4 = reinterpret_cast<const float4 *>(rec + i);
+            const float4 xa = r4[0], xb = r4[1], xc = r4[2];
+            if (xa.w != 0.f) accumulate_point(xa, xb, xc, q0, q1, q2, q3, t0, t1, t2, acc);
+        }
+        reduce_and_publish(acc, s_acc, s_cnt, block_counters, counters_from, out_rec, seq, 1);
+        counters_from = 0;
+        // wait for the next command from the host (bounded: the grid always drains).  The first
+        // wave reads the 72-byte command with ONE instruction per poll (lanes 0..8, one word each,
+        // relaxed system-scope loads: no cache invalidate per poll), then once more after the
+        // sequence word changed -- the host wrote the payload before the sequence word.
+        if (threadIdx.x < 64) {
+            const int lane = threadIdx.x;
+            unsigned long long *words = reinterpret_cast<unsigned long long *>(const_cast<EvalCmd *>(cmd));
+            unsigned long long *my = words + (lane < 9 ? lane : 0);
+            const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+            bool timed_out = false;
+            for (;;) {
+                const unsigned long long w = __hip_atomic_load(my, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (__shfl(w, 0, 64) != cmd_seen) break;
+                if (__builtin_amdgcn_s_memrealtime() - t_start > timeout_ticks) {
+                    timed_out = true;  // host went away: leave
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(4);
+            }
+            const unsigned long long w = __hip_atomic_load(my, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (lane < 9) reinterpret_cast<unsigned long long *>(&s_cmd)[lane] = w;
+            if (timed_out && lane == 0) s_cmd.op = kCmdStop;
+        }
+        __syncthreads();
+        if (s_cmd.op != kCmdEval) return;  // uniform over the workgroup
+        q0 = s_cmd.q[0];
+        q1 = s_cmd.q[1];
+        q2 = s_cmd.q[2];
+        q3 = s_cmd.q[3];
+        t0 = s_cmd.t[0];
+        t1 = s_cmd.t[1];
+        t2 = s_cmd.t[2];
+        seq = s_cmd.seq;
+        cmd_seen = s_cmd.seq;
+        __syncthreads();  // s_cmd is rewritten by thread 0 in the next round
     }
 }
 
@@ -483,12 +592,15 @@ static int scan_buffers(lom_map *m, uint32_t n, bool want_stats)
 static uint32_t *d_block_counters(lom_map *m) { return (uint32_t *)((char *)m->results.p + 1024); }
 static double *d_sums(lom_map *m) { return (double *)m->results.p; }
 
+static void server_stop(lom_map *m);
+
 static int launch_match(ScanCtx &c, const float t[3], const float q[4], float max_dist, bool stats)
 {
     lom_map *m = c.m;
     PoseArgs P;
     pose_args(t, q, max_dist, P);
     c.match_blocks = c.n ? match_grid(c.n) : 0;
+    server_stop(m);  // the previous outer iteration's evaluation server leaves before the new search
     const double t_launch = now_s();
     if (c.n) {
         hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -514,6 +626,66 @@ static int launch_match(ScanCtx &c, const float t[3], const float q[4], float ma
     return LOM_OK;
 }
 
+constexpr size_t kEvalLdsBytes = (size_t)28 * kAccStride * sizeof(double);
+constexpr unsigned long long kServerTimeoutTicks = 5000000ull;  // 50 ms of s_memrealtime (100 MHz)
+
+// LOM_TEST_SERVER_TIMEOUT_TICKS shortens the server's patience so that tests can exercise the
+// "server left, relaunch" path deterministically
+static unsigned long long server_timeout_ticks()
+{
+    const char *e = getenv("LOM_TEST_SERVER_TIMEOUT_TICKS");
+    if (e && *e) return strtoull(e, nullptr, 10);
+    return kServerTimeoutTicks;
+}
+
+static int eval_kernel_attrs(lom_map *m)
+{
+    if (m->eval_attr_set) return LOM_OK;
+    LOM_HIP(m, hipFuncSetAttribute(reinterpret_cast<const void *>(k_eval), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)kEvalLdsBytes));
+    LOM_HIP(m, hipFuncSetAttribute(reinterpret_cast<const void *>(k_eval_server),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEvalLdsBytes));
+    m->eval_attr_set = true;
+    return LOM_OK;
+}
+
+// tell a resident evaluation server to leave (it exits within one poll of the command word)
+static void server_stop(lom_map *m)
+{
+    if (!m->server_alive) return;
+    EvalCmd *cmd = reinterpret_cast<EvalCmd *>(m->h_cmd);
+    cmd->op = kCmdStop;
+    __atomic_store_n(&cmd->seq, ++m->mail_seq, __ATOMIC_RELEASE);
+    m->server_alive = false;
+}
+
+// wait for the nb records of evaluation `seq` and add them in workgroup order.
+// returns LOM_OK, a negative status, or 1 when the stream went idle without the records
+// (the server timed out and left; the caller relaunches)
+static int collect_records(lom_map *m, uint32_t nb, unsigned long long seq, double out[LOM_NSUMS])
+{
+    uint64_t spins = 0;
+    for (uint32_t b = 0; b < nb; b++) {
+        const double *rec = m->h_mail + (size_t)b * kRecWords;
+        volatile const unsigned long long *flag = reinterpret_cast<volatile const unsigned long long *>(rec + 31);
+        while (*flag != seq) {
+            __builtin_ia32_pause();
+            if ((++spins & 0x3FFF) == 0) {
+                const hipError_t e = hipStreamQuery(m->stream);
+                if (e == hipSuccess) {
+                    if (*flag == seq) break;
+                    return 1;
+                } else if (e != hipErrorNotReady) {
+                    return set_error(m, LOM_ERR_HIP, "stream failed while waiting for an evaluation", e);
+                }
+            }
+        }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        for (int k = 0; k < 31; k++) out[k] += rec[k];
+    }
+    return LOM_OK;
+}
+
 // evaluation at (q,t) -> host sums (rank-local, or rank-ordered total with a communicator)
 static int launch_eval(ScanCtx &c, const double q[4], const double t[3], bool fresh_match, double out[LOM_NSUMS])
 {
@@ -523,22 +695,23 @@ static int launch_eval(ScanCtx &c, const double q[4], const double t[3], bool fr
     for (int i = 0; i < 3; i++) E.t[i] = t[i];
     const uint32_t nb = c.n ? eval_grid(c.n) : 0;
     const bool mailbox = (m->comm == nullptr);
-    const unsigned long long seq = ++m->mail_seq;
     std::memset(out, 0, LOM_NSUMS * 8);
+    int rc = eval_kernel_attrs(m);
+    if (rc != LOM_OK) return rc;
     const double t_launch = now_s();
-    if (nb) {
-        hipLaunchKernelGGL(k_eval, dim3(nb), dim3(kEvalThreads), 0, m->stream, (const MatchRec *)m->scan_on.p, c.n, E,
-                           (const uint32_t *)d_block_counters(m), fresh_match ? c.match_blocks : 0u,
-                           mailbox ? m->d_mail : (double *)m->partials.p, seq, mailbox ? 1 : 0);
-        LOM_HIP(m, hipGetLastError());
-    }
-    const double t_wait = now_s();
-    c.launch_s += t_wait - t_launch;
     if (!mailbox) {
+        const unsigned long long seq = ++m->mail_seq;
+        if (nb) {
+            hipLaunchKernelGGL(k_eval, dim3(nb), dim3(kEvalThreads), kEvalLdsBytes, m->stream,
+                               (const MatchRec *)m->scan_on.p, c.n, E, (const uint32_t *)d_block_counters(m),
+                               fresh_match ? c.match_blocks : 0u, (double *)m->partials.p, seq);
+        }
         hipLaunchKernelGGL(k_sum_records, dim3(1), dim3(64), 0, m->stream, (const double *)m->partials.p, nb, c.n,
                            d_sums(m));
         LOM_HIP(m, hipGetLastError());
-        int rc = ensure(m, m->gather, (size_t)m->nranks * LOM_NSUMS * 8);
+        c.launch_s += now_s() - t_launch;
+        const double t_wait = now_s();
+        rc = ensure(m, m->gather, (size_t)m->nranks * LOM_NSUMS * 8);
         if (rc != LOM_OK) return rc;
         rc = comm_allgather_sums(m, d_sums(m), (double *)m->gather.p, LOM_NSUMS);
         if (rc != LOM_OK) return rc;
@@ -550,31 +723,46 @@ static int launch_eval(ScanCtx &c, const double q[4], const double t[3], bool fr
             for (int r = 0; r < m->nranks; r++) v += m->h_results[(size_t)r * LOM_NSUMS + k];  // rank order
             out[k] = v;
         }
-    } else {
-        // poll the records' sequence words in workgroup order and add them up in that order;
-        // the stream's status is consulted now and then so a failed launch cannot hang us
-        uint64_t spins = 0;
-        for (uint32_t b = 0; b < nb; b++) {
-            const double *rec = m->h_mail + (size_t)b * kRecWords;
-            volatile const unsigned long long *flag = reinterpret_cast<volatile const unsigned long long *>(rec + 31);
-            while (*flag != seq) {
-                __builtin_ia32_pause();
-                if ((++spins & 0xFFFF) == 0) {
-                    const hipError_t e = hipStreamQuery(m->stream);
-                    if (e == hipSuccess) {
-                        if (*flag == seq) break;
-                        if (spins > (1ull << 26)) return set_error(m, LOM_ERR_HIP, "evaluation record not written");
-                    } else if (e != hipErrorNotReady) {
-                        return set_error(m, LOM_ERR_HIP, "stream failed while waiting for k_eval", e);
-                    }
-                }
+        c.wait_s += now_s() - t_wait;
+    } else if (nb) {
+        for (int attempt = 0;; attempt++) {
+            unsigned long long seq;
+            const double t_l = now_s();
+            if (fresh_match || !m->server_alive) {
+                // (re)start the evaluation server of this outer iteration; its first evaluation is this one
+                EvalCmd *cmd = reinterpret_cast<EvalCmd *>(m->h_cmd);
+                seq = ++m->mail_seq;
+                hipLaunchKernelGGL(k_eval_server, dim3(nb), dim3(kEvalThreads), kEvalLdsBytes, m->stream,
+                                   (const MatchRec *)m->scan_on.p, c.n, E, (const uint32_t *)d_block_counters(m),
+                                   fresh_match ? c.match_blocks : 0u, m->d_mail, seq,
+                                   reinterpret_cast<const EvalCmd *>(m->d_cmd), (unsigned long long)cmd->seq,
+                                   server_timeout_ticks());
+                LOM_HIP(m, hipGetLastError());
+                m->server_alive = true;
+            } else {
+                EvalCmd *cmd = reinterpret_cast<EvalCmd *>(m->h_cmd);
+                for (int a = 0; a < 4; a++) cmd->q[a] = q[a];
+                for (int a = 0; a < 3; a++) cmd->t[a] = t[a];
+                cmd->op = kCmdEval;
+                seq = ++m->mail_seq;
+                __atomic_store_n(&cmd->seq, seq, __ATOMIC_RELEASE);  // payload before the sequence word
             }
-            __atomic_thread_fence(__ATOMIC_ACQUIRE);
-            for (int k = 0; k < 31; k++) out[k] += rec[k];
+            const double t_w = now_s();
+            c.launch_s += t_w - t_l;
+            std::memset(out, 0, LOM_NSUMS * 8);
+            rc = collect_records(m, nb, seq, out);
+            c.wait_s += now_s() - t_w;
+            if (getenv("LOM_DEBUG_TIMING"))
+                fprintf(stderr, "eval %s launch %.1f us wait %.1f us\n", fresh_match ? "fresh" : "fixed",
+                        (t_w - t_l) * 1e6, (now_s() - t_w) * 1e6);
+            if (rc == LOM_OK) break;
+            if (rc < 0) return rc;
+            m->server_alive = false;  // the server timed out and left (host was away > 50 ms): start another
+            fresh_match = false;      // counters were already folded, or are folded again below
+            if (attempt >= 3) return set_error(m, LOM_ERR_HIP, "evaluation server did not answer");
         }
         out[31] = (double)c.n;
     }
-    c.wait_s += now_s() - t_wait;
     // counters of the last k_match are summed on its first evaluation only
     if (fresh_match) {
         for (int k = 0; k < 4; k++) m->last_counters[k] = out[28 + k];
@@ -613,6 +801,7 @@ static int align_device(lom_map *m, const char *d_src, size_t n, size_t stride, 
     hooks.allreduce = nullptr;  // the rank-ordered all-gather sits inside launch_eval
     lom_align_stats st;
     rc = lom_align_with_hooks(&hooks, guess_t, guess_q, out_t, out_q, &st);
+    server_stop(m);
     if (rc != LOM_OK) {
         if (m->last_error.empty()) set_error(m, rc, "align failed");
         return rc == LOM_ERR_HOOK ? LOM_ERR_HIP : rc;
@@ -706,6 +895,7 @@ int lom_profile_match(lom_map *m, const float *d_src, size_t n, size_t stride, c
     double sums[LOM_NSUMS];
     const double qd[4] = {q[0], q[1], q[2], q[3]}, td[3] = {t[0], t[1], t[2]};
     if (rc == LOM_OK) rc = launch_eval(c, qd, td, true, sums);  // folds the counters of the last launch
+    server_stop(m);
     if (rc == LOM_OK && hipStreamSynchronize(m->stream) != hipSuccess) rc = LOM_ERR_HIP;
     float ms = 0.f;
     if (rc == LOM_OK && hipEventElapsedTime(&ms, e0, e1) != hipSuccess) rc = LOM_ERR_HIP;

@@ -648,13 +648,16 @@ int lom_map_create(float voxel_size, size_t max_points, size_t capacity_hint, in
         (e = hipHostMalloc((void **)&m->h_flags, 64 * sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess ||
         (e = hipHostMalloc((void **)&m->h_mail, 64 * 32 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent)) !=
             hipSuccess ||
-        (e = hipHostGetDevicePointer((void **)&m->d_mail, m->h_mail, 0)) != hipSuccess) {
+        (e = hipHostGetDevicePointer((void **)&m->d_mail, m->h_mail, 0)) != hipSuccess ||
+        (e = hipHostMalloc(&m->h_cmd, 256, hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess ||
+        (e = hipHostGetDevicePointer(&m->d_cmd, m->h_cmd, 0)) != hipSuccess) {
         set_error(nullptr, LOM_ERR_HIP, "handle setup", e);
         lom_map_destroy(m);
         return LOM_ERR_HIP;
     }
     m->stream = m->own_stream;
     std::memset(m->h_mail, 0, 64 * 32 * sizeof(double));
+    std::memset(m->h_cmd, 0, 256);
     m->min_cap = next_pow2(4ull * std::max<size_t>(capacity_hint, 256));
     int rc = ensure(m, m->scr[S_MISC], 256);
     if (rc == LOM_OK) {
@@ -676,6 +679,12 @@ void lom_map_destroy(lom_map *m)
 {
     if (!m) return;
     (void)hipSetDevice(m->device);
+    if (m->server_alive && m->h_cmd) {  // a resident evaluation server leaves on op = 2 (stop)
+        unsigned long long *w = reinterpret_cast<unsigned long long *>(m->h_cmd);
+        reinterpret_cast<unsigned int *>(w + 1)[0] = 2u;
+        __atomic_store_n(w, ++m->mail_seq, __ATOMIC_RELEASE);
+        m->server_alive = false;
+    }
     if (m->stream) (void)hipStreamSynchronize(m->stream);
     if (m->comm) lom_comm_finalize(m);
     if (m->d_table) (void)hipFree(m->d_table);
@@ -688,6 +697,7 @@ void lom_map_destroy(lom_map *m)
     if (m->h_results) (void)hipHostFree(m->h_results);
     if (m->h_flags) (void)hipHostFree(m->h_flags);
     if (m->h_mail) (void)hipHostFree(m->h_mail);
+    if (m->h_cmd) (void)hipHostFree(m->h_cmd);
     for (auto &e : m->prof_events)
         if (e) (void)hipEventDestroy(e);
     if (m->own_stream) (void)hipStreamDestroy(m->own_stream);

@@ -271,6 +271,26 @@ def test_align_parity_synth(lom, oracle):
     assert dt < POSE_TOL_M and dr < POSE_TOL_RAD
 
 
+def test_evaluation_server_timeout_recovery(lom, monkeypatch):
+    """The resident evaluation server leaves when the host stays away (bounded spin); the host
+    then relaunches it.  With a 1-tick timeout every LM iteration takes that path: same bits."""
+    sm = scenes.small_synth_case()
+    g = lom.VoxelGrid(0.5, 20)
+    g.addCloud(sm["map_xyz"], sm["map_nrm"])
+    m = lom.CloudMatcher()
+    ref = m.align(g, sm["scan"], lom.Pose3D())
+    ref_stats = dict(m.stats)
+    monkeypatch.setenv("LOM_TEST_SERVER_TIMEOUT_TICKS", "1")
+    got = m.align(g, sm["scan"], lom.Pose3D())
+    assert got.translation.tobytes() == ref.translation.tobytes()
+    assert got.rotation.tobytes() == ref.rotation.tobytes()
+    for k in ("outer_iterations", "evaluations", "queries", "cand_total", "valid_last"):
+        assert m.stats[k] == ref_stats[k]
+    monkeypatch.delenv("LOM_TEST_SERVER_TIMEOUT_TICKS")
+    again = m.align(g, sm["scan"], lom.Pose3D())
+    assert again.translation.tobytes() == ref.translation.tobytes()
+
+
 def test_zero_matches_returns_guess(lom):
     g = lom.VoxelGrid(0.5, 20)
     g.addCloudWithoutNormals(np.array([[50, 50, 50]], np.float32))
