@@ -190,6 +190,55 @@ int lom_align_with_hooks(const lom_align_hooks *hooks, const float guess_t[3],
                          const float guess_q_wxyz[4], float out_t[3], float out_q_wxyz[4],
                          lom_align_stats *stats_or_null);
 
+/* ---- callers of the path, ROS-free; host code over the ABI above -- */
+/* lidar_point::PointXYZIRT (src/lidar_point_type.h:13-21): 32 bytes, same field offsets */
+typedef struct {
+    float x, y, z, pad0;
+    float intensity;
+    uint16_t ring;
+    uint16_t pad1;
+    float time;
+    float pad2;
+} lom_point_xyzirt;
+
+/* utils::pointTimeNormalize, src/utils/point_time_normalize.h:15-39 */
+void lom_point_time_normalize(const lom_point_xyzirt *in, size_t n, lom_point_xyzirt *out);
+/* CloudTransformer::transformNonRigid (deskew), src/utils/cloud_transform.h:15-40 */
+void lom_transform_non_rigid(const lom_point_xyzirt *in, size_t n, const lom_pose *start_pose,
+                             const lom_pose *end_pose, lom_point_xyzirt *out);
+/* utils::rangeFilter, src/utils/range_filter.h:13-28; packed xyz (+ optional normals); returns kept count */
+size_t lom_range_filter(const float *xyz, const float *nrm, size_t n, float min_range, float max_range,
+                        float *xyz_out, float *nrm_out);
+/* CloudClassifier::classify, src/utils/cloud_classifier.h:19-168: planar points with normals
+ * (outputs sized for n points); the unclassified cloud's size and the organised grid {height,
+ * width} are optional outputs.  Returns the number of planar points. */
+size_t lom_cloud_classify(const lom_point_xyzirt *in, size_t n, float *xyz_out, float *nrm_out,
+                          size_t *unclassified_out, size_t grid_out[2]);
+
+/* LidarOdometry::Params, src/lidar_odometry.h:23-48 */
+typedef struct {
+    float lidar_min_range, lidar_max_range;
+    float keyframe_voxel_size;
+    uint32_t keyframe_max_points_cnt;
+    float keyframe_matching_voxel_size, keyframe_update_voxel_size;
+    float keyframe_cleanup_range, angular_divergence_threshold;
+} lom_odometry_params;
+
+typedef struct {
+    int64_t planar_points, filtered_points, update_points, matching_points, keyframe_voxels, queries;
+    int32_t outer_iterations, initialised_keyframe, unstable_rotation, pad;
+} lom_odometry_frame_stats;
+
+typedef struct lom_odometry lom_odometry;
+void lom_odometry_default_params(lom_odometry_params *p);          /* lidar_odometry.h:36-48 defaults */
+int lom_odometry_create(const lom_odometry_params *p, int device, lom_odometry **out); /* lidar_odometry.cpp:14-20 */
+void lom_odometry_destroy(lom_odometry *o);
+int lom_odometry_process_cloud(lom_odometry *o, const lom_point_xyzirt *pts, size_t n); /* :22-77 */
+int lom_odometry_get_pose(const lom_odometry *o, lom_pose *out);   /* getCurrentPose, :87-89 */
+int lom_odometry_get_stats(const lom_odometry *o, lom_odometry_frame_stats *out);
+lom_map *lom_odometry_keyframe(lom_odometry *o); /* keyframe_ (getKeyFrameCloud / getFullKeyFrameCloud via lom_map_export) */
+const char *lom_odometry_last_error(const lom_odometry *o);
+
 #ifdef __cplusplus
 }
 #endif

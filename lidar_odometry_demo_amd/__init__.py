@@ -14,7 +14,8 @@ import numpy as np
 from . import capi
 from .capi import LomError  # noqa: F401
 
-__all__ = ["Pose3D", "VoxelGrid", "CloudMatcher", "transform_points", "LomError", "capi"]
+__all__ = ["Pose3D", "VoxelGrid", "CloudMatcher", "LidarOdometry", "transform_points", "pointTimeNormalize",
+           "transformNonRigid", "rangeFilter", "classify", "LomError", "capi"]
 
 
 class Pose3D:
@@ -204,3 +205,109 @@ class CloudMatcher:
             capi.f4(position_guess.rotation), ot, oq, C.byref(st)), keyframe.handle)
         self.stats = st.asdict()
         return Pose3D(np.array(ot[:], np.float32), np.array(oq[:], np.float32))
+
+
+# ---- callers of the path: host code in the library over the C ABI --------
+
+def _cloud(points):
+    a = np.ascontiguousarray(points, dtype=capi.POINT_XYZIRT)
+    if a.ndim != 1:
+        raise ValueError("expected a 1-d array of POINT_XYZIRT records")
+    return a
+
+
+def pointTimeNormalize(points):
+    """utils::pointTimeNormalize (src/utils/point_time_normalize.h:15-39)."""
+    a = _cloud(points)
+    out = np.empty_like(a)
+    capi.lib().lom_point_time_normalize(a.ctypes.data, len(a), out.ctypes.data)
+    return out
+
+
+def transformNonRigid(points, start_pose, end_pose):
+    """CloudTransformer::transformNonRigid (src/utils/cloud_transform.h:15-40)."""
+    a = _cloud(points)
+    out = np.empty_like(a)
+    capi.lib().lom_transform_non_rigid(a.ctypes.data, len(a), C.byref(start_pose._c()), C.byref(end_pose._c()),
+                                       out.ctypes.data)
+    return out
+
+
+def rangeFilter(xyz, normals, min_range, max_range):
+    """utils::rangeFilter (src/utils/range_filter.h:13-28) on packed xyz (+ normals)."""
+    xyz = capi.xyz_array(xyz)
+    normals = capi.xyz_array(normals) if normals is not None else None
+    oxyz = np.empty_like(xyz)
+    onrm = np.empty_like(xyz) if normals is not None else None
+    n = capi.lib().lom_range_filter(xyz.ctypes.data, normals.ctypes.data if normals is not None else None, len(xyz),
+                                    float(min_range), float(max_range), oxyz.ctypes.data,
+                                    onrm.ctypes.data if normals is not None else None)
+    return (oxyz[:n], onrm[:n]) if normals is not None else oxyz[:n]
+
+
+def classify(points):
+    """CloudClassifier::classify (src/utils/cloud_classifier.h:19-168):
+    (planar xyz, planar normals, number of unclassified points, (height, width) of the organised cloud)."""
+    a = _cloud(points)
+    xyz = np.empty((max(len(a), 1), 3), np.float32)
+    nrm = np.empty((max(len(a), 1), 3), np.float32)
+    nu = C.c_size_t()
+    grid = (C.c_size_t * 2)()
+    n = capi.lib().lom_cloud_classify(a.ctypes.data, len(a), xyz.ctypes.data, nrm.ctypes.data, C.byref(nu), grid)
+    return xyz[:n].copy(), nrm[:n].copy(), int(nu.value), (int(grid[0]), int(grid[1]))
+
+
+class LidarOdometry:
+    """reference src/lidar_odometry.{h,cpp}; `params` overrides LidarOdometry::Params defaults by name."""
+
+    def __init__(self, device=0, **params):
+        p = capi.OdometryParams()
+        capi.lib().lom_odometry_default_params(C.byref(p))
+        for k, v in params.items():
+            if not hasattr(p, k):
+                raise TypeError(f"unknown parameter {k}")
+            setattr(p, k, v)
+        h = C.c_void_p()
+        rc = capi.lib().lom_odometry_create(C.byref(p), int(device), C.byref(h))
+        if rc != 0:
+            capi.check(rc, None)
+        self._h = h
+        self.params = p
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            capi.lib().lom_odometry_destroy(h)
+            self._h = None
+
+    def processCloud(self, input_cloud):                   # lidar_odometry.cpp:22-77
+        a = _cloud(input_cloud)
+        rc = capi.lib().lom_odometry_process_cloud(self._h, a.ctypes.data, len(a))
+        if rc != 0:
+            text = capi.lib().lom_odometry_last_error(self._h)
+            raise LomError(int(rc), text.decode() if text else "")
+
+    def getCurrentPose(self):                              # lidar_odometry.cpp:87-89
+        p = capi.Pose()
+        capi.check(capi.lib().lom_odometry_get_pose(self._h, C.byref(p)))
+        return Pose3D._from(p)
+
+    def _keyframe_export(self, mode):
+        kf = capi.lib().lom_odometry_keyframe(self._h)
+        n = capi.check(capi.lib().lom_map_export(kf, mode, None, None, 0), kf)
+        xyz = np.empty((n, 3), np.float32)
+        if n:
+            capi.check(capi.lib().lom_map_export(kf, mode, xyz.ctypes.data, None, n), kf)
+        return xyz
+
+    def getKeyFrameCloud(self):                            # lidar_odometry.cpp:79-81
+        return self._keyframe_export(capi.EXPORT_FIRST_PER_VOXEL)
+
+    def getFullKeyFrameCloud(self):                        # lidar_odometry.cpp:83-85
+        return self._keyframe_export(capi.EXPORT_FULL_NO_NORMALS)
+
+    @property
+    def stats(self):
+        s = capi.OdometryFrameStats()
+        capi.check(capi.lib().lom_odometry_get_stats(self._h, C.byref(s)))
+        return s.asdict()

@@ -55,6 +55,29 @@ class AlignStats(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
+# lidar_point::PointXYZIRT (src/lidar_point_type.h:13-21), 32 bytes
+POINT_XYZIRT = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("pad0", "<f4"), ("intensity", "<f4"),
+                         ("ring", "<u2"), ("pad1", "<u2"), ("time", "<f4"), ("pad2", "<f4")])
+assert POINT_XYZIRT.itemsize == 32
+
+
+class OdometryParams(C.Structure):
+    _fields_ = [("lidar_min_range", C.c_float), ("lidar_max_range", C.c_float), ("keyframe_voxel_size", C.c_float),
+                ("keyframe_max_points_cnt", C.c_uint32), ("keyframe_matching_voxel_size", C.c_float),
+                ("keyframe_update_voxel_size", C.c_float), ("keyframe_cleanup_range", C.c_float),
+                ("angular_divergence_threshold", C.c_float)]
+
+
+class OdometryFrameStats(C.Structure):
+    _fields_ = [("planar_points", C.c_int64), ("filtered_points", C.c_int64), ("update_points", C.c_int64),
+                ("matching_points", C.c_int64), ("keyframe_voxels", C.c_int64), ("queries", C.c_int64),
+                ("outer_iterations", C.c_int32), ("initialised_keyframe", C.c_int32),
+                ("unstable_rotation", C.c_int32), ("pad", C.c_int32)]
+
+    def asdict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "pad"}
+
+
 MATCH_EVAL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float),
                             C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double))
 EVAL_FIXED_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double),
@@ -75,7 +98,10 @@ EXPORTED = [
     "lom_map_add_points_device", "lom_map_radius_cleanup", "lom_map_size", "lom_map_point_count",
     "lom_map_export", "lom_match_find_pairs", "lom_match_align", "lom_match_align_device",
     "lom_map_set_profiling", "lom_profile_match", "lom_map_set_stream", "lom_comm_unique_id", "lom_comm_init",
-    "lom_comm_finalize", "lom_align_with_hooks",
+    "lom_comm_finalize", "lom_align_with_hooks", "lom_point_time_normalize", "lom_transform_non_rigid",
+    "lom_range_filter", "lom_cloud_classify", "lom_odometry_default_params", "lom_odometry_create",
+    "lom_odometry_destroy", "lom_odometry_process_cloud", "lom_odometry_get_pose", "lom_odometry_get_stats",
+    "lom_odometry_keyframe", "lom_odometry_last_error",
 ]
 
 _lib = None
@@ -150,6 +176,26 @@ def lib():
     L.lom_comm_init.argtypes = [vp, C.c_int, C.c_int, C.c_char_p]
     L.lom_comm_finalize.argtypes = [vp]
     L.lom_align_with_hooks.argtypes = [C.POINTER(AlignHooks), fp, fp, fp, fp, C.POINTER(AlignStats)]
+    L.lom_point_time_normalize.argtypes = [vp, C.c_size_t, vp]
+    L.lom_point_time_normalize.restype = None
+    L.lom_transform_non_rigid.argtypes = [vp, C.c_size_t, pp, pp, vp]
+    L.lom_transform_non_rigid.restype = None
+    L.lom_range_filter.argtypes = [vp, vp, C.c_size_t, C.c_float, C.c_float, vp, vp]
+    L.lom_range_filter.restype = C.c_size_t
+    L.lom_cloud_classify.argtypes = [vp, C.c_size_t, vp, vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    L.lom_cloud_classify.restype = C.c_size_t
+    L.lom_odometry_default_params.argtypes = [C.POINTER(OdometryParams)]
+    L.lom_odometry_default_params.restype = None
+    L.lom_odometry_create.argtypes = [C.POINTER(OdometryParams), C.c_int, C.POINTER(vp)]
+    L.lom_odometry_destroy.argtypes = [vp]
+    L.lom_odometry_destroy.restype = None
+    L.lom_odometry_process_cloud.argtypes = [vp, vp, C.c_size_t]
+    L.lom_odometry_get_pose.argtypes = [vp, pp]
+    L.lom_odometry_get_stats.argtypes = [vp, C.POINTER(OdometryFrameStats)]
+    L.lom_odometry_keyframe.argtypes = [vp]
+    L.lom_odometry_keyframe.restype = vp
+    L.lom_odometry_last_error.argtypes = [vp]
+    L.lom_odometry_last_error.restype = C.c_char_p
     _lib = L
     return L
 

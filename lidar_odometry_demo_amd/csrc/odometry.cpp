@@ -1,0 +1,412 @@
+// Host-side callers of the scan-matching core, ROS-free:
+//   utils::pointTimeNormalize            reference src/utils/point_time_normalize.h:15-39
+//   CloudTransformer::transformNonRigid  reference src/utils/cloud_transform.h:15-40
+//   CloudClassifier::classify            reference src/utils/cloud_classifier.h:19-168
+//   utils::rangeFilter                   reference src/utils/range_filter.h:13-28
+//   LidarOdometry                        reference src/lidar_odometry.{h,cpp}
+// In the reference these stay C++ on the host (north_star); they are restated here so the
+// streaming configuration (BASELINE.json configs[4]) can run end to end without ROS2/PCL/Eigen.
+// Everything that touches the voxel maps or the matcher goes through the C ABI, i.e. the GPU.
+// Built with -ffp-contract=off; f32 expression shapes follow the reference's.
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/lidar_odometry_amd.h"
+#include "pose_math.hpp"
+
+namespace {
+
+constexpr double kPi = 3.14159265358979323846;
+
+// ---- utils::pointTimeNormalize ---------------------------------------------------
+void time_normalize(const lom_point_xyzirt *in, size_t n, lom_point_xyzirt *out)
+{
+    float lo = 3.402823466e+38f, hi = -3.402823466e+38f;
+    for (size_t i = 0; i < n; i++) {
+        lo = in[i].time < lo ? in[i].time : lo;
+        hi = in[i].time > hi ? in[i].time : hi;
+    }
+    const float range = hi - lo;  // point_time_normalize.h:27 (0/0 when all stamps are equal, as there)
+    for (size_t i = 0; i < n; i++) {
+        out[i] = in[i];
+        out[i].time = (in[i].time - lo) / range;
+    }
+}
+
+// ---- Eigen Quaternionf::slerp (used by transformNonRigid) ------------------------------
+void slerp(const float a[4], float t, const float b[4], float out[4])
+{
+    const float one = 1.0f - 1.1920928955078125e-07f;
+    const float d = (a[0] * b[0] + a[1] * b[1]) + (a[2] * b[2] + a[3] * b[3]);
+    const float ad = std::fabs(d);
+    float s0, s1;
+    if (ad >= one) {
+        s0 = 1.0f - t;
+        s1 = t;
+    } else {
+        const float theta = std::acos(ad);
+        const float st = std::sin(theta);
+        s0 = std::sin((1.0f - t) * theta) / st;
+        s1 = std::sin(t * theta) / st;
+    }
+    if (d < 0.0f) s1 = -s1;
+    for (int i = 0; i < 4; i++) out[i] = s0 * a[i] + s1 * b[i];
+}
+
+// ---- CloudTransformer::transformNonRigid ---------------------------------------------
+void transform_non_rigid(const lom_point_xyzirt *in, size_t n, const lom_pose &start, const lom_pose &end,
+                         lom_point_xyzirt *out)
+{
+    for (size_t i = 0; i < n; i++) {
+        const float t = in[i].time;
+        float q[4], r[3];
+        slerp(start.q, t, end.q, q);  // cloud_transform.h:27
+        const float p[3] = {in[i].x, in[i].y, in[i].z};
+        lom::quat_rotate<float>(q, p, r);
+        const float w1 = (float)(1.0 - (double)t);  // :30
+        out[i] = in[i];
+        // the reference weights start.translation by time and end.translation by (1 - time)
+        out[i].x = (r[0] + start.t[0] * t) + end.t[0] * w1;
+        out[i].y = (r[1] + start.t[1] * t) + end.t[1] * w1;
+        out[i].z = (r[2] + start.t[2] * t) + end.t[2] * w1;
+    }
+}
+
+// ---- utils::rangeFilter ------------------------------------------------------------
+size_t range_filter(const float *xyz, const float *nrm, size_t n, float min_range, float max_range, float *xyz_out,
+                    float *nrm_out)
+{
+    const float lo = min_range * min_range, hi = max_range * max_range;
+    size_t w = 0;
+    for (size_t i = 0; i < n; i++) {
+        const float *p = xyz + 3 * i;
+        const float r2 = p[0] * p[0] + p[1] * p[1] + p[2] * p[2];
+        if (r2 >= lo && r2 <= hi) {
+            std::memcpy(xyz_out + 3 * w, p, 12);
+            if (nrm && nrm_out) std::memcpy(nrm_out + 3 * w, nrm + 3 * i, 12);
+            w++;
+        }
+    }
+    return w;
+}
+
+// ---- CloudClassifier::classify ---------------------------------------------------------
+// planar points + normals (the unclassified cloud is discarded by the only caller,
+// lidar_odometry.cpp:33, so only its size is reported)
+size_t classify(const lom_point_xyzirt *in, size_t n, float *xyz_out, float *nrm_out, size_t *unclassified,
+                size_t grid[2], std::vector<lom_point_xyzirt> &cloud)
+{
+    // organise by ring (map key is uint8_t in the reference, :23) and azimuth bin
+    size_t ring_count[256] = {};
+    for (size_t i = 0; i < n; i++) ring_count[(uint8_t)in[i].ring]++;
+    int row_of[256];
+    size_t H = 0, W = 0;
+    for (int r = 0; r < 256; r++) {
+        row_of[r] = -1;
+        if (ring_count[r]) {
+            row_of[r] = (int)H++;
+            W = ring_count[r] > W ? ring_count[r] : W;
+        }
+    }
+    if (grid) grid[0] = H, grid[1] = W;
+    if (unclassified) *unclassified = 0;
+    const size_t total = H * W;
+    if (!total) return 0;
+    lom_point_xyzirt zero;
+    std::memset(&zero, 0, sizeof zero);
+    cloud.assign(total, zero);
+    for (size_t i = 0; i < n; i++) {
+        const lom_point_xyzirt &p = in[i];
+        const float azimuth = (float)(std::atan2((double)-p.y, (double)p.x) + kPi);  // :49 (double atan2)
+        const size_t idx = (size_t)std::fabs((double)(azimuth * (float)W) / (2.0 * kPi));  // :50
+        if (idx < W) cloud[(size_t)row_of[(uint8_t)p.ring] * W + idx] = p;  // last writer wins
+    }
+    // curvature over the flattened array (+-4 window crosses ring boundaries), :76-103
+    const int cw = 4;
+    const float intensity_max = 1000.0f;
+    if (total > (size_t)(2 * cw)) {
+        for (size_t i = (size_t)cw; i < total - (size_t)cw; i++) {
+            lom_point_xyzirt &o = cloud[i];
+            const float range = powf(o.x, 2) + powf(o.y, 2) + powf(o.z, 2);
+            if ((double)range < 0.1) {
+                o.intensity = intensity_max;
+                continue;
+            }
+            float dx = (float)((double)(-o.x) * (cw * 2.0 + 1.0));
+            float dy = (float)((double)(-o.y) * (cw * 2.0 + 1.0));
+            float dz = (float)((double)(-o.z) * (cw * 2.0 + 1.0));
+            for (int w = -cw; w <= cw; w++) {
+                dx += cloud[i + w].x;
+                dy += cloud[i + w].y;
+                dz += cloud[i + w].z;
+            }
+            o.intensity = (float)(std::sqrt((double)(dx * dx + dy * dy + dz * dz)) / (double)range);
+        }
+    }
+    // normals from the previous ring, :105-165
+    const int nw = 4;
+    const float flat = 0.05f;
+    const double flat10 = (double)flat * 10.0;
+    size_t np = 0, nu = 0;
+    for (size_t ray = 1; ray < H; ray++) {
+        for (long pi = nw; pi < (long)W - nw; pi++) {
+            const lom_point_xyzirt &pt = cloud[ray * W + (size_t)pi];
+            if (pt.intensity < flat) {
+                const lom_point_xyzirt *row = &cloud[(ray - 1) * W];
+                int found = 0;
+                float L[3] = {0, 0, 0}, R[3] = {0, 0, 0};
+                for (long q = pi - nw; q < pi; q++)
+                    if ((double)row[q].intensity < flat10) {
+                        L[0] = row[q].x, L[1] = row[q].y, L[2] = row[q].z;
+                        found++;
+                        break;
+                    }
+                for (long q = pi + nw; q > pi; q--)
+                    if ((double)row[q].intensity < flat10) {
+                        R[0] = row[q].x, R[1] = row[q].y, R[2] = row[q].z;
+                        found++;
+                        break;
+                    }
+                if (found == 2) {
+                    const float a[3] = {L[0] - pt.x, L[1] - pt.y, L[2] - pt.z};
+                    const float b[3] = {R[0] - pt.x, R[1] - pt.y, R[2] - pt.z};
+                    float c[3] = {a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]};
+                    const float z = lom::sum3(c[0] * c[0], c[1] * c[1], c[2] * c[2]);
+                    if (z > 0.f) {
+                        const float s = std::sqrt(z);
+                        c[0] /= s, c[1] /= s, c[2] /= s;
+                    }
+                    xyz_out[3 * np] = pt.x, xyz_out[3 * np + 1] = pt.y, xyz_out[3 * np + 2] = pt.z;
+                    nrm_out[3 * np] = c[0], nrm_out[3 * np + 1] = c[1], nrm_out[3 * np + 2] = c[2];
+                    np++;
+                } else {
+                    nu++;
+                }
+            } else if (pt.intensity < intensity_max) {
+                nu++;
+            }
+        }
+    }
+    if (unclassified) *unclassified = nu;
+    return np;
+}
+
+// Eigen eulerAngles(0,1,2) of (qa * qb^-1).toRotationMatrix(), degrees (lidar_odometry.cpp:54-55)
+void delta_euler_deg(const float qa[4], const float qb[4], float out[3])
+{
+    lom_pose a{}, b{}, inv, prod;
+    std::memcpy(a.q, qa, 16);
+    std::memcpy(b.q, qb, 16);
+    lom::pose_inverse(b, inv);
+    lom::pose_compose(a, inv, prod);
+    float m[9];
+    lom::rotation_matrix(prod.q, m);
+    auto M = [&m](int r, int c) { return m[r * 3 + c]; };
+    float res[3];
+    res[0] = std::atan2(M(1, 2), M(2, 2));
+    const float c2 = std::sqrt(M(0, 0) * M(0, 0) + M(0, 1) * M(0, 1));
+    if (res[0] > 0.f) {
+        res[0] -= (float)kPi;
+        res[1] = std::atan2(-M(0, 2), -c2);
+    } else {
+        res[1] = std::atan2(-M(0, 2), c2);
+    }
+    const float s1 = std::sin(res[0]), c1 = std::cos(res[0]);
+    res[2] = std::atan2(s1 * M(2, 0) - c1 * M(1, 0), c1 * M(1, 1) - s1 * M(2, 1));
+    for (int i = 0; i < 3; i++) out[i] = ((-res[i]) * 180.0f) / (float)kPi;
+}
+
+}  // namespace
+
+// ---- LidarOdometry (src/lidar_odometry.{h,cpp}) ---------------------------------------------
+struct lom_odometry {
+    lom_odometry_params cfg;
+    lom_map *keyframe = nullptr;       // keyframe_           lidar_odometry.h:82
+    lom_map *update_ds = nullptr;      // keyframe_downsampler lidar_odometry.cpp:37 (reused per frame)
+    lom_map *matching_ds = nullptr;    // matching_downsampler lidar_odometry.cpp:46 (reused per frame)
+    lom_pose previous, current;        // lidar_odometry.h:84-85
+    lom_odometry_frame_stats last{};
+    std::vector<lom_point_xyzirt> normalized, deskewed, grid;
+    std::vector<float> planar, planar_n, filtered, filtered_n, down, down_n, match, upd, upd_n;
+    std::string error;
+};
+
+extern "C" {
+
+void lom_point_time_normalize(const lom_point_xyzirt *in, size_t n, lom_point_xyzirt *out) { time_normalize(in, n, out); }
+
+void lom_transform_non_rigid(const lom_point_xyzirt *in, size_t n, const lom_pose *start, const lom_pose *end,
+                             lom_point_xyzirt *out)
+{
+    transform_non_rigid(in, n, *start, *end, out);
+}
+
+size_t lom_range_filter(const float *xyz, const float *nrm, size_t n, float min_range, float max_range, float *xyz_out,
+                        float *nrm_out)
+{
+    return range_filter(xyz, nrm, n, min_range, max_range, xyz_out, nrm_out);
+}
+
+size_t lom_cloud_classify(const lom_point_xyzirt *in, size_t n, float *xyz_out, float *nrm_out,
+                          size_t *unclassified_out, size_t grid_out[2])
+{
+    std::vector<lom_point_xyzirt> scratch;
+    return classify(in, n, xyz_out, nrm_out, unclassified_out, grid_out, scratch);
+}
+
+void lom_odometry_default_params(lom_odometry_params *p)
+{
+    // lidar_odometry.h:36-48 and config/params.yaml
+    p->lidar_min_range = 4.0f;
+    p->lidar_max_range = 80.0f;
+    p->keyframe_voxel_size = 0.2f;
+    p->keyframe_max_points_cnt = 20;
+    p->keyframe_matching_voxel_size = 0.3f;
+    p->keyframe_update_voxel_size = 0.1f;
+    p->keyframe_cleanup_range = 80.0f;
+    p->angular_divergence_threshold = 5.0f;
+}
+
+int lom_odometry_create(const lom_odometry_params *params, int device, lom_odometry **out)
+{
+    if (!params || !out) return LOM_ERR_ARG;
+    *out = nullptr;
+    lom_odometry *o = new (std::nothrow) lom_odometry();
+    if (!o) return LOM_ERR_OOM;
+    o->cfg = *params;
+    lom_pose_identity(&o->current);  // lidar_odometry.cpp:15-17
+    o->previous = o->current;
+    int rc = lom_map_create(params->keyframe_voxel_size, params->keyframe_max_points_cnt, 1 << 16, device,
+                            &o->keyframe);  // :18-19
+    if (rc == LOM_OK) rc = lom_map_create(params->keyframe_update_voxel_size, 1, 1 << 15, device, &o->update_ds);
+    if (rc == LOM_OK) rc = lom_map_create(params->keyframe_matching_voxel_size, 1, 1 << 14, device, &o->matching_ds);
+    if (rc != LOM_OK) {
+        lom_odometry_destroy(o);
+        return rc;
+    }
+    *out = o;
+    return LOM_OK;
+}
+
+void lom_odometry_destroy(lom_odometry *o)
+{
+    if (!o) return;
+    lom_map_destroy(o->keyframe);
+    lom_map_destroy(o->update_ds);
+    lom_map_destroy(o->matching_ds);
+    delete o;
+}
+
+const char *lom_odometry_last_error(const lom_odometry *o) { return o ? o->error.c_str() : ""; }
+lom_map *lom_odometry_keyframe(lom_odometry *o) { return o ? o->keyframe : nullptr; }
+
+int lom_odometry_get_pose(const lom_odometry *o, lom_pose *out)
+{
+    if (!o || !out) return LOM_ERR_ARG;
+    *out = o->current;  // lidar_odometry.cpp:87-89
+    return LOM_OK;
+}
+
+int lom_odometry_get_stats(const lom_odometry *o, lom_odometry_frame_stats *out)
+{
+    if (!o || !out) return LOM_ERR_ARG;
+    *out = o->last;
+    return LOM_OK;
+}
+
+// LidarOdometry::processCloud, lidar_odometry.cpp:22-77
+int lom_odometry_process_cloud(lom_odometry *o, const lom_point_xyzirt *pts, size_t n)
+{
+    if (!o || (!pts && n)) return LOM_ERR_ARG;
+    auto fail = [o](int rc, lom_map *m) {
+        o->error = lom_last_error(m);
+        return rc;
+    };
+    try {
+        o->last = lom_odometry_frame_stats{};
+        const size_t cap = n ? n : 1;
+        o->normalized.resize(cap);
+        o->deskewed.resize(cap);
+        for (auto *v : {&o->planar, &o->planar_n, &o->filtered, &o->filtered_n}) v->resize(cap * 3);
+        time_normalize(pts, n, o->normalized.data());  // :25
+        lom_pose relative, rel_inv, ident, guess, result;
+        lom_pose_relative_to(&o->previous, &o->current, &relative);  // :27
+        o->previous = o->current;                                    // :28
+        lom::pose_inverse(relative, rel_inv);
+        lom_pose_identity(&ident);
+        transform_non_rigid(o->normalized.data(), n, rel_inv, ident, o->deskewed.data());  // :30
+        size_t nu = 0;
+        const size_t np = classify(o->deskewed.data(), n, o->planar.data(), o->planar_n.data(), &nu, nullptr, o->grid);  // :33
+        const size_t nf = range_filter(o->planar.data(), o->planar_n.data(), np, o->cfg.lidar_min_range,
+                                       o->cfg.lidar_max_range, o->filtered.data(), o->filtered_n.data());  // :35
+        o->last.planar_points = (int64_t)np;
+        o->last.filtered_points = (int64_t)nf;
+        int rc;
+        // VoxelGrid keyframe_downsampler(update_voxel_size, 1); addCloud(filtered)   :37-38
+        if ((rc = lom_map_clear(o->update_ds, o->cfg.keyframe_update_voxel_size)) != LOM_OK) return fail(rc, o->update_ds);
+        if ((rc = lom_map_add_points(o->update_ds, o->filtered.data(), o->filtered_n.data(), nf, 12)) != LOM_OK)
+            return fail(rc, o->update_ds);
+        int64_t nd = lom_map_export(o->update_ds, LOM_EXPORT_FULL, nullptr, nullptr, 0);
+        if (nd < 0) return fail((int)nd, o->update_ds);
+        o->down.resize((size_t)(nd ? nd : 1) * 3);
+        o->down_n.resize((size_t)(nd ? nd : 1) * 3);
+        if (nd && (rc = (int)lom_map_export(o->update_ds, LOM_EXPORT_FULL, o->down.data(), o->down_n.data(), (size_t)nd)) < 0)
+            return fail(rc, o->update_ds);
+        o->last.update_points = nd;
+        if (lom_map_size(o->keyframe) == 0) {  // :40-44 init keyframe
+            if ((rc = lom_map_add_points(o->keyframe, o->down.data(), o->down_n.data(), (size_t)nd, 12)) != LOM_OK)
+                return fail(rc, o->keyframe);
+            o->last.initialised_keyframe = 1;
+            o->last.keyframe_voxels = lom_map_size(o->keyframe);
+            return LOM_OK;
+        }
+        // VoxelGrid matching_downsampler(matching_voxel_size, 1); addCloud(filtered)   :46-47
+        if ((rc = lom_map_clear(o->matching_ds, o->cfg.keyframe_matching_voxel_size)) != LOM_OK) return fail(rc, o->matching_ds);
+        if ((rc = lom_map_add_points(o->matching_ds, o->filtered.data(), o->filtered_n.data(), nf, 12)) != LOM_OK)
+            return fail(rc, o->matching_ds);
+        int64_t nm = lom_map_export(o->matching_ds, LOM_EXPORT_FULL_NO_NORMALS, nullptr, nullptr, 0);
+        if (nm < 0) return fail((int)nm, o->matching_ds);
+        o->match.resize((size_t)(nm ? nm : 1) * 3);
+        if (nm && (rc = (int)lom_map_export(o->matching_ds, LOM_EXPORT_FULL_NO_NORMALS, o->match.data(), nullptr, (size_t)nm)) < 0)
+            return fail(rc, o->matching_ds);
+        o->last.matching_points = nm;
+        lom_pose_compose(&o->current, &relative, &guess);  // :51
+        lom_align_stats ast;
+        if ((rc = lom_match_align(o->keyframe, o->match.data(), (size_t)nm, 12, guess.t, guess.q, result.t, result.q,
+                                  &ast)) != LOM_OK)  // :49-51
+            return fail(rc, o->keyframe);
+        o->last.outer_iterations = ast.outer_iterations;
+        o->last.queries = ast.queries;
+        {  // :53-63 divergence guard
+            float ang[3];
+            delta_euler_deg(result.q, o->current.q, ang);
+            const float thr = o->cfg.angular_divergence_threshold;
+            bool ok = true;
+            for (int a = 0; a < 3; a++) ok = ok && (std::fabs(ang[a]) < thr || std::fabs(ang[a]) > 180 - thr);
+            if (!ok) {
+                result = guess;  // :61
+                o->last.unstable_rotation = 1;
+            }
+        }
+        o->current = result;                                                                          // :65
+        if ((rc = lom_map_radius_cleanup(o->keyframe, o->current.t, o->cfg.keyframe_cleanup_range)) != LOM_OK)  // :67
+            return fail(rc, o->keyframe);
+        o->upd.resize((size_t)(nd ? nd : 1) * 3);
+        o->upd_n.resize((size_t)(nd ? nd : 1) * 3);
+        lom_transform_points(&o->current, o->down.data(), o->down_n.data(), (size_t)nd, 12, o->upd.data(),
+                             o->upd_n.data(), 12);  // :69
+        if ((rc = lom_map_add_points(o->keyframe, o->upd.data(), o->upd_n.data(), (size_t)nd, 12)) != LOM_OK)  // :70
+            return fail(rc, o->keyframe);
+        o->last.keyframe_voxels = lom_map_size(o->keyframe);
+        return LOM_OK;
+    } catch (const std::bad_alloc &) {
+        o->error = "host allocation failed";
+        return LOM_ERR_OOM;
+    }
+}
+
+}  // extern "C"

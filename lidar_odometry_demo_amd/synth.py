@@ -179,3 +179,60 @@ CONFIGS = {
     "C3": dict(n_beams=64, n_az=2048, map_points=2_000_000),
     "C4": dict(n_beams=128, n_az=2048, map_points=2_000_000),
 }
+
+
+# ---- streaming sequence (BASELINE.json configs[4] / SURVEY.md 8d "C5") ---------------------------
+
+POINT_XYZIRT = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("pad0", "<f4"), ("intensity", "<f4"),
+                         ("ring", "<u2"), ("pad1", "<u2"), ("time", "<f4"), ("pad2", "<f4")])
+FRAME_PERIOD = 0.1      # 10 Hz
+SPEED = 5.0             # m/s along +x, reached after RAMP seconds from rest
+YAW_RATE_DEG = 5.0      # deg/s, likewise
+RAMP = 2.5              # s of constant acceleration (2 m/s^2, 2 deg/s^2)
+
+
+def _ramp_integral(t):
+    """integral of min(1, tau / RAMP) d tau over [0, t]"""
+    t = float(t)
+    return t * t / (2 * RAMP) if t <= RAMP else RAMP / 2 + (t - RAMP)
+
+
+def sequence_pose(t):
+    """Ground-truth sensor pose (position, wxyz quaternion) at time t [s].  The vehicle starts at
+    rest and accelerates to 5 m/s and 5 deg/s within 2.5 s: the reference's constant-velocity
+    guess starts from zero velocity and its 0.3 m correspondence gate cannot acquire a 0.5 m jump
+    between the first two frames."""
+    s = _ramp_integral(t)
+    return np.array([SPEED * s, 0.0, 0.0]), quat_from_ypr(YAW_RATE_DEG * s, 0.0, 0.0)
+
+
+def make_sequence_frame(k, n_beams=16, n_az=1800, noise_sigma=0.02, boxes=None):
+    """Frame k of the streaming sequence as lidar_point::PointXYZIRT records in firing order
+    (azimuth-major).  Every return is taken from the sensor pose at ITS OWN firing time
+    t_k + az/n_az * 0.1 s and reported in that instant's sensor frame (motion distortion, which
+    the pipeline's deskew step removes); `time` = seconds since the frame start, `ring` = beam."""
+    boxes = make_boxes() if boxes is None else boxes
+    el = np.deg2rad(beam_elevations(n_beams))
+    az = np.arange(n_az) * (2 * np.pi / n_az)
+    azs = np.repeat(np.arange(n_az), n_beams)
+    ring = np.tile(np.arange(n_beams), n_az)
+    t_pt = azs / n_az * FRAME_PERIOD
+    ce, se = np.cos(el[ring]), np.sin(el[ring])
+    d_s = np.stack([ce * np.cos(az[azs]), ce * np.sin(az[azs]), se], axis=1)
+    rng = np.full(len(d_s), np.inf)
+    t0 = k * FRAME_PERIOD
+    # one ray-cast per azimuth step would be slow in numpy: group steps into 36 chunks whose pose
+    # is evaluated at the chunk centre (50 steps = 2.8 ms = 1.4 cm of travel)
+    for c in range(0, n_az, 50):
+        sel = (azs >= c) & (azs < c + 50)
+        pos, q = sequence_pose(t0 + (c + 25) / n_az * FRAME_PERIOD)
+        rng[sel] = raycast(pos, d_s[sel] @ quat_to_matrix(q).T, boxes)
+    noise = _rng(SEED_NOISE + 1000 + k).normal(0.0, noise_sigma, size=len(d_s))
+    rng = rng + noise
+    keep = np.isfinite(rng) & (rng < MAX_RANGE) & (rng > 0.5)
+    out = np.zeros(int(keep.sum()), POINT_XYZIRT)
+    xyz = (d_s[keep] * rng[keep, None]).astype(np.float32)
+    out["x"], out["y"], out["z"] = xyz[:, 0], xyz[:, 1], xyz[:, 2]
+    out["ring"] = ring[keep]
+    out["time"] = t_pt[keep].astype(np.float32)
+    return out

@@ -133,6 +133,48 @@ int orc_shard_match_eval(void *shard, const float pose_t[3], const float pose_q[
 int orc_shard_eval_fixed(void *shard, const double q[4], const double t[3],
                          double out[ORC_NSUMS]);
 
+/* ---- callers of the hot path, oracle/pipeline.c ---------- */
+/* lidar_point::PointXYZIRT, src/lidar_point_type.h:13-21 (32 bytes, EIGEN_ALIGN16) */
+typedef struct {
+    float x, y, z, pad0;
+    float intensity;
+    uint16_t ring;
+    uint16_t pad1;
+    float time;
+    float pad2;
+} orc_point_xyzirt;
+
+void orc_time_normalize(const orc_point_xyzirt *in, size_t n, orc_point_xyzirt *out);
+void orc_transform_non_rigid(const orc_point_xyzirt *in, size_t n, const orc_pose *start, const orc_pose *end,
+                             orc_point_xyzirt *out);
+size_t orc_range_filter(const float *xyz, const float *nrm, size_t n, float min_range, float max_range,
+                        float *xyz_out, float *nrm_out);
+size_t orc_classify(const orc_point_xyzirt *in, size_t n, float *xyz_out, float *nrm_out, size_t *unclassified_out,
+                    size_t grid_out[2]);
+
+/* LidarOdometry::Params, src/lidar_odometry.h:23-48 */
+typedef struct {
+    float lidar_min_range, lidar_max_range;
+    float keyframe_voxel_size;
+    uint32_t keyframe_max_points_cnt;
+    float keyframe_matching_voxel_size, keyframe_update_voxel_size;
+    float keyframe_cleanup_range, angular_divergence_threshold;
+} orc_odom_params;
+
+typedef struct {
+    int64_t planar_points, filtered_points, update_points, matching_points, keyframe_voxels, queries;
+    int32_t outer_iterations, initialised_keyframe, unstable_rotation, pad;
+} orc_odom_frame_stats;
+
+typedef struct orc_odom orc_odom;
+void orc_odom_default_params(orc_odom_params *p);
+orc_odom *orc_odom_create(const orc_odom_params *p);                 /* lidar_odometry.cpp:14-20 */
+void orc_odom_destroy(orc_odom *o);
+int orc_odom_process(orc_odom *o, const orc_point_xyzirt *pts, size_t n, int nthreads); /* :22-77 */
+void orc_odom_get_pose(const orc_odom *o, orc_pose *out);             /* :87-89 */
+void orc_odom_get_stats(const orc_odom *o, orc_odom_frame_stats *out);
+const orc_map *orc_odom_keyframe(const orc_odom *o);
+
 #ifdef __cplusplus
 }
 #endif

@@ -20,7 +20,7 @@ def build(force=False):
     """Compile oracle.c with the committed Makefile (gcc, no third-party code)."""
     if force or not os.path.exists(_LIB_PATH) or any(
         os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH)
-        for f in ("oracle.c", "oracle.h", "Makefile")
+        for f in ("oracle.c", "pipeline.c", "oracle.h", "Makefile")
     ):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _LIB_PATH
@@ -284,3 +284,147 @@ class Shard:
     @property
     def handle(self):
         return self._h
+
+
+# ---- callers of the hot path (oracle/pipeline.c), tests only ---------------------------------
+
+POINT_XYZIRT = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("pad0", "<f4"), ("intensity", "<f4"),
+                         ("ring", "<u2"), ("pad1", "<u2"), ("time", "<f4"), ("pad2", "<f4")])
+
+
+class OdomParams(C.Structure):
+    _fields_ = [("lidar_min_range", C.c_float), ("lidar_max_range", C.c_float), ("keyframe_voxel_size", C.c_float),
+                ("keyframe_max_points_cnt", C.c_uint32), ("keyframe_matching_voxel_size", C.c_float),
+                ("keyframe_update_voxel_size", C.c_float), ("keyframe_cleanup_range", C.c_float),
+                ("angular_divergence_threshold", C.c_float)]
+
+
+class OdomFrameStats(C.Structure):
+    _fields_ = [("planar_points", C.c_int64), ("filtered_points", C.c_int64), ("update_points", C.c_int64),
+                ("matching_points", C.c_int64), ("keyframe_voxels", C.c_int64), ("queries", C.c_int64),
+                ("outer_iterations", C.c_int32), ("initialised_keyframe", C.c_int32),
+                ("unstable_rotation", C.c_int32), ("pad", C.c_int32)]
+
+    def asdict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "pad"}
+
+
+def _pipeline_lib():
+    L = lib()
+    if getattr(L, "_pipeline_ready", False):
+        return L
+    pp = C.POINTER(Pose)
+    L.orc_time_normalize.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+    L.orc_time_normalize.restype = None
+    L.orc_transform_non_rigid.argtypes = [C.c_void_p, C.c_size_t, pp, pp, C.c_void_p]
+    L.orc_transform_non_rigid.restype = None
+    L.orc_range_filter.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+    L.orc_range_filter.restype = C.c_size_t
+    L.orc_classify.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t),
+                               C.POINTER(C.c_size_t)]
+    L.orc_classify.restype = C.c_size_t
+    L.orc_odom_default_params.argtypes = [C.POINTER(OdomParams)]
+    L.orc_odom_default_params.restype = None
+    L.orc_odom_create.argtypes = [C.POINTER(OdomParams)]
+    L.orc_odom_create.restype = C.c_void_p
+    L.orc_odom_destroy.argtypes = [C.c_void_p]
+    L.orc_odom_destroy.restype = None
+    L.orc_odom_process.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    L.orc_odom_get_pose.argtypes = [C.c_void_p, pp]
+    L.orc_odom_get_pose.restype = None
+    L.orc_odom_get_stats.argtypes = [C.c_void_p, C.POINTER(OdomFrameStats)]
+    L.orc_odom_get_stats.restype = None
+    L.orc_odom_keyframe.argtypes = [C.c_void_p]
+    L.orc_odom_keyframe.restype = C.c_void_p
+    L._pipeline_ready = True
+    return L
+
+
+def _cloud(points):
+    a = np.ascontiguousarray(points, dtype=POINT_XYZIRT)
+    assert a.ndim == 1
+    return a
+
+
+def pointTimeNormalize(points):
+    a = _cloud(points)
+    out = np.empty_like(a)
+    _pipeline_lib().orc_time_normalize(a.ctypes.data, len(a), out.ctypes.data)
+    return out
+
+
+def transformNonRigid(points, start_pose, end_pose):
+    a = _cloud(points)
+    out = np.empty_like(a)
+    _pipeline_lib().orc_transform_non_rigid(a.ctypes.data, len(a), C.byref(start_pose._c()), C.byref(end_pose._c()),
+                                            out.ctypes.data)
+    return out
+
+
+def rangeFilter(xyz, normals, min_range, max_range):
+    xyz = _xyz(xyz)
+    normals = _xyz(normals) if normals is not None else None
+    oxyz = np.empty_like(xyz)
+    onrm = np.empty_like(xyz) if normals is not None else None
+    n = _pipeline_lib().orc_range_filter(xyz.ctypes.data, normals.ctypes.data if normals is not None else None,
+                                         len(xyz), float(min_range), float(max_range), oxyz.ctypes.data,
+                                         onrm.ctypes.data if normals is not None else None)
+    return (oxyz[:n], onrm[:n]) if normals is not None else oxyz[:n]
+
+
+def classify(points):
+    a = _cloud(points)
+    xyz = np.empty((max(len(a), 1), 3), np.float32)
+    nrm = np.empty((max(len(a), 1), 3), np.float32)
+    nu = C.c_size_t()
+    grid = (C.c_size_t * 2)()
+    n = _pipeline_lib().orc_classify(a.ctypes.data, len(a), xyz.ctypes.data, nrm.ctypes.data, C.byref(nu), grid)
+    return xyz[:n].copy(), nrm[:n].copy(), int(nu.value), (int(grid[0]), int(grid[1]))
+
+
+class LidarOdometry:
+    """CPU restatement of reference src/lidar_odometry.{h,cpp}."""
+
+    def __init__(self, nthreads=1, **params):
+        L = _pipeline_lib()
+        p = OdomParams()
+        L.orc_odom_default_params(C.byref(p))
+        for k, v in params.items():
+            setattr(p, k, v)
+        self._h = L.orc_odom_create(C.byref(p))
+        self.nthreads = nthreads
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _pipeline_lib().orc_odom_destroy(self._h)
+            self._h = None
+
+    def processCloud(self, input_cloud):
+        a = _cloud(input_cloud)
+        rc = _pipeline_lib().orc_odom_process(self._h, a.ctypes.data, len(a), self.nthreads)
+        if rc != 0:
+            raise RuntimeError(f"oracle error {rc}")
+
+    def getCurrentPose(self):
+        p = Pose()
+        _pipeline_lib().orc_odom_get_pose(self._h, C.byref(p))
+        return Pose3D._from(p)
+
+    def _export(self, mode):
+        kf = _pipeline_lib().orc_odom_keyframe(self._h)
+        n = lib().orc_map_export(kf, mode, None, None, 0)
+        xyz = np.empty((n, 3), np.float32)
+        lib().orc_map_export(kf, mode, xyz.ctypes.data, None, n)
+        return xyz
+
+    def getKeyFrameCloud(self):
+        return self._export(EXPORT_FIRST_PER_VOXEL)
+
+    def getFullKeyFrameCloud(self):
+        return self._export(EXPORT_FULL_NO_NORMALS)
+
+    @property
+    def stats(self):
+        s = OdomFrameStats()
+        _pipeline_lib().orc_odom_get_stats(self._h, C.byref(s))
+        return s.asdict()
