@@ -102,6 +102,11 @@ struct lom_map {
     float *d_pts = nullptr;                    // [slab_cap][K][3]
     float *d_nrm = nullptr;                    // [slab_cap][K][3]
     uint64_t n_points = 0;
+    // second slab set: radiusCleanup compacts into it and swaps (no allocation per frame)
+    unsigned long long *alt_key = nullptr;
+    uint32_t *alt_count = nullptr;
+    float *alt_pts = nullptr, *alt_nrm = nullptr;
+    uint32_t alt_cap = 0;
 
     // scratch (grown on demand, never shrunk)
     lom::DeviceBuf scr[12];

@@ -8,11 +8,19 @@
 // streaming configuration (BASELINE.json configs[4]) can run end to end without ROS2/PCL/Eigen.
 // Everything that touches the voxel maps or the matcher goes through the C ABI, i.e. the GPU.
 // Built with -ffp-contract=off; f32 expression shapes follow the reference's.
+#include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
+#include <condition_variable>
 #include <cstring>
+#include <ctime>
+#include <functional>
+#include <memory>
+#include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/lidar_odometry_amd.h"
@@ -22,19 +30,123 @@ namespace {
 
 constexpr double kPi = 3.14159265358979323846;
 
+// LOM_DEBUG_TIMING=1: per-stage wall times of processCloud on stderr
+struct StageTimer {
+    bool on = getenv("LOM_DEBUG_TIMING") != nullptr;
+    double t0 = now(), last = t0;
+    static double now()
+    {
+        timespec ts;
+        clock_gettime(CLOCK_MONOTONIC, &ts);
+        return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+    }
+    void lap(const char *what)
+    {
+        if (!on) return;
+        const double t = now();
+        std::fprintf(stderr, "  %-14s %8.1f us\n", what, (t - last) * 1e6);
+        last = t;
+    }
+    void total()
+    {
+        if (on) std::fprintf(stderr, "processCloud total %8.1f us\n", (now() - t0) * 1e6);
+    }
+};
+
+// ---- host worker pool -------------------------------------------------------------
+// The reference runs its per-point transforms under std::execution::par
+// (point_time_normalize.h:31, cloud_transform.h:21); this is the same idea without TBB.
+// Work is split into contiguous index ranges, so results do not depend on the thread count.
+class Pool {
+public:
+    explicit Pool(unsigned n_threads)
+    {
+        for (unsigned i = 1; i < n_threads; i++) workers_.emplace_back([this, i] { run(i); });
+    }
+    ~Pool()
+    {
+        {
+            std::lock_guard<std::mutex> l(m_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto &t : workers_) t.join();
+    }
+    unsigned size() const { return (unsigned)workers_.size() + 1; }
+
+    // fn(begin, end, part) over [0, n) in size() contiguous parts; the caller takes part 0,
+    // worker w always takes part w
+    template <typename F>
+    void parallel_for(size_t n, F &&fn, size_t serial_below = 2048)
+    {
+        const unsigned parts = size();
+        if (parts == 1 || n < serial_below) {
+            fn(size_t(0), n, 0u);
+            return;
+        }
+        std::function<void(unsigned)> job = [&](unsigned p) { fn(n * p / parts, n * (p + 1) / parts, p); };
+        {
+            std::lock_guard<std::mutex> l(m_);
+            job_ = &job;
+            pending_ = parts - 1;
+            generation_++;
+        }
+        cv_.notify_all();
+        job(0);
+        std::unique_lock<std::mutex> l(m_);
+        done_.wait(l, [this] { return pending_ == 0; });
+        job_ = nullptr;
+    }
+
+private:
+    void run(unsigned part)
+    {
+        unsigned long seen = 0;
+        std::unique_lock<std::mutex> l(m_);
+        for (;;) {
+            cv_.wait(l, [&] { return stop_ || generation_ != seen; });
+            if (stop_) return;
+            seen = generation_;
+            const std::function<void(unsigned)> *job = job_;
+            l.unlock();
+            (*job)(part);
+            l.lock();
+            if (--pending_ == 0) done_.notify_one();
+        }
+    }
+    std::vector<std::thread> workers_;
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    const std::function<void(unsigned)> *job_ = nullptr;
+    unsigned pending_ = 0;
+    unsigned long generation_ = 0;
+    bool stop_ = false;
+};
+
+template <typename F>
+void run_parts(Pool *pool, size_t n, F &&fn, size_t serial_below = 2048)
+{
+    if (pool)
+        pool->parallel_for(n, fn, serial_below);
+    else
+        fn(size_t(0), n, 0u);
+}
+
 // ---- utils::pointTimeNormalize ---------------------------------------------------
-void time_normalize(const lom_point_xyzirt *in, size_t n, lom_point_xyzirt *out)
+void time_normalize(const lom_point_xyzirt *in, size_t n, lom_point_xyzirt *out, Pool *pool = nullptr)
 {
     float lo = 3.402823466e+38f, hi = -3.402823466e+38f;
-    for (size_t i = 0; i < n; i++) {
+    for (size_t i = 0; i < n; i++) {  // sequential in the reference too (:21 execution::seq)
         lo = in[i].time < lo ? in[i].time : lo;
         hi = in[i].time > hi ? in[i].time : hi;
     }
     const float range = hi - lo;  // point_time_normalize.h:27 (0/0 when all stamps are equal, as there)
-    for (size_t i = 0; i < n; i++) {
-        out[i] = in[i];
-        out[i].time = (in[i].time - lo) / range;
-    }
+    run_parts(pool, n, [&](size_t b, size_t e, unsigned) {
+        for (size_t i = b; i < e; i++) {
+            out[i] = in[i];
+            out[i].time = (in[i].time - lo) / range;
+        }
+    });
 }
 
 // ---- Eigen Quaternionf::slerp (used by transformNonRigid) ------------------------------
@@ -59,9 +171,10 @@ void slerp(const float a[4], float t, const float b[4], float out[4])
 
 // ---- CloudTransformer::transformNonRigid ---------------------------------------------
 void transform_non_rigid(const lom_point_xyzirt *in, size_t n, const lom_pose &start, const lom_pose &end,
-                         lom_point_xyzirt *out)
+                         lom_point_xyzirt *out, Pool *pool = nullptr)
 {
-    for (size_t i = 0; i < n; i++) {
+    run_parts(pool, n, [&](size_t pb, size_t pe, unsigned) {
+    for (size_t i = pb; i < pe; i++) {
         const float t = in[i].time;
         float q[4], r[3];
         slerp(start.q, t, end.q, q);  // cloud_transform.h:27
@@ -74,6 +187,7 @@ void transform_non_rigid(const lom_point_xyzirt *in, size_t n, const lom_pose &s
         out[i].y = (r[1] + start.t[1] * t) + end.t[1] * w1;
         out[i].z = (r[2] + start.t[2] * t) + end.t[2] * w1;
     }
+    });
 }
 
 // ---- utils::rangeFilter ------------------------------------------------------------
@@ -98,7 +212,7 @@ size_t range_filter(const float *xyz, const float *nrm, size_t n, float min_rang
 // planar points + normals (the unclassified cloud is discarded by the only caller,
 // lidar_odometry.cpp:33, so only its size is reported)
 size_t classify(const lom_point_xyzirt *in, size_t n, float *xyz_out, float *nrm_out, size_t *unclassified,
-                size_t grid[2], std::vector<lom_point_xyzirt> &cloud)
+                size_t grid[2], std::vector<lom_point_xyzirt> &cloud, Pool *pool = nullptr)
 {
     // organise by ring (map key is uint8_t in the reference, :23) and azimuth bin
     size_t ring_count[256] = {};
@@ -119,17 +233,25 @@ size_t classify(const lom_point_xyzirt *in, size_t n, float *xyz_out, float *nrm
     lom_point_xyzirt zero;
     std::memset(&zero, 0, sizeof zero);
     cloud.assign(total, zero);
-    for (size_t i = 0; i < n; i++) {
-        const lom_point_xyzirt &p = in[i];
-        const float azimuth = (float)(std::atan2((double)-p.y, (double)p.x) + kPi);  // :49 (double atan2)
-        const size_t idx = (size_t)std::fabs((double)(azimuth * (float)W) / (2.0 * kPi));  // :50
-        if (idx < W) cloud[(size_t)row_of[(uint8_t)p.ring] * W + idx] = p;  // last writer wins
-    }
+    // cell of every point in parallel, then the scatter in input order (last writer wins, :52-54)
+    std::vector<uint32_t> cell(n);
+    run_parts(pool, n, [&](size_t pb, size_t pe, unsigned) {
+        for (size_t i = pb; i < pe; i++) {
+            const lom_point_xyzirt &p = in[i];
+            const float azimuth = (float)(std::atan2((double)-p.y, (double)p.x) + kPi);       // :49 (double atan2)
+            const size_t idx = (size_t)std::fabs((double)(azimuth * (float)W) / (2.0 * kPi));  // :50
+            cell[i] = idx < W ? (uint32_t)((size_t)row_of[(uint8_t)p.ring] * W + idx) : 0xFFFFFFFFu;
+        }
+    });
+    for (size_t i = 0; i < n; i++)
+        if (cell[i] != 0xFFFFFFFFu) cloud[cell[i]] = in[i];
     // curvature over the flattened array (+-4 window crosses ring boundaries), :76-103
     const int cw = 4;
     const float intensity_max = 1000.0f;
     if (total > (size_t)(2 * cw)) {
-        for (size_t i = (size_t)cw; i < total - (size_t)cw; i++) {
+        // each cell reads its neighbours' coordinates only and writes its own intensity
+        run_parts(pool, total - 2 * (size_t)cw, [&](size_t pb, size_t pe, unsigned) {
+        for (size_t i = pb + (size_t)cw; i < pe + (size_t)cw; i++) {
             lom_point_xyzirt &o = cloud[i];
             const float range = powf(o.x, 2) + powf(o.y, 2) + powf(o.z, 2);
             if ((double)range < 0.1) {
@@ -146,13 +268,19 @@ size_t classify(const lom_point_xyzirt *in, size_t n, float *xyz_out, float *nrm
             }
             o.intensity = (float)(std::sqrt((double)(dx * dx + dy * dy + dz * dz)) / (double)range);
         }
+        });
     }
     // normals from the previous ring, :105-165
     const int nw = 4;
     const float flat = 0.05f;
     const double flat10 = (double)flat * 10.0;
-    size_t np = 0, nu = 0;
-    for (size_t ray = 1; ray < H; ray++) {
+    // rays are independent: each one fills its own slice, slices are concatenated in ray order
+    std::vector<float> tmp_xyz(total * 3), tmp_nrm(total * 3);
+    std::vector<size_t> cnt_p(H, 0), cnt_u(H, 0);
+    run_parts(pool, H - 1, [&](size_t rb, size_t re, unsigned) {
+    for (size_t ray = rb + 1; ray < re + 1; ray++) {
+        size_t np = 0, nu = 0;
+        float *oxyz = tmp_xyz.data() + ray * W * 3, *onrm = tmp_nrm.data() + ray * W * 3;
         for (long pi = nw; pi < (long)W - nw; pi++) {
             const lom_point_xyzirt &pt = cloud[ray * W + (size_t)pi];
             if (pt.intensity < flat) {
@@ -180,8 +308,8 @@ size_t classify(const lom_point_xyzirt *in, size_t n, float *xyz_out, float *nrm
                         const float s = std::sqrt(z);
                         c[0] /= s, c[1] /= s, c[2] /= s;
                     }
-                    xyz_out[3 * np] = pt.x, xyz_out[3 * np + 1] = pt.y, xyz_out[3 * np + 2] = pt.z;
-                    nrm_out[3 * np] = c[0], nrm_out[3 * np + 1] = c[1], nrm_out[3 * np + 2] = c[2];
+                    oxyz[3 * np] = pt.x, oxyz[3 * np + 1] = pt.y, oxyz[3 * np + 2] = pt.z;
+                    onrm[3 * np] = c[0], onrm[3 * np + 1] = c[1], onrm[3 * np + 2] = c[2];
                     np++;
                 } else {
                     nu++;
@@ -190,6 +318,16 @@ size_t classify(const lom_point_xyzirt *in, size_t n, float *xyz_out, float *nrm
                 nu++;
             }
         }
+        cnt_p[ray] = np;
+        cnt_u[ray] = nu;
+    }
+    }, 2);
+    size_t np = 0, nu = 0;
+    for (size_t ray = 1; ray < H; ray++) {
+        std::memcpy(xyz_out + 3 * np, tmp_xyz.data() + ray * W * 3, cnt_p[ray] * 12);
+        std::memcpy(nrm_out + 3 * np, tmp_nrm.data() + ray * W * 3, cnt_p[ray] * 12);
+        np += cnt_p[ray];
+        nu += cnt_u[ray];
     }
     if (unclassified) *unclassified = nu;
     return np;
@@ -233,6 +371,7 @@ struct lom_odometry {
     std::vector<lom_point_xyzirt> normalized, deskewed, grid;
     std::vector<float> planar, planar_n, filtered, filtered_n, down, down_n, match, upd, upd_n;
     std::string error;
+    std::unique_ptr<Pool> pool;  // host workers for the per-point stages (std::execution::par in the reference)
 };
 
 extern "C" {
@@ -278,6 +417,11 @@ int lom_odometry_create(const lom_odometry_params *params, int device, lom_odome
     lom_odometry *o = new (std::nothrow) lom_odometry();
     if (!o) return LOM_ERR_OOM;
     o->cfg = *params;
+    {
+        unsigned hw = std::thread::hardware_concurrency();
+        if (const char *e = getenv("LOM_HOST_THREADS")) hw = (unsigned)std::max(1, atoi(e));
+        o->pool.reset(new Pool(std::max(1u, std::min(hw, 8u))));
+    }
     lom_pose_identity(&o->current);  // lidar_odometry.cpp:15-17
     o->previous = o->current;
     int rc = lom_map_create(params->keyframe_voxel_size, params->keyframe_max_points_cnt, 1 << 16, device,
@@ -328,23 +472,27 @@ int lom_odometry_process_cloud(lom_odometry *o, const lom_point_xyzirt *pts, siz
     };
     try {
         o->last = lom_odometry_frame_stats{};
+        StageTimer tm;
         const size_t cap = n ? n : 1;
         o->normalized.resize(cap);
         o->deskewed.resize(cap);
         for (auto *v : {&o->planar, &o->planar_n, &o->filtered, &o->filtered_n}) v->resize(cap * 3);
-        time_normalize(pts, n, o->normalized.data());  // :25
+        time_normalize(pts, n, o->normalized.data(), o->pool.get());  // :25
         lom_pose relative, rel_inv, ident, guess, result;
         lom_pose_relative_to(&o->previous, &o->current, &relative);  // :27
         o->previous = o->current;                                    // :28
         lom::pose_inverse(relative, rel_inv);
         lom_pose_identity(&ident);
-        transform_non_rigid(o->normalized.data(), n, rel_inv, ident, o->deskewed.data());  // :30
+        transform_non_rigid(o->normalized.data(), n, rel_inv, ident, o->deskewed.data(), o->pool.get());  // :30
+        tm.lap("norm+deskew");
         size_t nu = 0;
-        const size_t np = classify(o->deskewed.data(), n, o->planar.data(), o->planar_n.data(), &nu, nullptr, o->grid);  // :33
+        const size_t np = classify(o->deskewed.data(), n, o->planar.data(), o->planar_n.data(), &nu, nullptr, o->grid,
+                                   o->pool.get());  // :33
         const size_t nf = range_filter(o->planar.data(), o->planar_n.data(), np, o->cfg.lidar_min_range,
                                        o->cfg.lidar_max_range, o->filtered.data(), o->filtered_n.data());  // :35
         o->last.planar_points = (int64_t)np;
         o->last.filtered_points = (int64_t)nf;
+        tm.lap("classify+filter");
         int rc;
         // VoxelGrid keyframe_downsampler(update_voxel_size, 1); addCloud(filtered)   :37-38
         if ((rc = lom_map_clear(o->update_ds, o->cfg.keyframe_update_voxel_size)) != LOM_OK) return fail(rc, o->update_ds);
@@ -357,6 +505,7 @@ int lom_odometry_process_cloud(lom_odometry *o, const lom_point_xyzirt *pts, siz
         if (nd && (rc = (int)lom_map_export(o->update_ds, LOM_EXPORT_FULL, o->down.data(), o->down_n.data(), (size_t)nd)) < 0)
             return fail(rc, o->update_ds);
         o->last.update_points = nd;
+        tm.lap("update_ds");
         if (lom_map_size(o->keyframe) == 0) {  // :40-44 init keyframe
             if ((rc = lom_map_add_points(o->keyframe, o->down.data(), o->down_n.data(), (size_t)nd, 12)) != LOM_OK)
                 return fail(rc, o->keyframe);
@@ -374,6 +523,7 @@ int lom_odometry_process_cloud(lom_odometry *o, const lom_point_xyzirt *pts, siz
         if (nm && (rc = (int)lom_map_export(o->matching_ds, LOM_EXPORT_FULL_NO_NORMALS, o->match.data(), nullptr, (size_t)nm)) < 0)
             return fail(rc, o->matching_ds);
         o->last.matching_points = nm;
+        tm.lap("matching_ds");
         lom_pose_compose(&o->current, &relative, &guess);  // :51
         lom_align_stats ast;
         if ((rc = lom_match_align(o->keyframe, o->match.data(), (size_t)nm, 12, guess.t, guess.q, result.t, result.q,
@@ -381,6 +531,7 @@ int lom_odometry_process_cloud(lom_odometry *o, const lom_point_xyzirt *pts, siz
             return fail(rc, o->keyframe);
         o->last.outer_iterations = ast.outer_iterations;
         o->last.queries = ast.queries;
+        tm.lap("align");
         {  // :53-63 divergence guard
             float ang[3];
             delta_euler_deg(result.q, o->current.q, ang);
@@ -395,6 +546,7 @@ int lom_odometry_process_cloud(lom_odometry *o, const lom_point_xyzirt *pts, siz
         o->current = result;                                                                          // :65
         if ((rc = lom_map_radius_cleanup(o->keyframe, o->current.t, o->cfg.keyframe_cleanup_range)) != LOM_OK)  // :67
             return fail(rc, o->keyframe);
+        tm.lap("cleanup");
         o->upd.resize((size_t)(nd ? nd : 1) * 3);
         o->upd_n.resize((size_t)(nd ? nd : 1) * 3);
         lom_transform_points(&o->current, o->down.data(), o->down_n.data(), (size_t)nd, 12, o->upd.data(),
@@ -402,6 +554,8 @@ int lom_odometry_process_cloud(lom_odometry *o, const lom_point_xyzirt *pts, siz
         if ((rc = lom_map_add_points(o->keyframe, o->upd.data(), o->upd_n.data(), (size_t)nd, 12)) != LOM_OK)  // :70
             return fail(rc, o->keyframe);
         o->last.keyframe_voxels = lom_map_size(o->keyframe);
+        tm.lap("keyframe add");
+        tm.total();
         return LOM_OK;
     } catch (const std::bad_alloc &) {
         o->error = "host allocation failed";

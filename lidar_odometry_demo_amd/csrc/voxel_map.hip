@@ -507,7 +507,8 @@ static int read_words(lom_map *m, int first, int n)
     return LOM_OK;
 }
 
-static int add_points_device(lom_map *m, const char *d_xyz, const char *d_nrm, size_t n, size_t stride)
+static int add_points_device(lom_map *m, const char *d_xyz, const char *d_nrm, size_t n, size_t stride,
+                             bool validated_on_host)
 {
     if (n == 0) return LOM_OK;
     if (n >= 0x7FFFFFFFull) return set_error(m, LOM_ERR_ARG, "too many points in one call");
@@ -515,11 +516,13 @@ static int add_points_device(lom_map *m, const char *d_xyz, const char *d_nrm, s
     int rc;
     // 1. validate (a failing call inserts nothing)
     LOM_HIP(m, hipMemsetAsync(d_word(m, 2), 0, 12, m->stream));  // flag, cursor, total
-    hipLaunchKernelGGL(k_validate, dim3(blocks_for(N)), dim3(kThreads), 0, m->stream, d_xyz, stride, N,
-                       m->voxel_size, d_word(m, 2));
-    LOM_HIP(m, hipGetLastError());
-    if ((rc = read_words(m, 2, 1)) != LOM_OK) return rc;
-    if (m->h_flags[0]) return set_error(m, LOM_ERR_RANGE, "coordinate / voxel_size out of range or not finite");
+    if (!validated_on_host) {
+        hipLaunchKernelGGL(k_validate, dim3(blocks_for(N)), dim3(kThreads), 0, m->stream, d_xyz, stride, N,
+                           m->voxel_size, d_word(m, 2));
+        LOM_HIP(m, hipGetLastError());
+        if ((rc = read_words(m, 2, 1)) != LOM_OK) return rc;
+        if (m->h_flags[0]) return set_error(m, LOM_ERR_RANGE, "coordinate / voxel_size out of range or not finite");
+    }
     // 2. table capacity for the worst case (every point a new voxel); shrunk afterwards
     const uint64_t worst = (uint64_t)m->n_vox + N;
     if ((uint64_t)m->cap < 2 * worst) {
@@ -690,6 +693,8 @@ void lom_map_destroy(lom_map *m)
     if (m->d_table) (void)hipFree(m->d_table);
     Slabs s{m->d_slab_key, m->d_slab_count, m->d_pts, m->d_nrm};
     slabs_free(s);
+    Slabs alt{m->alt_key, m->alt_count, m->alt_pts, m->alt_nrm};
+    slabs_free(alt);
     for (auto &b : m->scr)
         if (b.p) (void)hipFree(b.p);
     for (DeviceBuf *b : {&m->scan_src, &m->scan_idx, &m->scan_on, &m->scan_stats, &m->partials, &m->results, &m->gather})
@@ -742,6 +747,12 @@ int lom_map_set_max_points(lom_map *m, size_t max_points)
     LOM_HIP(m, hipStreamSynchronize(m->stream));
     Slabs s{m->d_slab_key, m->d_slab_count, m->d_pts, m->d_nrm};
     slabs_free(s);
+    Slabs alt{m->alt_key, m->alt_count, m->alt_pts, m->alt_nrm};
+    slabs_free(alt);
+    m->alt_key = nullptr;
+    m->alt_count = nullptr;
+    m->alt_pts = m->alt_nrm = nullptr;
+    m->alt_cap = 0;
     m->d_slab_key = nullptr;
     m->d_slab_count = nullptr;
     m->d_pts = m->d_nrm = nullptr;
@@ -754,7 +765,7 @@ int lom_map_add_points_device(lom_map *m, const float *d_xyz, const float *d_nrm
 {
     if (!m || (n && !d_xyz) || stride < 12 || (stride & 3)) return LOM_ERR_ARG;
     LOM_HIP(m, hipSetDevice(m->device));
-    return add_points_device(m, (const char *)d_xyz, (const char *)d_nrm, n, stride);
+    return add_points_device(m, (const char *)d_xyz, (const char *)d_nrm, n, stride, false);
 }
 
 int lom_map_add_points(lom_map *m, const float *xyz, const float *nrm, size_t n, size_t stride)
@@ -762,10 +773,23 @@ int lom_map_add_points(lom_map *m, const float *xyz, const float *nrm, size_t n,
     if (!m || (n && !xyz) || stride < 12 || (stride & 3)) return LOM_ERR_ARG;
     if (n == 0) return LOM_OK;
     LOM_HIP(m, hipSetDevice(m->device));
+    // the points are in host memory: range-check them here (same f32 division and bounds as the
+    // device's voxel_index) instead of paying a kernel and a synchronisation
+    {
+        const float vs = m->voxel_size;
+        bool bad = false;
+        for (size_t i = 0; i < n; i++) {
+            const float *p = reinterpret_cast<const float *>(reinterpret_cast<const char *>(xyz) + i * stride);
+            const float fx = p[0] / vs, fy = p[1] / vs, fz = p[2] / vs;
+            bad |= !(fx > -kIdxLimit && fx < kIdxLimit) || !(fy > -kIdxLimit && fy < kIdxLimit) ||
+                   !(fz > -kIdxLimit && fz < kIdxLimit);
+        }
+        if (bad) return set_error(m, LOM_ERR_RANGE, "coordinate / voxel_size out of range or not finite");
+    }
     const char *dx = nullptr, *dn = nullptr;
     int rc = stage_host_points(m, xyz, nrm, n, stride, &dx, &dn);
     if (rc != LOM_OK) return rc;
-    rc = add_points_device(m, dx, dn, n, stride);
+    rc = add_points_device(m, dx, dn, n, stride, true);
     // the staging copy reads the caller's buffer asynchronously: finish before returning
     hipError_t e = hipStreamSynchronize(m->stream);
     if (rc == LOM_OK && e != hipSuccess) return set_error(m, LOM_ERR_HIP, "hipStreamSynchronize", e);
@@ -791,20 +815,32 @@ int lom_map_radius_cleanup(lom_map *m, const float center[3], float radius)
     if ((rc = read_words(m, 4, 1)) != LOM_OK) return rc;
     const uint32_t n_keep = m->h_flags[0];
     if (n_keep == nv) return LOM_OK;
-    // stable compaction into a second set of slab arrays, then rebuild the table
-    Slabs dst;
-    if ((rc = slabs_alloc(m, m->slab_cap, dst)) != LOM_OK) return rc;
+    // stable compaction into the second (persistent) set of slab arrays, swap, rebuild the table
+    if (m->alt_cap != m->slab_cap) {
+        Slabs stale{m->alt_key, m->alt_count, m->alt_pts, m->alt_nrm};
+        LOM_HIP(m, hipStreamSynchronize(m->stream));
+        slabs_free(stale);
+        m->alt_key = nullptr;
+        m->alt_count = nullptr;
+        m->alt_pts = m->alt_nrm = nullptr;
+        m->alt_cap = 0;
+        Slabs fresh;
+        if ((rc = slabs_alloc(m, m->slab_cap, fresh)) != LOM_OK) return rc;
+        m->alt_key = fresh.key;
+        m->alt_count = fresh.count;
+        m->alt_pts = fresh.pts;
+        m->alt_nrm = fresh.nrm;
+        m->alt_cap = m->slab_cap;
+    }
     const size_t work = (size_t)nv * m->K;
     hipLaunchKernelGGL(k_compact, dim3(blocks_for(work)), dim3(kThreads), 0, m->stream, keep, newid, nv, m->K,
-                       m->d_slab_key, m->d_slab_count, m->d_pts, m->d_nrm, dst.key, dst.count, dst.pts, dst.nrm);
+                       m->d_slab_key, m->d_slab_count, m->d_pts, m->d_nrm, m->alt_key, m->alt_count, m->alt_pts,
+                       m->alt_nrm);
     LOM_HIP(m, hipGetLastError());
-    LOM_HIP(m, hipStreamSynchronize(m->stream));
-    Slabs old{m->d_slab_key, m->d_slab_count, m->d_pts, m->d_nrm};
-    slabs_free(old);
-    m->d_slab_key = dst.key;
-    m->d_slab_count = dst.count;
-    m->d_pts = dst.pts;
-    m->d_nrm = dst.nrm;
+    std::swap(m->d_slab_key, m->alt_key);
+    std::swap(m->d_slab_count, m->alt_count);
+    std::swap(m->d_pts, m->alt_pts);
+    std::swap(m->d_nrm, m->alt_nrm);
     m->n_vox = n_keep;
     const MapView v = view_of(m);
     hipLaunchKernelGGL(k_table_init, dim3(blocks_for(m->cap)), dim3(kThreads), 0, m->stream, m->d_table, m->cap);
