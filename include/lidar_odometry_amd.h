@@ -100,6 +100,16 @@ typedef enum {
  * xyz_out / nrm_out may be NULL (count only). */
 int64_t lom_map_export(lom_map *m, int mode, float *xyz_out, float *nrm_out, size_t cap);
 
+/* The reference's down-sampling idiom in one pass: VoxelGrid(voxel_size, 1).addCloud(cloud)
+ * followed by getCloud() / getCloudWithoutNormals() (src/lidar_odometry.cpp:37-38,42,46-47,50):
+ * the first point of every voxel in input order, returned in order of first appearance -- exactly
+ * what lom_map_create(voxel,1) + lom_map_add_points + lom_map_export(LOM_EXPORT_FULL) return.
+ * `workspace` is any map handle; it is cleared and left empty.  nrm / nrm_out may be NULL
+ * (nrm == NULL with nrm_out set yields zero normals, like addCloudWithoutNormals).  Returns the
+ * number of voxels; writes at most `cap` points. */
+int64_t lom_voxel_downsample(lom_map *workspace, float voxel_size, const float *xyz, const float *nrm, size_t n,
+                             size_t stride_bytes, float *xyz_out, float *nrm_out, size_t cap);
+
 /* ---- getCorrespondence / findMatchingPairs (voxel_grid.h:164-234) -------- */
 typedef struct {
     int64_t index;   /* voxel_creation_index * max_points + in_voxel_index, or -1 */

@@ -149,6 +149,18 @@ class VoxelGrid:
     def getSparseCloudWithoutNormals(self):                # voxel_grid.h:150-162
         return self._export(capi.EXPORT_FIRST_PER_VOXEL, False)[0]
 
+    def downsample(self, xyz, normals, voxel_size):
+        """VoxelGrid(voxel_size, 1).addCloud(...).getCloud() in one fused pass (lidar_odometry.cpp:37-47);
+        this grid is only the workspace and is left empty."""
+        xyz = capi.xyz_array(xyz)
+        normals = capi.xyz_array(normals) if normals is not None else None
+        oxyz = np.empty_like(xyz)
+        onrm = np.empty_like(xyz)
+        n = capi.check(capi.lib().lom_voxel_downsample(
+            self._h, float(voxel_size), xyz.ctypes.data, normals.ctypes.data if normals is not None else None,
+            len(xyz), 12, oxyz.ctypes.data, onrm.ctypes.data, len(xyz)), self._h)
+        return oxyz[:n].copy(), onrm[:n].copy()
+
     def radiusCleanup(self, point, radius):                # voxel_grid.h:236-246
         capi.check(capi.lib().lom_map_radius_cleanup(self._h, capi.f3(point), float(radius)), self._h)
 

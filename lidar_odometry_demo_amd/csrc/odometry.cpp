@@ -494,16 +494,12 @@ int lom_odometry_process_cloud(lom_odometry *o, const lom_point_xyzirt *pts, siz
         o->last.filtered_points = (int64_t)nf;
         tm.lap("classify+filter");
         int rc;
-        // VoxelGrid keyframe_downsampler(update_voxel_size, 1); addCloud(filtered)   :37-38
-        if ((rc = lom_map_clear(o->update_ds, o->cfg.keyframe_update_voxel_size)) != LOM_OK) return fail(rc, o->update_ds);
-        if ((rc = lom_map_add_points(o->update_ds, o->filtered.data(), o->filtered_n.data(), nf, 12)) != LOM_OK)
-            return fail(rc, o->update_ds);
-        int64_t nd = lom_map_export(o->update_ds, LOM_EXPORT_FULL, nullptr, nullptr, 0);
+        // VoxelGrid keyframe_downsampler(update_voxel_size, 1); addCloud(filtered); getCloud()   :37-38,42,69
+        o->down.resize((nf ? nf : 1) * 3);
+        o->down_n.resize((nf ? nf : 1) * 3);
+        const int64_t nd = lom_voxel_downsample(o->update_ds, o->cfg.keyframe_update_voxel_size, o->filtered.data(),
+                                                o->filtered_n.data(), nf, 12, o->down.data(), o->down_n.data(), nf);
         if (nd < 0) return fail((int)nd, o->update_ds);
-        o->down.resize((size_t)(nd ? nd : 1) * 3);
-        o->down_n.resize((size_t)(nd ? nd : 1) * 3);
-        if (nd && (rc = (int)lom_map_export(o->update_ds, LOM_EXPORT_FULL, o->down.data(), o->down_n.data(), (size_t)nd)) < 0)
-            return fail(rc, o->update_ds);
         o->last.update_points = nd;
         tm.lap("update_ds");
         if (lom_map_size(o->keyframe) == 0) {  // :40-44 init keyframe
@@ -513,15 +509,11 @@ int lom_odometry_process_cloud(lom_odometry *o, const lom_point_xyzirt *pts, siz
             o->last.keyframe_voxels = lom_map_size(o->keyframe);
             return LOM_OK;
         }
-        // VoxelGrid matching_downsampler(matching_voxel_size, 1); addCloud(filtered)   :46-47
-        if ((rc = lom_map_clear(o->matching_ds, o->cfg.keyframe_matching_voxel_size)) != LOM_OK) return fail(rc, o->matching_ds);
-        if ((rc = lom_map_add_points(o->matching_ds, o->filtered.data(), o->filtered_n.data(), nf, 12)) != LOM_OK)
-            return fail(rc, o->matching_ds);
-        int64_t nm = lom_map_export(o->matching_ds, LOM_EXPORT_FULL_NO_NORMALS, nullptr, nullptr, 0);
+        // VoxelGrid matching_downsampler(matching_voxel_size, 1); addCloud(filtered); getCloudWithoutNormals()   :46-47,50
+        o->match.resize((nf ? nf : 1) * 3);
+        const int64_t nm = lom_voxel_downsample(o->matching_ds, o->cfg.keyframe_matching_voxel_size,
+                                                o->filtered.data(), nullptr, nf, 12, o->match.data(), nullptr, nf);
         if (nm < 0) return fail((int)nm, o->matching_ds);
-        o->match.resize((size_t)(nm ? nm : 1) * 3);
-        if (nm && (rc = (int)lom_map_export(o->matching_ds, LOM_EXPORT_FULL_NO_NORMALS, o->match.data(), nullptr, (size_t)nm)) < 0)
-            return fail(rc, o->matching_ds);
         o->last.matching_points = nm;
         tm.lap("matching_ds");
         lom_pose_compose(&o->current, &relative, &guess);  // :51

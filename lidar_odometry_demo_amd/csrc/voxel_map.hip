@@ -334,6 +334,56 @@ __global__ void k_ins_finalize(Slot *table, uint32_t n, const uint32_t *pt_slot,
 }
 
 // ---------------------------------------------------------------------------
+// fused down-sampler: VoxelGrid(voxel, 1).addCloud(cloud) followed by getCloud() /
+// getCloudWithoutNormals() (the reference's idiom, lidar_odometry.cpp:37-38,42,46-47,50) keeps
+// the FIRST point of every voxel in input order and returns them in order of first appearance.
+// That is: claim a slot per voxel, take the minimum input index per slot, keep the points whose
+// index is that minimum, compact them by a scan over the input.  No payload slabs are touched.
+// ---------------------------------------------------------------------------
+__global__ void k_ds_claim(Slot *table, uint32_t mask, uint32_t shift, const char *xyz, size_t stride, uint32_t n,
+                           float vs, uint32_t *pt_slot, uint32_t *head)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float *p = point_at(xyz, i, stride);
+    int ix = 0, iy = 0, iz = 0;
+    voxel_index(p[0], vs, ix);
+    voxel_index(p[1], vs, iy);
+    voxel_index(p[2], vs, iz);
+    const uint32_t h = claim_slot(table, mask, shift, pack_key(ix, iy, iz));
+    pt_slot[i] = h;
+    atomicMin(&head[h], i);
+}
+
+__global__ void k_ds_flag(uint32_t n, const uint32_t *pt_slot, const uint32_t *head, uint32_t *flag)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flag[i] = head[pt_slot[i]] == i ? 1u : 0u;
+}
+
+__global__ void k_ds_write(uint32_t n, const uint32_t *flag, const uint32_t *rank, const char *xyz, const char *nrm,
+                           size_t stride, float *out_xyz, float *out_nrm)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !flag[i]) return;
+    const size_t d = (size_t)rank[i] * 3;
+    const float *p = point_at(xyz, i, stride);
+    out_xyz[d] = p[0];
+    out_xyz[d + 1] = p[1];
+    out_xyz[d + 2] = p[2];
+    if (out_nrm) {
+        if (nrm) {
+            const float *q = point_at(nrm, i, stride);
+            out_nrm[d] = q[0];
+            out_nrm[d + 1] = q[1];
+            out_nrm[d + 2] = q[2];
+        } else {
+            out_nrm[d] = out_nrm[d + 1] = out_nrm[d + 2] = 0.f;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // cleanup / export kernels
 // ---------------------------------------------------------------------------
 // voxel_grid.h:238-241: erase iff (getOrigin() - point).squaredNorm() > radius_sq (f32, strict)
@@ -866,6 +916,62 @@ int64_t lom_map_point_count(const lom_map *cm)
         return set_error(m, LOM_ERR_HIP, "point count readback");
     std::memcpy(&v, m->h_flags, 8);
     return (int64_t)v;
+}
+
+int64_t lom_voxel_downsample(lom_map *ws, float voxel_size, const float *xyz, const float *nrm, size_t n,
+                             size_t stride, float *xyz_out, float *nrm_out, size_t cap)
+{
+    lom_map *m = ws;
+    if (!m || !(voxel_size > 0.f) || (n && !xyz) || stride < 12 || (stride & 3) || (n && !xyz_out)) return LOM_ERR_ARG;
+    if (n >= 0x7FFFFFFFull) return LOM_ERR_ARG;
+    LOM_HIP(m, hipSetDevice(m->device));
+    int rc = lom_map_clear(m, voxel_size);  // the workspace grid ends up cleared, like a fresh VoxelGrid(voxel, 1)
+    if (rc != LOM_OK || n == 0) return rc;
+    const uint32_t N = (uint32_t)n;
+    for (size_t i = 0; i < n; i++) {  // same range rule as addCloud (host-resident input: checked here)
+        const float *p = reinterpret_cast<const float *>(reinterpret_cast<const char *>(xyz) + i * stride);
+        const float fx = p[0] / voxel_size, fy = p[1] / voxel_size, fz = p[2] / voxel_size;
+        if (!(fx > -kIdxLimit && fx < kIdxLimit) || !(fy > -kIdxLimit && fy < kIdxLimit) ||
+            !(fz > -kIdxLimit && fz < kIdxLimit))
+            return set_error(m, LOM_ERR_RANGE, "coordinate / voxel_size out of range or not finite");
+    }
+    if ((uint64_t)m->cap < 2ull * N) {
+        if ((rc = rehash(m, next_pow2(4ull * N))) != LOM_OK) return rc;
+    }
+    const char *dx = nullptr, *dn = nullptr;
+    if ((rc = stage_host_points(m, xyz, nrm, n, stride, &dx, &dn)) != LOM_OK) return rc;
+    if ((rc = ensure(m, m->scr[S_PT_SLOT], (size_t)N * 4)) != LOM_OK) return rc;
+    if ((rc = ensure(m, m->scr[S_FLAG], (size_t)N * 4)) != LOM_OK) return rc;
+    if ((rc = ensure(m, m->scr[S_RANK], (size_t)N * 4)) != LOM_OK) return rc;
+    if ((rc = ensure(m, m->scr[S_BKT_HEAD], (size_t)m->cap * 4)) != LOM_OK) return rc;
+    if ((rc = ensure(m, m->scr[S_SCAN], scan_tmp_words(N) * 4)) != LOM_OK) return rc;
+    if ((rc = ensure(m, m->scr[S_ITEMS], (size_t)N * 12)) != LOM_OK) return rc;     // compacted xyz
+    if ((rc = ensure(m, m->scr[S_PT_POS], (size_t)N * 12)) != LOM_OK) return rc;    // compacted normals
+    uint32_t *pt_slot = (uint32_t *)m->scr[S_PT_SLOT].p, *flag = (uint32_t *)m->scr[S_FLAG].p;
+    uint32_t *rank = (uint32_t *)m->scr[S_RANK].p, *head = (uint32_t *)m->scr[S_BKT_HEAD].p;
+    float *oxyz = (float *)m->scr[S_ITEMS].p, *onrm = nrm_out ? (float *)m->scr[S_PT_POS].p : nullptr;
+    LOM_HIP(m, hipMemsetAsync(head, 0xFF, (size_t)m->cap * 4, m->stream));
+    const MapView v = view_of(m);
+    const dim3 g(blocks_for(N)), b(kThreads);
+    hipLaunchKernelGGL(k_ds_claim, g, b, 0, m->stream, m->d_table, v.mask, v.shift, dx, stride, N, voxel_size, pt_slot,
+                       head);
+    hipLaunchKernelGGL(k_ds_flag, g, b, 0, m->stream, N, pt_slot, head, flag);
+    LOM_HIP(m, hipGetLastError());
+    if ((rc = scan_exclusive(m, flag, rank, N, d_word(m, 4), (uint32_t *)m->scr[S_SCAN].p)) != LOM_OK) return rc;
+    hipLaunchKernelGGL(k_ds_write, g, b, 0, m->stream, N, flag, rank, dx, dn, stride, oxyz, onrm);
+    LOM_HIP(m, hipGetLastError());
+    if ((rc = read_words(m, 4, 1)) != LOM_OK) return rc;
+    const size_t total = m->h_flags[0];
+    const size_t take = std::min(total, cap);
+    if (take) {
+        LOM_HIP(m, hipMemcpyAsync(xyz_out, oxyz, take * 12, hipMemcpyDeviceToHost, m->stream));
+        if (nrm_out) LOM_HIP(m, hipMemcpyAsync(nrm_out, onrm, take * 12, hipMemcpyDeviceToHost, m->stream));
+    }
+    // leave the workspace empty again (its table holds claimed keys without payload)
+    hipLaunchKernelGGL(k_table_init, dim3(blocks_for(m->cap)), dim3(kThreads), 0, m->stream, m->d_table, m->cap);
+    LOM_HIP(m, hipGetLastError());
+    LOM_HIP(m, hipStreamSynchronize(m->stream));
+    return (int64_t)total;
 }
 
 int64_t lom_map_export(lom_map *m, int mode, float *xyz_out, float *nrm_out, size_t cap)

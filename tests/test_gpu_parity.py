@@ -129,6 +129,25 @@ def test_insert_heavy_duplicates_and_order(lom, oracle):
     _assert_same_map(g, og)
 
 
+@pytest.mark.parametrize("voxel", [0.1, 0.3, 0.5])
+def test_fused_downsample_equals_grid_of_cap_one(lom, oracle, fixture_cloud, voxel):
+    """lom_voxel_downsample == VoxelGrid(voxel, 1).addCloud(cloud); getCloud() (lidar_odometry.cpp:37-47)."""
+    _, xyzn = fixture_cloud
+    og = oracle.VoxelGrid(voxel, 1)
+    og.addCloud(xyzn[:, :3], xyzn[:, 3:])
+    oxyz, onrm = og.getCloud()
+    ws = lom.VoxelGrid(1.0, 1)
+    xyz, nrm = ws.downsample(xyzn[:, :3], xyzn[:, 3:], voxel)
+    assert xyz.tobytes() == oxyz.tobytes() and nrm.tobytes() == onrm.tobytes()
+    assert ws.size() == 0                                       # the workspace is left empty
+    xyz0, nrm0 = ws.downsample(xyzn[:, :3], None, voxel)        # addCloudWithoutNormals flavour
+    assert xyz0.tobytes() == oxyz.tobytes() and not nrm0.any()
+    ws.addCloud(xyzn[:100, :3], xyzn[:100, 3:])                 # and is still a working grid
+    assert ws.size() > 0
+    with pytest.raises(lom.LomError):
+        ws.downsample(np.array([[1e9, 0, 0]], np.float32), None, voxel)
+
+
 def test_out_of_range_rejected_and_nothing_inserted(lom):
     g = lom.VoxelGrid(0.5, 20)
     g.addCloudWithoutNormals(scenes.UNIQUE_POINTS)
