@@ -238,7 +238,7 @@ def main():
 
     # roofline probe for the dominant kernel, outside the timed region: a back-to-back train of
     # k_match launches at the converged pose under one HIP event pair on the library's stream
-    train_us, train_bytes = grid.profileMatch(d_scan.data_ptr(), d_scan.shape[0], pose, 0.3, reps=50)
+    train_us, train_bytes, train_requested = grid.profileMatch(d_scan.data_ptr(), d_scan.shape[0], pose, 0.3, reps=50)
     # PCIe-inclusive variant (scan handed over as a host buffer every step); never `value`
     t1 = time.perf_counter()
     for _ in range(max(3, args.steps // 4)):
@@ -294,6 +294,9 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
                 "algorithmic_bytes_per_launch": bytes_per_launch,
+                "requested_bytes_per_launch": train_requested,
+                "requested_note": "bytes the kernel itself asks for: neighbour voxels that provably cannot hold "
+                                  "a point within max_dist are not scanned (exact pruning), + 52 B output/query",
                 "avg_launch_us": avg_launch_s * 1e6,
                 "avg_launch_us_method": "HIP events around a back-to-back train of 50 launches at the final pose",
                 "in_loop_avg_launch_us": in_loop_us,

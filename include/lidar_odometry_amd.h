@@ -166,10 +166,12 @@ int lom_map_set_profiling(lom_map *m, int enabled);
 /* Roofline probe: `reps` back-to-back launches of the correspondence kernel on a device-resident
  * scan at pose (t,q), bracketed by ONE HIP event pair on the handle's stream, so the per-event
  * packet overhead is amortised.  Returns the average launch duration in microseconds and the
- * algorithmic bytes of one launch (SURVEY.md 8d formula, counted by the kernel). */
+ * algorithmic bytes of one launch (SURVEY.md 8d formula, counted by the kernel), and optionally the
+ * bytes the kernel itself requests (candidates of pruned voxels are not read; + 52 B of output per
+ * query). */
 int lom_profile_match(lom_map *m, const float *d_src_xyz, size_t n, size_t stride_bytes, const float t[3],
                       const float q_wxyz[4], float max_dist, int reps, double *avg_us_out,
-                      double *algorithmic_bytes_out);
+                      double *algorithmic_bytes_out, double *requested_bytes_out);
 /* run the handle's work on a caller-owned hipStream_t (NULL = handle's own stream) */
 int lom_map_set_stream(lom_map *m, void *hip_stream);
 

@@ -180,13 +180,14 @@ class VoxelGrid:
         return c[0]
 
     def profileMatch(self, d_src_ptr, n, transform, max_correspondence_distance=0.3, reps=20, stride_bytes=12):
-        """(average k_match launch duration [us], algorithmic bytes per launch) over a back-to-back train."""
-        us, by = C.c_double(), C.c_double()
+        """(average k_match launch duration [us], algorithmic bytes per launch, bytes the kernel requests
+        per launch) over a back-to-back train."""
+        us, by, rq = C.c_double(), C.c_double(), C.c_double()
         capi.check(capi.lib().lom_profile_match(
             self._h, d_src_ptr, int(n), int(stride_bytes), capi.f3(transform.translation),
-            capi.f4(transform.rotation), float(max_correspondence_distance), int(reps), C.byref(us), C.byref(by)),
-            self._h)
-        return us.value, by.value
+            capi.f4(transform.rotation), float(max_correspondence_distance), int(reps), C.byref(us), C.byref(by),
+            C.byref(rq)), self._h)
+        return us.value, by.value, rq.value
 
     def setProfiling(self, on):
         capi.check(capi.lib().lom_map_set_profiling(self._h, 1 if on else 0), self._h)

@@ -173,7 +173,7 @@ def lib():
     L.lom_match_align_device.argtypes = L.lom_match_align.argtypes
     L.lom_map_set_profiling.argtypes = [vp, C.c_int]
     L.lom_map_set_stream.argtypes = [vp, vp]
-    L.lom_profile_match.argtypes = [vp, vp, C.c_size_t, C.c_size_t, fp, fp, C.c_float, C.c_int, dp, dp]
+    L.lom_profile_match.argtypes = [vp, vp, C.c_size_t, C.c_size_t, fp, fp, C.c_float, C.c_int, dp, dp, dp]
     L.lom_comm_unique_id.argtypes = [C.c_char_p]
     L.lom_comm_init.argtypes = [vp, C.c_int, C.c_int, C.c_char_p]
     L.lom_comm_finalize.argtypes = [vp]

@@ -81,8 +81,8 @@ __device__ inline float axis_gap(float q, int i, float vs)
     return fmaxf(g - (1e-4f * vs + 1e-6f * fabsf(q)), 0.f);
 }
 
-template <int G>
-__global__ __launch_bounds__(kMatchThreads) void k_match(MapView map, const char *__restrict__ src, size_t stride,
+template <int G, int kU, int kMinWaves>
+__global__ __launch_bounds__(kMatchThreads, kMinWaves) void k_match(MapView map, const char *__restrict__ src, size_t stride,
                                                          uint32_t n, PoseArgs P, int32_t *__restrict__ out_idx,
                                                          MatchRec *__restrict__ out_rec,
                                                          QStat *__restrict__ out_stat,
@@ -92,11 +92,11 @@ __global__ __launch_bounds__(kMatchThreads) void k_match(MapView map, const char
     constexpr int kSets = (27 + G - 1) / G;
     __shared__ uint32_t s_pref[kGroups][32];  // inclusive prefix of scanned counts, scan order; padded with total
     __shared__ uint32_t s_base[kGroups][32];  // slab * K - exclusive prefix: point index = s_base[b] + c
-    __shared__ uint32_t s_cnt[kGroups][3];
+    __shared__ uint32_t s_cnt[kGroups][4];
     const int gl = threadIdx.x % G;
     const int grp = threadIdx.x / G;
     const uint32_t groups_total = gridDim.x * kGroups;
-    uint32_t acc_cand = 0, acc_occ = 0, acc_valid = 0;
+    uint32_t acc_cand = 0, acc_occ = 0, acc_valid = 0, acc_scanned = 0;
 
     for (uint32_t q = blockIdx.x * kGroups + grp; q < n; q += groups_total) {
         const float *sp = reinterpret_cast<const float *>(src + (size_t)q * stride);
@@ -173,26 +173,44 @@ __global__ __launch_bounds__(kMatchThreads) void k_match(MapView map, const char
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-        float best = INFINITY;
+        float best = INFINITY, bpx = 0.f, bpy = 0.f, bpz = 0.f;
         uint32_t best_c = 0xFFFFFFFFu, best_idx = 0;
         const uint32_t *pref = s_pref[grp];
-        for (uint32_t c = gl; c < T; c += G) {
-            // smallest b with pref[b] > c
-            uint32_t b = 0;
-            b += (pref[b + 15] <= c) ? 16u : 0u;
-            b += (pref[b + 7] <= c) ? 8u : 0u;
-            b += (pref[b + 3] <= c) ? 4u : 0u;
-            b += (pref[b + 1] <= c) ? 2u : 0u;
-            b += (pref[b] <= c) ? 1u : 0u;
-            const uint32_t pi = s_base[grp][b] + c;
-            const float *vp = map.pts + (size_t)pi * 3;
-            const float ax = vp[0], ay = vp[1], az = vp[2];
-            const float dx = qx - ax, dy = qy - ay, dz = qz - az;
-            const float d2 = dx * dx + (dy * dy + dz * dz);  // voxel_grid.h:184 f32 squaredNorm
-            if (d2 < P.max_sq && d2 < best) {                // :186-187 strict
-                best = d2;
-                best_c = c;
-                best_idx = pi;
+        // four candidates per lane and trip: their loads are issued together (one memory round
+        // trip for T <= 4G), then compared in candidate order (strict minimum, first wins)
+        for (uint32_t c0 = gl; c0 < T; c0 += kU * G) {
+            uint32_t pi[kU];
+            float ax[kU], ay[kU], az[kU];
+#pragma unroll
+            for (int u = 0; u < kU; u++) {
+                const uint32_t c = c0 + u * G;
+                const uint32_t cc = c < T ? c : T - 1;  // clamp: a valid address, result discarded below
+                // smallest b with pref[b] > cc
+                uint32_t b = 0;
+                b += (pref[b + 15] <= cc) ? 16u : 0u;
+                b += (pref[b + 7] <= cc) ? 8u : 0u;
+                b += (pref[b + 3] <= cc) ? 4u : 0u;
+                b += (pref[b + 1] <= cc) ? 2u : 0u;
+                b += (pref[b] <= cc) ? 1u : 0u;
+                pi[u] = s_base[grp][b] + cc;
+                const float *vp = map.pts + (size_t)pi[u] * 3;
+                ax[u] = vp[0];
+                ay[u] = vp[1];
+                az[u] = vp[2];
+            }
+#pragma unroll
+            for (int u = 0; u < kU; u++) {
+                const uint32_t c = c0 + u * G;
+                const float dx = qx - ax[u], dy = qy - ay[u], dz = qz - az[u];
+                const float d2 = dx * dx + (dy * dy + dz * dz);   // voxel_grid.h:184 f32 squaredNorm
+                if (c < T && d2 < P.max_sq && d2 < best) {        // :186-187 strict
+                    best = d2;
+                    best_c = c;
+                    best_idx = pi[u];
+                    bpx = ax[u];
+                    bpy = ay[u];
+                    bpz = az[u];
+                }
             }
         }
         // lexicographic min over the group; d2 >= 0 so its bit pattern orders like the value
@@ -204,16 +222,18 @@ __global__ __launch_bounds__(kMatchThreads) void k_match(MapView map, const char
         }
         const uint32_t w_c = (uint32_t)keyv;
         const bool valid = w_c != 0xFFFFFFFFu;
-        const uint32_t w_idx = __shfl(best_idx, valid ? (int)(w_c % G) : 0, G);  // the lane that scanned it
+        const int w_lane = valid ? (int)(w_c % G) : 0;  // the lane that scanned the winner
+        const uint32_t w_idx = __shfl(best_idx, w_lane, G);
+        const float w_px = __shfl(bpx, w_lane, G), w_py = __shfl(bpy, w_lane, G), w_pz = __shfl(bpz, w_lane, G);
         if (gl == 0) {
             int32_t idx = -1;
             float o0 = 0.f, o1 = 0.f, o2 = 0.f, n0 = 0.f, n1 = 0.f, n2 = 0.f;
             if (valid) {
                 const size_t pi = w_idx;
                 idx = (int32_t)pi;
-                o0 = map.pts[pi * 3 + 0];  // voxel_grid.h:197-198
-                o1 = map.pts[pi * 3 + 1];
-                o2 = map.pts[pi * 3 + 2];
+                o0 = w_px;  // voxel_grid.h:197-198 (already in registers from the scan)
+                o1 = w_py;
+                o2 = w_pz;
                 n0 = map.nrm[pi * 3 + 0];
                 n1 = map.nrm[pi * 3 + 1];
                 n2 = map.nrm[pi * 3 + 2];
@@ -234,6 +254,7 @@ __global__ __launch_bounds__(kMatchThreads) void k_match(MapView map, const char
             acc_cand += n_cand;
             acc_occ += n_occ;
             acc_valid += valid ? 1 : 0;
+            acc_scanned += T;  // candidates actually read (after the exact pruning)
         }
         // the LDS tables are rewritten next iteration: all reads above are complete for this wave
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -245,9 +266,10 @@ __global__ __launch_bounds__(kMatchThreads) void k_match(MapView map, const char
         s_cnt[grp][0] = acc_valid;
         s_cnt[grp][1] = acc_cand;
         s_cnt[grp][2] = acc_occ;
+        s_cnt[grp][3] = acc_scanned;
     }
     __syncthreads();
-    if (threadIdx.x < 3) {
+    if (threadIdx.x < 4) {
         uint32_t v = 0;
         for (int g = 0; g < kGroups; g++) v += s_cnt[g][threadIdx.x];
         block_counters[blockIdx.x * 4 + threadIdx.x] = v;
@@ -616,8 +638,11 @@ static int launch_match(ScanCtx &c, const float t[3], const float q[4], float ma
             c.prof_used++;
             LOM_HIP(m, hipEventRecord(e0, m->stream));
         }
-        hipLaunchKernelGGL(k_match<kMatchG>, dim3(c.match_blocks), dim3(kMatchThreads), 0, m->stream, view_of(m), c.d_src,
-                           c.stride, c.n, P, (int32_t *)m->scan_idx.p, (MatchRec *)m->scan_on.p,
+        // <lanes per query, candidates per lane and trip, min waves per SIMD>: measured on C2 / C3
+        // (tools/ab_match.py): <16,1,8> 9.2 / 37.3 us, <16,2,1> 8.9 / 41.0, <16,4,1> 10.0 / 43.5,
+        // <16,2,8> and <16,4,8> spill and lose
+        hipLaunchKernelGGL((k_match<kMatchG, 1, 8>), dim3(c.match_blocks), dim3(kMatchThreads), 0, m->stream,
+                           view_of(m), c.d_src, c.stride, c.n, P, (int32_t *)m->scan_idx.p, (MatchRec *)m->scan_on.p,
                            stats ? (QStat *)m->scan_stats.p : (QStat *)nullptr, d_block_counters(m));
         LOM_HIP(m, hipGetLastError());
         if (m->profiling) LOM_HIP(m, hipEventRecord(e1, m->stream));
@@ -875,7 +900,7 @@ int64_t lom_match_find_pairs(lom_map *m, const float *src, size_t n, size_t stri
 }
 
 int lom_profile_match(lom_map *m, const float *d_src, size_t n, size_t stride, const float t[3], const float q[4],
-                      float max_dist, int reps, double *avg_us_out, double *bytes_out)
+                      float max_dist, int reps, double *avg_us_out, double *bytes_out, double *requested_bytes_out)
 {
     if (!m || !d_src || !n || !t || !q || reps < 1 || !avg_us_out || stride < 12 || (stride & 3)) return LOM_ERR_ARG;
     if (n >= 0x7FFFFFFFull) return LOM_ERR_ARG;
@@ -905,6 +930,15 @@ int lom_profile_match(lom_map *m, const float *d_src, size_t n, size_t stride, c
     if (rc != LOM_OK) return set_error(m, rc, "lom_profile_match failed");
     *avg_us_out = (double)ms * 1e3 / reps;
     if (bytes_out) *bytes_out = 444.0 * sums[31] + 12.0 * sums[29] + 12.0 * sums[28];
+    if (requested_bytes_out) {
+        // what the kernel itself asked the memory system for: pruned neighbour voxels are not scanned
+        std::vector<uint32_t> bc((size_t)c.match_blocks * 4);
+        if (hipMemcpy(bc.data(), d_block_counters(m), bc.size() * 4, hipMemcpyDeviceToHost) != hipSuccess)
+            return set_error(m, LOM_ERR_HIP, "counter readback");
+        double scanned = 0.0;
+        for (uint32_t b = 0; b < c.match_blocks; b++) scanned += bc[(size_t)b * 4 + 3];
+        *requested_bytes_out = 444.0 * sums[31] + 12.0 * scanned + 12.0 * sums[28] + 52.0 * sums[31];
+    }
     return LOM_OK;
 }
 

@@ -21,6 +21,7 @@
 // round like the reference's (plain -O3 x86-64 build, no FMA contraction).
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -104,36 +105,36 @@ static inline uint32_t blocks_for(size_t n, int t = kThreads) { return (uint32_t
 constexpr int kScanItems = 8;
 constexpr int kScanTile = kThreads * kScanItems;
 
-__global__ __launch_bounds__(kThreads) void k_scan_tile(const uint32_t *__restrict__ in,
-                                                        uint32_t *__restrict__ out,
-                                                        uint32_t *__restrict__ tile_sums, uint32_t n)
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_scan_tile(const T *__restrict__ in, T *__restrict__ out,
+                                                        T *__restrict__ tile_sums, uint32_t n)
 {
-    __shared__ uint32_t s_wave[kThreads / 64];
+    __shared__ T s_wave[kThreads / 64];
     const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
-    uint32_t v[kScanItems];
-    uint32_t sum = 0;
+    T v[kScanItems];
+    T sum = 0;
 #pragma unroll
     for (int k = 0; k < kScanItems; k++) {
-        v[k] = (base + k < n) ? in[base + k] : 0u;
+        v[k] = (base + k < n) ? in[base + k] : T(0);
         sum += v[k];
     }
     // inclusive scan of per-thread sums inside the wave
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t inc = sum;
+    T inc = sum;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t o = __shfl_up(inc, d, 64);
+        const T o = __shfl_up(inc, d, 64);
         if (lane >= d) inc += o;
     }
     if (lane == 63) s_wave[wave] = inc;
     __syncthreads();
-    uint32_t wave_off = 0, total = 0;
+    T wave_off = 0, total = 0;
 #pragma unroll
     for (int w = 0; w < kThreads / 64; w++) {
         if (w < wave) wave_off += s_wave[w];
         total += s_wave[w];
     }
-    uint32_t run = wave_off + inc - sum;
+    T run = wave_off + inc - sum;
 #pragma unroll
     for (int k = 0; k < kScanItems; k++) {
         if (base + k < n) out[base + k] = run;
@@ -142,28 +143,30 @@ __global__ __launch_bounds__(kThreads) void k_scan_tile(const uint32_t *__restri
     if (threadIdx.x == 0) tile_sums[blockIdx.x] = total;
 }
 
-__global__ void k_scan_add(uint32_t *__restrict__ out, const uint32_t *__restrict__ tile_prefix, uint32_t n)
+template <typename T>
+__global__ void k_scan_add(T *__restrict__ out, const T *__restrict__ tile_prefix, uint32_t n)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] += tile_prefix[i / kScanTile];
 }
 
-// out[i] = sum in[0..i), *d_total = sum of all.  tmp must hold 2*(n/tile + 2) words per level.
-static int scan_exclusive(lom_map *m, const uint32_t *in, uint32_t *out, uint32_t n, uint32_t *d_total,
-                          uint32_t *tmp)
+// out[i] = sum in[0..i), *d_total = sum of all.  tmp must hold scan_tmp_words(n) elements of T.
+// T = uint64 scans two packed uint32 quantities at once (no carry while the low sum < 2^32).
+template <typename T>
+static int scan_exclusive(lom_map *m, const T *in, T *out, uint32_t n, T *d_total, T *tmp)
 {
     const uint32_t nt = (n + kScanTile - 1) / kScanTile;
     if (nt <= 1) {
-        hipLaunchKernelGGL(k_scan_tile, dim3(1), dim3(kThreads), 0, m->stream, in, out, d_total, n);
+        hipLaunchKernelGGL(k_scan_tile<T>, dim3(1), dim3(kThreads), 0, m->stream, in, out, d_total, n);
         LOM_HIP(m, hipGetLastError());
         return LOM_OK;
     }
-    uint32_t *sums = tmp, *prefix = tmp + nt;
-    hipLaunchKernelGGL(k_scan_tile, dim3(nt), dim3(kThreads), 0, m->stream, in, out, sums, n);
+    T *sums = tmp, *prefix = tmp + nt;
+    hipLaunchKernelGGL(k_scan_tile<T>, dim3(nt), dim3(kThreads), 0, m->stream, in, out, sums, n);
     LOM_HIP(m, hipGetLastError());
-    int rc = scan_exclusive(m, sums, prefix, nt, d_total, tmp + 2 * (size_t)nt);
+    int rc = scan_exclusive<T>(m, sums, prefix, nt, d_total, tmp + 2 * (size_t)nt);
     if (rc != LOM_OK) return rc;
-    hipLaunchKernelGGL(k_scan_add, dim3(blocks_for(n)), dim3(kThreads), 0, m->stream, out, prefix, n);
+    hipLaunchKernelGGL(k_scan_add<T>, dim3(blocks_for(n)), dim3(kThreads), 0, m->stream, out, prefix, n);
     LOM_HIP(m, hipGetLastError());
     return LOM_OK;
 }
@@ -205,14 +208,13 @@ __device__ inline uint32_t claim_slot(Slot *table, uint32_t mask, uint32_t shift
 
 // rebuild the table from the slab arrays (after rehash / cleanup)
 __global__ void k_rebuild(Slot *table, uint32_t mask, uint32_t shift, const unsigned long long *slab_key,
-                          const uint32_t *slab_count, uint32_t n_vox, unsigned long long *n_points)
+                          const uint32_t *slab_count, uint32_t n_vox)
 {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_vox) return;
     const uint32_t h = claim_slot(table, mask, shift, slab_key[s]);
     table[h].count = slab_count[s];
     table[h].slab = s;
-    if (n_points) atomicAdd(n_points, (unsigned long long)slab_count[s]);
 }
 
 // ---------------------------------------------------------------------------
@@ -250,30 +252,39 @@ __global__ void k_ins_claim(Slot *table, uint32_t mask, uint32_t shift, const ch
     atomicMin(&bkt_head[h], i);              // earliest input index touching the voxel
 }
 
+// per point: low word = 1 if it is the first point of a voxel seen for the first time (creation
+// order = order of first appearance, voxel_grid.h:83-87), high word = size of the voxel's bucket
+// if the point is the bucket's head.  One 64-bit exclusive scan then yields the new voxel's slab
+// rank and the bucket's offset in the scratch list -- no same-address atomics.
 __global__ void k_ins_heads(const Slot *table, uint32_t n, const uint32_t *pt_slot, const uint32_t *bkt_cnt,
-                            const uint32_t *bkt_head, uint32_t *bkt_off, uint32_t *cursor, uint32_t *flag_new)
+                            const uint32_t *bkt_head, unsigned long long *flag64)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t h = pt_slot[i];
-    uint32_t fn = 0;
+    unsigned long long f = 0;
     if (bkt_head[h] == i) {
-        bkt_off[h] = atomicAdd(cursor, bkt_cnt[h]);  // scratch placement only
-        fn = table[h].slab == kNoSlab;               // voxel_grid.h:83 it == end()
+        f = (unsigned long long)bkt_cnt[h] << 32;
+        if (table[h].slab == kNoSlab) f |= 1ull;  // voxel_grid.h:83 it == end()
     }
-    flag_new[i] = fn;
+    flag64[i] = f;
 }
 
-// creation order = order of first appearance in the input (voxel_grid.h:83-87)
-__global__ void k_ins_assign(Slot *table, uint32_t n, const uint32_t *pt_slot, const uint32_t *flag_new,
-                             const uint32_t *rank, uint32_t n_vox_before, unsigned long long *slab_key)
+__global__ void k_ins_assign(Slot *table, uint32_t n, const uint32_t *pt_slot, const uint32_t *bkt_head,
+                             const unsigned long long *flag64, const unsigned long long *scan64,
+                             uint32_t n_vox_before, unsigned long long *slab_key, uint32_t *bkt_off)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n || !flag_new[i]) return;
+    if (i >= n) return;
     const uint32_t h = pt_slot[i];
-    const uint32_t slab = n_vox_before + rank[i];
-    table[h].slab = slab;
-    slab_key[slab] = table[h].key;
+    if (bkt_head[h] != i) return;
+    const unsigned long long sc = scan64[i];
+    bkt_off[h] = (uint32_t)(sc >> 32);
+    if (flag64[i] & 1ull) {
+        const uint32_t slab = n_vox_before + (uint32_t)sc;
+        table[h].slab = slab;
+        slab_key[slab] = table[h].key;
+    }
 }
 
 __global__ void k_ins_scatter(uint32_t n, const uint32_t *pt_slot, const uint32_t *pt_pos,
@@ -318,8 +329,7 @@ __global__ void k_ins_place(const Slot *table, uint32_t n, const uint32_t *pt_sl
 }
 
 __global__ void k_ins_finalize(Slot *table, uint32_t n, const uint32_t *pt_slot, const uint32_t *bkt_cnt,
-                               const uint32_t *bkt_head, uint32_t K, uint32_t *slab_count,
-                               unsigned long long *n_points)
+                               const uint32_t *bkt_head, uint32_t K, uint32_t *slab_count)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -330,7 +340,6 @@ __global__ void k_ins_finalize(Slot *table, uint32_t n, const uint32_t *pt_slot,
     const uint32_t nc = want < K ? want : K;
     table[h].count = nc;
     slab_count[s.slab] = nc;
-    atomicAdd(n_points, (unsigned long long)(nc - s.count));
 }
 
 // ---------------------------------------------------------------------------
@@ -470,8 +479,7 @@ static int table_alloc(lom_map *m, uint32_t cap, Slot **out)
     return LOM_OK;
 }
 
-// counters: [0] n_points (u64), then u32 words: [2] flag, [3] cursor, [4] total
-static unsigned long long *d_npoints(lom_map *m) { return (unsigned long long *)m->scr[S_MISC].p; }
+// scratch words: [0..1] u64 scan total, [2] flag, [4] u32 scan total
 static uint32_t *d_word(lom_map *m, int i) { return (uint32_t *)m->scr[S_MISC].p + i; }
 
 static int rehash(lom_map *m, uint32_t new_cap)
@@ -485,8 +493,7 @@ static int rehash(lom_map *m, uint32_t new_cap)
     if (m->n_vox) {
         const MapView v = view_of(m);
         hipLaunchKernelGGL(k_rebuild, dim3(blocks_for(m->n_vox)), dim3(kThreads), 0, m->stream, m->d_table,
-                           v.mask, v.shift, m->d_slab_key, m->d_slab_count, m->n_vox,
-                           (unsigned long long *)nullptr);
+                           v.mask, v.shift, m->d_slab_key, m->d_slab_count, m->n_vox);
         LOM_HIP(m, hipGetLastError());
     }
     if (old) {
@@ -581,15 +588,16 @@ static int add_points_device(lom_map *m, const char *d_xyz, const char *d_nrm, s
     // 3. scratch
     if ((rc = ensure(m, m->scr[S_PT_SLOT], (size_t)N * 4)) != LOM_OK) return rc;
     if ((rc = ensure(m, m->scr[S_PT_POS], (size_t)N * 4)) != LOM_OK) return rc;
-    if ((rc = ensure(m, m->scr[S_FLAG], (size_t)N * 4)) != LOM_OK) return rc;
-    if ((rc = ensure(m, m->scr[S_RANK], (size_t)N * 4)) != LOM_OK) return rc;
+    if ((rc = ensure(m, m->scr[S_FLAG], (size_t)N * 8)) != LOM_OK) return rc;
+    if ((rc = ensure(m, m->scr[S_RANK], (size_t)N * 8)) != LOM_OK) return rc;
     if ((rc = ensure(m, m->scr[S_ITEMS], (size_t)N * 4)) != LOM_OK) return rc;
     if ((rc = ensure(m, m->scr[S_BKT_CNT], (size_t)m->cap * 4)) != LOM_OK) return rc;
     if ((rc = ensure(m, m->scr[S_BKT_HEAD], (size_t)m->cap * 4)) != LOM_OK) return rc;
     if ((rc = ensure(m, m->scr[S_BKT_OFF], (size_t)m->cap * 4)) != LOM_OK) return rc;
-    if ((rc = ensure(m, m->scr[S_SCAN], scan_tmp_words(N) * 4)) != LOM_OK) return rc;
+    if ((rc = ensure(m, m->scr[S_SCAN], scan_tmp_words(N) * 8)) != LOM_OK) return rc;
     uint32_t *pt_slot = (uint32_t *)m->scr[S_PT_SLOT].p, *pt_pos = (uint32_t *)m->scr[S_PT_POS].p;
-    uint32_t *flag = (uint32_t *)m->scr[S_FLAG].p, *rank = (uint32_t *)m->scr[S_RANK].p;
+    unsigned long long *flag64 = (unsigned long long *)m->scr[S_FLAG].p;
+    unsigned long long *scan64 = (unsigned long long *)m->scr[S_RANK].p;
     uint32_t *items = (uint32_t *)m->scr[S_ITEMS].p;
     uint32_t *bcnt = (uint32_t *)m->scr[S_BKT_CNT].p, *bhead = (uint32_t *)m->scr[S_BKT_HEAD].p;
     uint32_t *boff = (uint32_t *)m->scr[S_BKT_OFF].p;
@@ -599,21 +607,26 @@ static int add_points_device(lom_map *m, const char *d_xyz, const char *d_nrm, s
     const dim3 g(blocks_for(N)), b(kThreads);
     hipLaunchKernelGGL(k_ins_claim, g, b, 0, m->stream, m->d_table, v.mask, v.shift, d_xyz, stride, N,
                        m->voxel_size, pt_slot, pt_pos, bcnt, bhead);
-    hipLaunchKernelGGL(k_ins_heads, g, b, 0, m->stream, m->d_table, N, pt_slot, bcnt, bhead, boff, d_word(m, 3), flag);
+    hipLaunchKernelGGL(k_ins_heads, g, b, 0, m->stream, m->d_table, N, pt_slot, bcnt, bhead, flag64);
     LOM_HIP(m, hipGetLastError());
-    if ((rc = scan_exclusive(m, flag, rank, N, d_word(m, 4), (uint32_t *)m->scr[S_SCAN].p)) != LOM_OK) return rc;
-    if ((rc = read_words(m, 4, 1)) != LOM_OK) return rc;
+    unsigned long long *d_total64 = (unsigned long long *)m->scr[S_MISC].p;
+    if ((rc = scan_exclusive<unsigned long long>(m, flag64, scan64, N, d_total64,
+                                                 (unsigned long long *)m->scr[S_SCAN].p)) != LOM_OK)
+        return rc;
+    if ((rc = read_words(m, 0, 1)) != LOM_OK) return rc;  // low word of the total = number of new voxels
     const uint32_t n_new = m->h_flags[0];
     if ((rc = ensure_slabs(m, (uint64_t)m->n_vox + n_new)) != LOM_OK) return rc;
-    hipLaunchKernelGGL(k_ins_assign, g, b, 0, m->stream, m->d_table, N, pt_slot, flag, rank, m->n_vox, m->d_slab_key);
+    hipLaunchKernelGGL(k_ins_assign, g, b, 0, m->stream, m->d_table, N, pt_slot, bhead, flag64, scan64, m->n_vox,
+                       m->d_slab_key, boff);
     hipLaunchKernelGGL(k_ins_scatter, g, b, 0, m->stream, N, pt_slot, pt_pos, boff, items);
     hipLaunchKernelGGL(k_ins_place, g, b, 0, m->stream, m->d_table, N, pt_slot, bcnt, boff, items, d_xyz, d_nrm,
                        stride, m->K, m->d_pts, m->d_nrm);
     hipLaunchKernelGGL(k_ins_finalize, g, b, 0, m->stream, m->d_table, N, pt_slot, bcnt, bhead, m->K,
-                       m->d_slab_count, d_npoints(m));
+                       m->d_slab_count);
     LOM_HIP(m, hipGetLastError());
     m->n_vox += n_new;
     // 4. keep the table dense enough to stay cache-resident: load factor in (1/16, 1/2]
+    // (measured on C2/C3: 2 slots per voxel costs the search 5-10 %, 4..16 are equal within noise)
     const uint32_t target = std::max(m->min_cap, next_pow2(4ull * m->n_vox));
     if (m->cap > 4 * target) {
         if ((rc = rehash(m, target)) != LOM_OK) return rc;
@@ -784,7 +797,6 @@ int lom_map_clear(lom_map *m, float voxel_size)
     m->n_points = 0;
     hipLaunchKernelGGL(k_table_init, dim3(blocks_for(m->cap)), dim3(kThreads), 0, m->stream, m->d_table, m->cap);
     LOM_HIP(m, hipGetLastError());
-    LOM_HIP(m, hipMemsetAsync(d_npoints(m), 0, 8, m->stream));
     return LOM_OK;
 }
 
@@ -894,10 +906,9 @@ int lom_map_radius_cleanup(lom_map *m, const float center[3], float radius)
     m->n_vox = n_keep;
     const MapView v = view_of(m);
     hipLaunchKernelGGL(k_table_init, dim3(blocks_for(m->cap)), dim3(kThreads), 0, m->stream, m->d_table, m->cap);
-    LOM_HIP(m, hipMemsetAsync(d_npoints(m), 0, 8, m->stream));
     if (n_keep) {
         hipLaunchKernelGGL(k_rebuild, dim3(blocks_for(n_keep)), dim3(kThreads), 0, m->stream, m->d_table, v.mask,
-                           v.shift, m->d_slab_key, m->d_slab_count, n_keep, d_npoints(m));
+                           v.shift, m->d_slab_key, m->d_slab_count, n_keep);
     }
     LOM_HIP(m, hipGetLastError());
     return LOM_OK;
@@ -907,15 +918,8 @@ int64_t lom_map_size(const lom_map *m) { return m ? (int64_t)m->n_vox : LOM_ERR_
 
 int64_t lom_map_point_count(const lom_map *cm)
 {
-    lom_map *m = const_cast<lom_map *>(cm);
-    if (!m) return LOM_ERR_ARG;
-    if (hipSetDevice(m->device) != hipSuccess) return LOM_ERR_HIP;
-    unsigned long long v = 0;
-    if (hipMemcpyAsync(m->h_flags, d_npoints(m), 8, hipMemcpyDeviceToHost, m->stream) != hipSuccess ||
-        hipStreamSynchronize(m->stream) != hipSuccess)
-        return set_error(m, LOM_ERR_HIP, "point count readback");
-    std::memcpy(&v, m->h_flags, 8);
-    return (int64_t)v;
+    // the stored points are exactly what the full export would return
+    return lom_map_export(const_cast<lom_map *>(cm), LOM_EXPORT_FULL_NO_NORMALS, nullptr, nullptr, 0);
 }
 
 int64_t lom_voxel_downsample(lom_map *ws, float voxel_size, const float *xyz, const float *nrm, size_t n,
