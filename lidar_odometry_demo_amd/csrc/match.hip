@@ -431,12 +431,17 @@ __device__ __forceinline__ void reduce_and_publish(const double acc[28], double 
         else if (tid < 31)
             o = n_match_blocks ? (double)s_cnt[tid - 28] : 0.0;
         double *dst = out_rec + (size_t)blockIdx.x * kRecWords;
-        if (tid < 31) dst[tid] = o;
         if (to_host) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // system scope: payload before the sequence word
+            // payload as system-scope (write-through) stores, wait until they have left the wave,
+            // then the sequence word: the same order a system-scope release gives, without its
+            // L2 write-back pass (nothing this wave wrote is cached)
+            if (tid < 31) __hip_atomic_store(dst + tid, o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (tid == 31)
-                __hip_atomic_store(reinterpret_cast<unsigned long long *>(dst + 31), seq, __ATOMIC_RELEASE,
+                __hip_atomic_store(reinterpret_cast<unsigned long long *>(dst + 31), seq, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_SYSTEM);
+        } else if (tid < 31) {
+            dst[tid] = o;
         }
     }
     __syncthreads();  // s_acc / s_cnt may be rewritten by the next evaluation
