@@ -31,6 +31,23 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+_REAL_STDOUT = None
+
+
+def claim_stdout():
+    """Libraries underneath (RCCL's init banner, HIP warnings) printf to stdout; the contract is ONE
+    JSON line there.  Everything else is sent to stderr; emit() writes the line to the real stdout."""
+    global _REAL_STDOUT
+    sys.stdout.flush()
+    _REAL_STDOUT = os.dup(1)
+    os.dup2(2, 1)
+
+
+def emit(line):
+    sys.stdout.flush()
+    os.write(_REAL_STDOUT if _REAL_STDOUT is not None else 1, (json.dumps(line) + "\n").encode())
+
+
 def build_workload(n_gpus, rank, config="C2"):
     from lidar_odometry_demo_amd import synth
 
@@ -143,7 +160,7 @@ def streaming(args, lom):
         line["cpu_baseline"] = {"value": q / el / 1e6, "unit": "Mcorr/s", "cores": cores, "kind": "port",
                                 "frames_per_s": m / el,
                                 "sample": f"first {m} frames of the same sequence ({el:.1f} s), CPU restatement"}
-    print(json.dumps(line), flush=True)
+    emit(line)
 
 
 def main():
@@ -156,6 +173,7 @@ def main():
                     help="C2 = BASELINE.json configs[1] (the bench line); C3 = configs[2], single GPU only; "
                          "C5 = configs[4], streaming LidarOdometry::processCloud (--steps = frames)")
     args = ap.parse_args()
+    claim_stdout()
 
     import torch
     import torch.distributed as dist
@@ -168,10 +186,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if n > 1 and world != n:
         raise SystemExit(f"--gpus {n} needs WORLD_SIZE={n} (launch with torch.distributed.run); got {world}")
+    # LOM_BENCH_FORCE_DIST=1 takes the multi-rank code path (process group, id broadcast, RCCL
+    # communicator, exchange per evaluation) with a single rank: a rehearsal on a one-GPU box
+    use_dist = n > 1 or bool(os.environ.get("LOM_BENCH_FORCE_DIST"))
+    if use_dist and "MASTER_ADDR" not in os.environ:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if n > 1:
+    if use_dist:
         dist.init_process_group("nccl", device_id=dev)
 
     if args.config != "C2" and n != 1:
@@ -185,7 +208,7 @@ def main():
     d_scan = torch.from_numpy(work["shard"]).to(dev)
     torch.cuda.synchronize()
 
-    if n > 1:
+    if use_dist:
         import ctypes as C
 
         ident = torch.zeros(lom.capi.COMM_ID_BYTES, dtype=torch.uint8, device=dev)
@@ -209,7 +232,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if n > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -231,7 +254,7 @@ def main():
         wait_ms += st["host_wait_ms"]
     fence()
     elapsed = time.perf_counter() - t0
-    if n > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -312,9 +335,9 @@ def main():
             line["cpu_baseline"] = cpu_baseline(work)
             line["speedup_vs_cpu_port"] = value / line["cpu_baseline"]["value"]
         line["pose"] = {"t": [float(v) for v in pose.translation], "q_wxyz": [float(v) for v in pose.rotation]}
-        print(json.dumps(line), flush=True)
+        emit(line)
 
-    if n > 1:
+    if use_dist:
         lom.capi.lib().lom_comm_finalize(grid.handle)
         dist.barrier()
         dist.destroy_process_group()

@@ -310,6 +310,34 @@ def test_evaluation_server_timeout_recovery(lom, monkeypatch):
     assert again.translation.tobytes() == ref.translation.tobytes()
 
 
+def test_comm_path_single_rank(lom):
+    """The multi-GPU exchange path (k_eval -> k_sum_records -> RCCL all-gather -> rank-ordered host
+    sum) with a one-rank communicator: same pose and stats as the single-GPU server path.  More
+    ranks need more GPUs than a gpurun box has; the N>1 logic itself is covered on CPU by
+    tests/test_dist_gloo.py."""
+    sm = scenes.small_synth_case()
+    g = lom.VoxelGrid(0.5, 20)
+    g.addCloud(sm["map_xyz"], sm["map_nrm"])
+    m = lom.CloudMatcher()
+    ref = m.align(g, sm["scan"], lom.Pose3D())
+    ref_stats = dict(m.stats)
+    L = lom.capi.lib()
+    ident = C.create_string_buffer(lom.capi.COMM_ID_BYTES)
+    lom.capi.check(L.lom_comm_unique_id(ident))
+    lom.capi.check(L.lom_comm_init(g.handle, 0, 1, ident.raw), g.handle)
+    assert L.lom_comm_init(g.handle, 0, 1, ident.raw) == lom.capi.ERR_STATE      # already initialised
+    try:
+        got = m.align(g, sm["scan"], lom.Pose3D())
+        assert got.translation.tobytes() == ref.translation.tobytes()
+        assert got.rotation.tobytes() == ref.rotation.tobytes()
+        for k in ("outer_iterations", "evaluations", "queries", "cand_total", "valid_last"):
+            assert m.stats[k] == ref_stats[k]
+    finally:
+        lom.capi.check(L.lom_comm_finalize(g.handle), g.handle)
+    again = m.align(g, sm["scan"], lom.Pose3D())                                 # back on the server path
+    assert again.translation.tobytes() == ref.translation.tobytes()
+
+
 def test_zero_matches_returns_guess(lom):
     g = lom.VoxelGrid(0.5, 20)
     g.addCloudWithoutNormals(np.array([[50, 50, 50]], np.float32))
