@@ -208,17 +208,45 @@ def main():
     d_scan = torch.from_numpy(work["shard"]).to(dev)
     torch.cuda.synchronize()
 
-    if use_dist:
+    # Exchange of the 32 reduced sums per residual evaluation (the path's one real exchange step).
+    # "host" (default): the ranks' hosts exchange through shared memory -- the consumer is the
+    # host-side solver and each host already holds its own sums; "rccl": all-gather over xGMI.
+    exchange = os.environ.get("LOM_EXCHANGE", "host")
+    host_comm = None
+    L = lom.capi.lib()
+
+    def broadcast_id(make):
         import ctypes as C
 
         ident = torch.zeros(lom.capi.COMM_ID_BYTES, dtype=torch.uint8, device=dev)
         if rank == 0:
             buf = C.create_string_buffer(lom.capi.COMM_ID_BYTES)
-            lom.capi.check(lom.capi.lib().lom_comm_unique_id(buf))
+            lom.capi.check(make(buf))
             ident.copy_(torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8))
         dist.broadcast(ident, 0)
-        lom.capi.check(lom.capi.lib().lom_comm_init(grid.handle, rank, n, bytes(ident.cpu().numpy().tobytes())),
-                       grid.handle)
+        return bytes(ident.cpu().numpy().tobytes())
+
+    def attach(kind):
+        nonlocal host_comm
+        import ctypes as C
+
+        if kind == "rccl":
+            lom.capi.check(L.lom_comm_init(grid.handle, rank, world, broadcast_id(L.lom_comm_unique_id)), grid.handle)
+        else:
+            h = C.c_void_p()
+            lom.capi.check(L.lom_host_comm_create(rank, world, broadcast_id(L.lom_comm_host_id), C.byref(h)))
+            lom.capi.check(L.lom_comm_attach_host(grid.handle, h), grid.handle)
+            host_comm = h
+
+    def detach():
+        nonlocal host_comm
+        L.lom_comm_finalize(grid.handle)
+        if host_comm is not None:
+            L.lom_host_comm_destroy(host_comm)
+            host_comm = None
+
+    if use_dist:
+        attach(exchange)
 
     matcher = lom.CloudMatcher()
     guess = lom.Pose3D()
@@ -259,6 +287,29 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # the other transport, for comparison (never `value`; a failure here must not cost the line)
+    other = None
+    if use_dist:
+        alt = "rccl" if exchange == "host" else "host"
+        try:
+            detach()
+            attach(alt)
+            for _ in range(min(3, args.warmup)):
+                step()
+            fence()
+            t_alt = time.perf_counter()
+            q_alt = 0
+            for _ in range(args.steps):
+                q_alt += step()[1]["queries"]
+            fence()
+            el = time.perf_counter() - t_alt
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            other = {"exchange": alt, "value": q_alt / float(t.item()) / 1e6, "unit": "Mcorr/s",
+                     "ms_per_step": float(t.item()) / args.steps * 1e3}
+        except Exception as e:  # noqa: BLE001
+            other = {"exchange": alt, "error": repr(e)[:300]}
+
     # roofline probe for the dominant kernel, outside the timed region: a back-to-back train of
     # k_match launches at the converged pose under one HIP event pair on the library's stream
     train_us, train_bytes, train_requested = grid.profileMatch(d_scan.data_ptr(), d_scan.shape[0], pose, 0.3, reps=50)
@@ -271,7 +322,8 @@ def main():
     if rank == 0:
         # stats are global (summed over ranks) after the in-library all-gather
         value = queries / elapsed / 1e6
-        bytes_per_launch = train_bytes
+        bytes_per_launch = train_bytes / n        # counters are totals over ranks after the exchange
+        train_requested = train_requested if n == 1 else None
         avg_launch_s = train_us * 1e-6
         achieved = bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
         in_loop_us = match_ms * 1e3 / max(launches, 1)
@@ -305,6 +357,10 @@ def main():
                 "outer_iterations_per_frame": outer / args.steps,
                 "evaluations_per_frame": evals / args.steps,
                 "parallelism": f"source-range x{n}, map replicated" if n > 1 else "single GPU",
+                "exchange": (exchange if use_dist else None),
+                "exchange_note": ("32 f64 per rank per residual evaluation; host = shared-memory exchange "
+                                  "between the ranks' hosts, rccl = all-gather over xGMI" if use_dist else None),
+                "other_exchange": other,
             },
             "host_breakdown_ms_per_step": {"in_launch_calls": launch_ms / args.steps,
                                            "waiting_for_results": wait_ms / args.steps},
@@ -338,7 +394,7 @@ def main():
         emit(line)
 
     if use_dist:
-        lom.capi.lib().lom_comm_finalize(grid.handle)
+        detach()
         dist.barrier()
         dist.destroy_process_group()
 

@@ -182,6 +182,18 @@ int lom_map_set_stream(lom_map *m, void *hip_stream);
 int lom_comm_unique_id(char id_out[LOM_COMM_ID_BYTES]);   /* rank 0: ncclGetUniqueId */
 int lom_comm_init(lom_map *m, int rank, int nranks, const char id[LOM_COMM_ID_BYTES]);
 int lom_comm_finalize(lom_map *m);
+/* Same contract between the ranks of ONE node without a device-side collective: each rank's host
+ * receives its own sums from the resident evaluation server, the hosts exchange the 256 bytes
+ * through POSIX shared memory and add them in rank order.  lom_comm_host_id() on rank 0, broadcast
+ * the id, lom_host_comm_create() on every rank, lom_comm_attach_host() on the map.  The exchange
+ * object is plain host code (usable without a GPU, e.g. as the allreduce hook of
+ * lom_align_with_hooks); the caller owns it. */
+typedef struct lom_host_comm lom_host_comm;
+int lom_comm_host_id(char id_out[LOM_COMM_ID_BYTES]);
+int lom_host_comm_create(int rank, int nranks, const char id[LOM_COMM_ID_BYTES], lom_host_comm **out);
+int lom_host_comm_allreduce(lom_host_comm *c, double *buf, int count); /* in place, count <= LOM_NSUMS */
+void lom_host_comm_destroy(lom_host_comm *c);
+int lom_comm_attach_host(lom_map *m, lom_host_comm *c_or_null);
 
 /* ---- host-side align driver over user evaluators ------------------------ */
 /* lom_match_align* = this driver over the HIP kernels.  Exposed so that the

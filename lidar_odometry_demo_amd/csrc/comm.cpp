@@ -9,10 +9,22 @@
 //
 // RCCL (573 MB) is loaded lazily with dlopen the first time a communicator is
 // requested, so single-GPU users never pay for it.
+//
+// Second transport, same contract (lom_comm_init_host): the reduced system is consumed by
+// the HOST-side solver of every rank, and each rank's host already holds its own 32 sums
+// ~15 us after the evaluation (resident server, pinned mailbox).  For ranks of one node the
+// hosts can exchange those 256 bytes through POSIX shared memory in about a microsecond;
+// the device-side collective costs a launch plus the collective's latency per LM iteration.
 #include <dlfcn.h>
+#include <fcntl.h>
 #include <rccl/rccl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
+#include <cstdio>
 #include <cstring>
+#include <ctime>
 
 #include "lom_internal.hpp"
 
@@ -72,7 +84,140 @@ int comm_allgather_sums(lom_map *m, const double *d_send, double *d_recv, int co
 
 }  // namespace lom
 
+// one 512-byte slot per (buffer, rank): sequence word + LOM_NSUMS doubles, cache-line separated
+struct HostSlot {
+    volatile unsigned long long seq;
+    double data[LOM_NSUMS];
+    char pad[512 - 8 - LOM_NSUMS * 8];
+};
+static_assert(sizeof(HostSlot) == 512, "slot size");
+
+struct lom_host_comm {
+    HostSlot *slots = nullptr;  // [2 buffers][nranks]
+    size_t bytes = 0;
+    std::string name;
+    int rank = 0, nranks = 1;
+    unsigned long long seq = 0;
+    std::string error;
+};
+
+namespace {
+
+double mono_s()
+{
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+}  // namespace
+
+namespace lom {
+
+int host_exchange_sums(lom_map *m, const double *mine, double *out)
+{
+    lom_host_comm *hc = reinterpret_cast<lom_host_comm *>(m->host_comm);
+    if (!hc) return set_error(m, LOM_ERR_COMM, "host exchange not attached");
+    for (int k = 0; k < LOM_NSUMS; k++) out[k] = mine[k];
+    const int rc = lom_host_comm_allreduce(hc, out, LOM_NSUMS);
+    if (rc != LOM_OK) return set_error(m, rc, hc->error.c_str());
+    return LOM_OK;
+}
+
+}  // namespace lom
+
 extern "C" {
+
+int lom_host_comm_create(int rank, int nranks, const char id_in[LOM_COMM_ID_BYTES], lom_host_comm **out)
+{
+    if (!out || !id_in || nranks < 1 || nranks > 64 || rank < 0 || rank >= nranks) return LOM_ERR_ARG;
+    *out = nullptr;
+    lom_host_comm *hc = new (std::nothrow) lom_host_comm();
+    if (!hc) return LOM_ERR_OOM;
+    char name[64];
+    std::snprintf(name, sizeof name, "/lom_%02x%02x%02x%02x%02x%02x%02x%02x", (unsigned char)id_in[0],
+                  (unsigned char)id_in[1], (unsigned char)id_in[2], (unsigned char)id_in[3], (unsigned char)id_in[4],
+                  (unsigned char)id_in[5], (unsigned char)id_in[6], (unsigned char)id_in[7]);
+    hc->name = name;
+    hc->rank = rank;
+    hc->nranks = nranks;
+    hc->bytes = sizeof(HostSlot) * 2 * (size_t)nranks;
+    // every rank opens with O_CREAT; the segment starts zero-filled (seq 0 = nothing published)
+    const int fd = shm_open(name, O_CREAT | O_RDWR, 0600);
+    if (fd < 0 || ftruncate(fd, (off_t)hc->bytes) != 0) {
+        if (fd >= 0) close(fd);
+        delete hc;
+        return LOM_ERR_COMM;
+    }
+    void *p = mmap(nullptr, hc->bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (p == MAP_FAILED) {
+        delete hc;
+        return LOM_ERR_COMM;
+    }
+    hc->slots = reinterpret_cast<HostSlot *>(p);
+    *out = hc;
+    return LOM_OK;
+}
+
+// In-place sum over the ranks of buf[0..count), count <= LOM_NSUMS, added in rank order on every
+// rank (bitwise the same result everywhere).  Double buffered: a rank can start exchange k+2 only
+// after every rank finished k+1, i.e. after every rank is done reading exchange k, whose buffer it
+// then reuses.
+int lom_host_comm_allreduce(lom_host_comm *hc, double *buf, int count)
+{
+    if (!hc || !buf || count < 0 || count > LOM_NSUMS) return LOM_ERR_ARG;
+    const unsigned long long seq = ++hc->seq;
+    HostSlot *slots = hc->slots + (size_t)(seq & 1) * hc->nranks;
+    HostSlot &me = slots[hc->rank];
+    for (int k = 0; k < count; k++) me.data[k] = buf[k];
+    __atomic_store_n(&me.seq, seq, __ATOMIC_RELEASE);
+    for (int k = 0; k < count; k++) buf[k] = 0.0;
+    const double t0 = mono_s();
+    for (int r = 0; r < hc->nranks; r++) {
+        unsigned long long spins = 0;
+        while (__atomic_load_n(&slots[r].seq, __ATOMIC_ACQUIRE) != seq) {
+            __builtin_ia32_pause();
+            if ((++spins & 0xFFFFF) == 0 && mono_s() - t0 > 60.0) {
+                hc->error = "host exchange timed out waiting for rank " + std::to_string(r);
+                return LOM_ERR_COMM;
+            }
+        }
+        for (int k = 0; k < count; k++) buf[k] += slots[r].data[k];  // rank order
+    }
+    return LOM_OK;
+}
+
+void lom_host_comm_destroy(lom_host_comm *hc)
+{
+    if (!hc) return;
+    munmap(hc->slots, hc->bytes);
+    shm_unlink(hc->name.c_str());  // every rank unlinks; later calls fail harmlessly
+    delete hc;
+}
+
+int lom_comm_attach_host(lom_map *m, lom_host_comm *hc)
+{
+    if (!m) return LOM_ERR_ARG;
+    if (m->comm) return lom::set_error(m, LOM_ERR_STATE, "an RCCL communicator is already attached");
+    m->host_comm = hc;  // NULL detaches; the caller keeps ownership
+    m->rank = hc ? hc->rank : 0;
+    m->nranks = hc ? hc->nranks : 1;
+    return LOM_OK;
+}
+
+int lom_comm_host_id(char id_out[LOM_COMM_ID_BYTES])
+{
+    if (!id_out) return LOM_ERR_ARG;
+    std::memset(id_out, 0, LOM_COMM_ID_BYTES);
+    const int fd = open("/dev/urandom", O_RDONLY);
+    if (fd < 0 || read(fd, id_out, 16) != 16) {
+        if (fd >= 0) close(fd);
+        return lom::set_error(nullptr, LOM_ERR_COMM, "/dev/urandom not readable");
+    }
+    close(fd);
+    return LOM_OK;
+}
 
 int lom_comm_unique_id(char id_out[LOM_COMM_ID_BYTES])
 {
@@ -90,7 +235,7 @@ int lom_comm_unique_id(char id_out[LOM_COMM_ID_BYTES])
 int lom_comm_init(lom_map *m, int rank, int nranks, const char id_in[LOM_COMM_ID_BYTES])
 {
     if (!m || !id_in || nranks < 1 || rank < 0 || rank >= nranks) return LOM_ERR_ARG;
-    if (m->comm) return lom::set_error(m, LOM_ERR_STATE, "communicator already initialised");
+    if (m->comm || m->host_comm) return lom::set_error(m, LOM_ERR_STATE, "communicator already initialised");
     Rccl &r = rccl();
     if (!r.ok) return lom::set_error(m, LOM_ERR_COMM, "librccl.so could not be loaded");
     LOM_HIP(m, hipSetDevice(m->device));
@@ -108,6 +253,11 @@ int lom_comm_init(lom_map *m, int rank, int nranks, const char id_in[LOM_COMM_ID
 int lom_comm_finalize(lom_map *m)
 {
     if (!m) return LOM_ERR_ARG;
+    if (m->host_comm) {  // attached host exchange: detach (its owner destroys it)
+        m->host_comm = nullptr;
+        m->rank = 0;
+        m->nranks = 1;
+    }
     if (!m->comm) return LOM_OK;
     (void)hipSetDevice(m->device);
     (void)hipStreamSynchronize(m->stream);

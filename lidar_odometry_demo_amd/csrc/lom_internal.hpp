@@ -133,7 +133,8 @@ struct lom_map {
     std::vector<hipEvent_t> prof_events;  // pairs around each k_match launch of one align
 
     // RCCL
-    void *comm = nullptr;
+    void *comm = nullptr;       // RCCL communicator (device-side all-gather)
+    void *host_comm = nullptr;  // host shared-memory exchange between the ranks of one node
     int rank = 0, nranks = 1;
     lom::DeviceBuf gather;
 
@@ -154,5 +155,7 @@ MapView view_of(const lom_map *m);
 
 // RCCL (comm.cpp), loaded lazily with dlopen
 int comm_allgather_sums(lom_map *m, const double *d_send, double *d_recv, int count);
+// host shared-memory exchange: out = sum over ranks (rank order) of `mine`
+int host_exchange_sums(lom_map *m, const double *mine, double *out);
 
 }  // namespace lom

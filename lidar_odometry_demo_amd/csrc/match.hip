@@ -799,6 +799,14 @@ static int launch_eval(ScanCtx &c, const double q[4], const double t[3], bool fr
     } else {
         for (int k = 0; k < 3; k++) out[28 + k] = m->last_counters[k];
     }
+    if (m->host_comm) {  // ranks of one node: the hosts exchange their 32 sums through shared memory
+        double mine[LOM_NSUMS];
+        std::memcpy(mine, out, sizeof mine);
+        const double t_x = now_s();
+        rc = host_exchange_sums(m, mine, out);
+        c.wait_s += now_s() - t_x;
+        if (rc != LOM_OK) return rc;
+    }
     return LOM_OK;
 }
 

@@ -752,7 +752,7 @@ void lom_map_destroy(lom_map *m)
         m->server_alive = false;
     }
     if (m->stream) (void)hipStreamSynchronize(m->stream);
-    if (m->comm) lom_comm_finalize(m);
+    if (m->comm || m->host_comm) lom_comm_finalize(m);
     if (m->d_table) (void)hipFree(m->d_table);
     Slabs s{m->d_slab_key, m->d_slab_count, m->d_pts, m->d_nrm};
     slabs_free(s);
