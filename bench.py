@@ -83,7 +83,7 @@ def build_workload(n_gpus, rank, config="C2"):
     return dict(scan=scan, shard=shard, map_xyz=map_xyz, map_nrm=map_nrm, name=name)
 
 
-def cpu_baseline(work, budget_s=20.0):
+def cpu_baseline(work, budget_s=10.0):
     """The CPU restatement (oracle, kind "port") on the same workload, on this box's host
     cores: search over all cores, solve single-threaded (mirrors std::execution::par +
     Ceres num_threads=1).  Bounded sample: whole frames until ~budget_s."""
@@ -101,7 +101,7 @@ def cpu_baseline(work, budget_s=20.0):
         frames += 1
         queries += m.stats["queries"]
         el = time.perf_counter() - t0
-        if el > budget_s or frames >= 50:
+        if el > budget_s or frames >= 2000:
             break
     return {"value": queries / el / 1e6, "unit": "Mcorr/s", "cores": cores, "kind": "port",
             "frames_per_s": frames / el,
@@ -200,6 +200,8 @@ def main():
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # the align is a chain of host<->device round trips: run on the socket the GPU hangs off
+    pinned = lom.capi.pin_to_device_numa_node(local_rank) if not os.environ.get("LOM_NO_PIN") else None
     if use_dist:
         dist.init_process_group("nccl", device_id=dev)
 
@@ -368,6 +370,7 @@ def main():
                 "outer_iterations_per_frame": outer / args.steps,
                 "evaluations_per_frame": evals / args.steps,
                 "parallelism": f"source-range x{n}, map replicated" if n > 1 else "single GPU",
+                "host_cpus": (f"{len(pinned)} CPUs of the GPU's NUMA node" if pinned else "not pinned"),
                 "exchange": (exchange if use_dist else None),
                 "exchange_note": ("32 f64 per rank per residual evaluation; host = shared-memory exchange "
                                   "between the ranks' hosts, rccl = all-gather over xGMI" if use_dist else None),

@@ -50,6 +50,9 @@ typedef enum {
 int lom_abi_version(void);
 /* number of visible HIP devices (0 when none; never initialises a context) */
 int lom_device_count(void);
+/* CPU list (sysfs syntax, e.g. "64-127,192-255") of the NUMA node a device is attached to; callers
+ * that care about the latency of the host<->device round trips run on those CPUs */
+int lom_device_local_cpus(int device, char *out, size_t cap);
 
 /* ---- Pose3D (src/pose_3d.h:10-59), f32 ---------------------------------- */
 typedef struct {

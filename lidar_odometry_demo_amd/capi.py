@@ -92,7 +92,7 @@ class AlignHooks(C.Structure):
 
 # every symbol include/lidar_odometry_amd.h declares
 EXPORTED = [
-    "lom_abi_version", "lom_device_count", "lom_pose_identity", "lom_pose_compose", "lom_pose_inverse",
+    "lom_abi_version", "lom_device_count", "lom_device_local_cpus", "lom_pose_identity", "lom_pose_compose", "lom_pose_inverse",
     "lom_pose_relative_to", "lom_pose_rotation_matrix", "lom_transform_points", "lom_map_create",
     "lom_map_destroy", "lom_last_error", "lom_map_clear", "lom_map_set_max_points", "lom_map_add_points",
     "lom_map_add_points_device", "lom_map_radius_cleanup", "lom_map_size", "lom_map_point_count",
@@ -144,6 +144,7 @@ def lib():
     fp, dp, pp, vp = C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(Pose), C.c_void_p
     L.lom_abi_version.restype = C.c_int
     L.lom_device_count.restype = C.c_int
+    L.lom_device_local_cpus.argtypes = [C.c_int, C.c_char_p, C.c_size_t]
     L.lom_pose_identity.argtypes = [pp]
     L.lom_pose_compose.argtypes = [pp, pp, pp]
     L.lom_pose_inverse.argtypes = [pp, pp]
@@ -207,6 +208,23 @@ def lib():
     L.lom_odometry_last_error.restype = C.c_char_p
     _lib = L
     return L
+
+
+def pin_to_device_numa_node(device=0):
+    """Restrict this process to the CPUs of the NUMA node the GPU is attached to (no-op when sysfs
+    does not tell).  Returns the cpu set used, or None."""
+    buf = C.create_string_buffer(512)
+    if lib().lom_device_local_cpus(int(device), buf, 512) != 0 or not buf.value:
+        return None
+    cpus = set()
+    for part in buf.value.decode().split(","):
+        lo, _, hi = part.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    cpus &= os.sched_getaffinity(0)
+    if not cpus:
+        return None
+    os.sched_setaffinity(0, cpus)
+    return cpus
 
 
 def f3(a):
