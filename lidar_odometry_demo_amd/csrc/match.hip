@@ -645,7 +645,7 @@ static int launch_match(ScanCtx &c, const float t[3], const float q[4], float ma
         }
         // <lanes per query, candidates per lane and trip, min waves per SIMD>: measured on C2 / C3
         // (tools/ab_match.py): <16,1,8> 9.2 / 37.3 us, <16,2,1> 8.9 / 41.0, <16,4,1> 10.0 / 43.5,
-        // <16,2,8> and <16,4,8> spill and lose
+        // <16,2,8> and <16,4,8> spill and lose; 8 lanes per query 12.3 / 44.1, 32 lanes 10.1 / 44.5
         hipLaunchKernelGGL((k_match<kMatchG, 1, 8>), dim3(c.match_blocks), dim3(kMatchThreads), 0, m->stream,
                            view_of(m), c.d_src, c.stride, c.n, P, (int32_t *)m->scan_idx.p, (MatchRec *)m->scan_on.p,
                            stats ? (QStat *)m->scan_stats.p : (QStat *)nullptr, d_block_counters(m));

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""A/B of k_match variants (LOM_MATCH_VARIANT) on C2 and C3: back-to-back launch trains."""
+"""Back-to-back launch trains of k_match on C2 and C3 (the numbers quoted in match.hip come from
+rebuilding with other template arguments and running this)."""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -20,10 +21,8 @@ for name, (nb, naz, nmap) in {"C2": (16, 1800, 500_000), "C3": (64, 2048, 2_000_
     d = torch.from_numpy(scan).to("cuda:0")
     torch.cuda.synchronize()
     cases[name] = (g, d)
-variants = [int(v) for v in (sys.argv[1:] or ["0", "1", "2", "3", "4"])]
-for rep in range(2):
-    for v in variants:
-        os.environ["LOM_MATCH_VARIANT"] = str(v)
+for rep in range(3):
+    for v in ("built-in",):
         row = []
         for name, (g, d) in cases.items():
             us, by, rq = g.profileMatch(d.data_ptr(), d.shape[0], lom.Pose3D(), 0.3, reps=100)
