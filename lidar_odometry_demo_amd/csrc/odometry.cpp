@@ -9,6 +9,7 @@
 // Everything that touches the voxel maps or the matcher goes through the C ABI, i.e. the GPU.
 // Built with -ffp-contract=off; f32 expression shapes follow the reference's.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -68,6 +69,7 @@ public:
         {
             std::lock_guard<std::mutex> l(m_);
             stop_ = true;
+            generation_.fetch_add(1, std::memory_order_release);
         }
         cv_.notify_all();
         for (auto &t : workers_) t.join();
@@ -75,7 +77,8 @@ public:
     unsigned size() const { return (unsigned)workers_.size() + 1; }
 
     // fn(begin, end, part) over [0, n) in size() contiguous parts; the caller takes part 0,
-    // worker w always takes part w
+    // worker w always takes part w.  Workers spin for a while after each job (a frame issues
+    // five of these within a millisecond) and park on a condition variable when idle longer.
     template <typename F>
     void parallel_for(size_t n, F &&fn, size_t serial_below = 2048)
     {
@@ -85,16 +88,15 @@ public:
             return;
         }
         std::function<void(unsigned)> job = [&](unsigned p) { fn(n * p / parts, n * (p + 1) / parts, p); };
+        job_ = &job;
+        pending_.store(parts - 1, std::memory_order_relaxed);
         {
-            std::lock_guard<std::mutex> l(m_);
-            job_ = &job;
-            pending_ = parts - 1;
-            generation_++;
+            std::lock_guard<std::mutex> l(m_);  // pairs with the parked workers' predicate check
+            generation_.fetch_add(1, std::memory_order_release);
         }
         cv_.notify_all();
         job(0);
-        std::unique_lock<std::mutex> l(m_);
-        done_.wait(l, [this] { return pending_ == 0; });
+        while (pending_.load(std::memory_order_acquire) != 0) __builtin_ia32_pause();
         job_ = nullptr;
     }
 
@@ -102,24 +104,28 @@ private:
     void run(unsigned part)
     {
         unsigned long seen = 0;
-        std::unique_lock<std::mutex> l(m_);
         for (;;) {
-            cv_.wait(l, [&] { return stop_ || generation_ != seen; });
+            // spin ~100 us for the next job, then park
+            unsigned long g = seen;
+            for (int spin = 0; spin < 40000 && (g = generation_.load(std::memory_order_acquire)) == seen; spin++)
+                __builtin_ia32_pause();
+            if (g == seen) {
+                std::unique_lock<std::mutex> l(m_);
+                cv_.wait(l, [&] { return generation_.load(std::memory_order_acquire) != seen; });
+                g = generation_.load(std::memory_order_acquire);
+            }
+            seen = g;
             if (stop_) return;
-            seen = generation_;
-            const std::function<void(unsigned)> *job = job_;
-            l.unlock();
-            (*job)(part);
-            l.lock();
-            if (--pending_ == 0) done_.notify_one();
+            (*job_)(part);
+            pending_.fetch_sub(1, std::memory_order_release);
         }
     }
     std::vector<std::thread> workers_;
     std::mutex m_;
-    std::condition_variable cv_, done_;
+    std::condition_variable cv_;
     const std::function<void(unsigned)> *job_ = nullptr;
-    unsigned pending_ = 0;
-    unsigned long generation_ = 0;
+    std::atomic<unsigned> pending_{0};
+    std::atomic<unsigned long> generation_{0};
     bool stop_ = false;
 };
 
@@ -211,9 +217,17 @@ size_t range_filter(const float *xyz, const float *nrm, size_t n, float min_rang
 // ---- CloudClassifier::classify ---------------------------------------------------------
 // planar points + normals (the unclassified cloud is discarded by the only caller,
 // lidar_odometry.cpp:33, so only its size is reported)
+struct ClassifyScratch {  // reused across frames: no allocation or zero-fill beyond what the algorithm needs
+    std::vector<lom_point_xyzirt> cloud;
+    std::vector<uint32_t> cell;
+    std::vector<float> tmp_xyz, tmp_nrm;
+    std::vector<size_t> cnt_p, cnt_u;
+};
+
 size_t classify(const lom_point_xyzirt *in, size_t n, float *xyz_out, float *nrm_out, size_t *unclassified,
-                size_t grid[2], std::vector<lom_point_xyzirt> &cloud, Pool *pool = nullptr)
+                size_t grid[2], ClassifyScratch &sc, Pool *pool = nullptr)
 {
+    std::vector<lom_point_xyzirt> &cloud = sc.cloud;
     // organise by ring (map key is uint8_t in the reference, :23) and azimuth bin
     size_t ring_count[256] = {};
     for (size_t i = 0; i < n; i++) ring_count[(uint8_t)in[i].ring]++;
@@ -234,7 +248,8 @@ size_t classify(const lom_point_xyzirt *in, size_t n, float *xyz_out, float *nrm
     std::memset(&zero, 0, sizeof zero);
     cloud.assign(total, zero);
     // cell of every point in parallel, then the scatter in input order (last writer wins, :52-54)
-    std::vector<uint32_t> cell(n);
+    std::vector<uint32_t> &cell = sc.cell;
+    if (cell.size() < n) cell.resize(n);
     run_parts(pool, n, [&](size_t pb, size_t pe, unsigned) {
         for (size_t i = pb; i < pe; i++) {
             const lom_point_xyzirt &p = in[i];
@@ -275,8 +290,11 @@ size_t classify(const lom_point_xyzirt *in, size_t n, float *xyz_out, float *nrm
     const float flat = 0.05f;
     const double flat10 = (double)flat * 10.0;
     // rays are independent: each one fills its own slice, slices are concatenated in ray order
-    std::vector<float> tmp_xyz(total * 3), tmp_nrm(total * 3);
-    std::vector<size_t> cnt_p(H, 0), cnt_u(H, 0);
+    std::vector<float> &tmp_xyz = sc.tmp_xyz, &tmp_nrm = sc.tmp_nrm;
+    if (tmp_xyz.size() < total * 3) tmp_xyz.resize(total * 3), tmp_nrm.resize(total * 3);
+    std::vector<size_t> &cnt_p = sc.cnt_p, &cnt_u = sc.cnt_u;
+    cnt_p.assign(H, 0);
+    cnt_u.assign(H, 0);
     run_parts(pool, H - 1, [&](size_t rb, size_t re, unsigned) {
     for (size_t ray = rb + 1; ray < re + 1; ray++) {
         size_t np = 0, nu = 0;
@@ -368,7 +386,8 @@ struct lom_odometry {
     lom_map *matching_ds = nullptr;    // matching_downsampler lidar_odometry.cpp:46 (reused per frame)
     lom_pose previous, current;        // lidar_odometry.h:84-85
     lom_odometry_frame_stats last{};
-    std::vector<lom_point_xyzirt> normalized, deskewed, grid;
+    std::vector<lom_point_xyzirt> normalized, deskewed;
+    ClassifyScratch classify_scratch;
     std::vector<float> planar, planar_n, filtered, filtered_n, down, down_n, match, upd, upd_n;
     std::string error;
     std::unique_ptr<Pool> pool;  // host workers for the per-point stages (std::execution::par in the reference)
@@ -393,7 +412,7 @@ size_t lom_range_filter(const float *xyz, const float *nrm, size_t n, float min_
 size_t lom_cloud_classify(const lom_point_xyzirt *in, size_t n, float *xyz_out, float *nrm_out,
                           size_t *unclassified_out, size_t grid_out[2])
 {
-    std::vector<lom_point_xyzirt> scratch;
+    ClassifyScratch scratch;
     return classify(in, n, xyz_out, nrm_out, unclassified_out, grid_out, scratch);
 }
 
@@ -420,7 +439,7 @@ int lom_odometry_create(const lom_odometry_params *params, int device, lom_odome
     {
         unsigned hw = std::thread::hardware_concurrency();
         if (const char *e = getenv("LOM_HOST_THREADS")) hw = (unsigned)std::max(1, atoi(e));
-        o->pool.reset(new Pool(std::max(1u, std::min(hw, 8u))));
+        o->pool.reset(new Pool(std::max(1u, std::min(hw, 16u))));
     }
     lom_pose_identity(&o->current);  // lidar_odometry.cpp:15-17
     o->previous = o->current;
@@ -486,8 +505,8 @@ int lom_odometry_process_cloud(lom_odometry *o, const lom_point_xyzirt *pts, siz
         transform_non_rigid(o->normalized.data(), n, rel_inv, ident, o->deskewed.data(), o->pool.get());  // :30
         tm.lap("norm+deskew");
         size_t nu = 0;
-        const size_t np = classify(o->deskewed.data(), n, o->planar.data(), o->planar_n.data(), &nu, nullptr, o->grid,
-                                   o->pool.get());  // :33
+        const size_t np = classify(o->deskewed.data(), n, o->planar.data(), o->planar_n.data(), &nu, nullptr,
+                                   o->classify_scratch, o->pool.get());  // :33
         const size_t nf = range_filter(o->planar.data(), o->planar_n.data(), np, o->cfg.lidar_min_range,
                                        o->cfg.lidar_max_range, o->filtered.data(), o->filtered_n.data());  // :35
         o->last.planar_points = (int64_t)np;
