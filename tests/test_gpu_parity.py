@@ -148,6 +148,40 @@ def test_fused_downsample_equals_grid_of_cap_one(lom, oracle, fixture_cloud, vox
         ws.downsample(np.array([[1e9, 0, 0]], np.float32), None, voxel)
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_randomized_map_and_search_parity(lom, oracle, seed):
+    """Ragged random inputs: clustered points (many collisions per voxel), negative coordinates and the
+    double-width voxel 0 of the truncating index, random cap / voxel size, several inserts with
+    cleanups in between, queries at random poses -- everything compared exactly with the oracle."""
+    rng = np.random.default_rng(1000 + seed)
+    K = int(rng.choice([1, 2, 3, 7, 20, 33]))
+    voxel = float(rng.choice([0.1, 0.25, 0.37, 0.5, 1.0]))
+    g, og = _both(lom, oracle, voxel, K)
+    for rnd in range(4):
+        n = int(rng.integers(1, 6000))
+        centers = rng.uniform(-6, 6, size=(int(rng.integers(1, 40)), 3))
+        pts = (centers[rng.integers(0, len(centers), n)] + rng.normal(0, rng.uniform(0.01, 0.8), (n, 3))).astype(np.float32)
+        pts[rng.random(n) < 0.05] *= np.float32(0.01)          # crowd the double-width voxel around 0
+        nrm = rng.standard_normal((n, 3)).astype(np.float32)
+        if rng.random() < 0.3:
+            g.addCloudWithoutNormals(pts)
+            og.addCloudWithoutNormals(pts)
+        else:
+            g.addCloud(pts, nrm)
+            og.addCloud(pts, nrm)
+        _assert_same_map(g, og)
+        if rnd in (1, 2):
+            c = rng.uniform(-3, 3, 3).astype(np.float32)
+            r = float(rng.uniform(2, 9))
+            g.radiusCleanup(c, r)
+            og.radiusCleanup(c, r)
+            _assert_same_map(g, og)
+        q = (rng.uniform(-7, 7, (int(rng.integers(1, 3000)), 3))).astype(np.float32)
+        pose = (rng.uniform(-0.5, 0.5, 3), scenes.angle_axis_q(rng.uniform(-0.3, 0.3), scenes._unit(rng.standard_normal(3))))
+        d = float(rng.choice([0.05, 0.3, 0.3, 1.0]))
+        _assert_same_pairs(g.findMatchingPairs(q, lom.Pose3D(*pose), d), og.findMatchingPairs(q, oracle.Pose3D(*pose), d))
+
+
 def test_out_of_range_rejected_and_nothing_inserted(lom):
     g = lom.VoxelGrid(0.5, 20)
     g.addCloudWithoutNormals(scenes.UNIQUE_POINTS)
@@ -370,6 +404,27 @@ def test_align_device_resident_source(lom):
     g2 = lom.VoxelGrid(0.5, 20)
     g2.addCloudDevice(mp.data_ptr(), mn.data_ptr(), mp.shape[0])
     assert g2.getCloud()[0].tobytes() == g.getCloud()[0].tobytes()
+
+
+def test_caller_owned_stream(lom):
+    """lom_map_set_stream: the handle's work runs on a caller-owned hipStream_t (here one that torch
+    created); results are unchanged and the handle can go back to its own stream."""
+    import torch
+
+    sm = scenes.small_synth_case()
+    g = lom.VoxelGrid(0.5, 20)
+    g.addCloud(sm["map_xyz"], sm["map_nrm"])
+    m = lom.CloudMatcher()
+    ref = m.align(g, sm["scan"], lom.Pose3D())
+    stream = torch.cuda.Stream()
+    lom.capi.check(lom.capi.lib().lom_map_set_stream(g.handle, C.c_void_p(stream.cuda_stream)), g.handle)
+    got = m.align(g, sm["scan"], lom.Pose3D())
+    g.addCloud(sm["map_xyz"][:1000], sm["map_nrm"][:1000])
+    n_after = g.pointCount()
+    lom.capi.check(lom.capi.lib().lom_map_set_stream(g.handle, None), g.handle)
+    assert got.translation.tobytes() == ref.translation.tobytes()
+    assert got.rotation.tobytes() == ref.rotation.tobytes()
+    assert g.pointCount() == n_after
 
 
 # ---- full BASELINE.json sizes: size-independent properties ----------------------
