@@ -94,8 +94,16 @@ struct lom_map {
     uint32_t cap = 0;  // power of two
     uint32_t min_cap = 0;
 
-    // slabs (creation order)
+    // slabs (creation order).  n_vox is the host's copy of the device-side voxel counter: an insert
+    // whose worst case fits the allocated slabs does not wait for the GPU, it only raises the upper
+    // bound n_vox_ub and marks n_vox stale; whoever needs the exact value calls refresh_nvox().
     uint32_t n_vox = 0;
+    uint32_t n_vox_ub = 0;
+    bool n_vox_stale = false;
+    // pinned bounce buffer for host-resident inputs (truly asynchronous H2D) + "last copy done" event
+    void *h_stage = nullptr;
+    size_t h_stage_bytes = 0;
+    hipEvent_t stage_ev = nullptr;
     uint32_t slab_cap = 0;
     unsigned long long *d_slab_key = nullptr;  // [slab_cap]
     uint32_t *d_slab_count = nullptr;          // [slab_cap]

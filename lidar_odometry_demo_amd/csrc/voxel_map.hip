@@ -273,12 +273,13 @@ __global__ void k_ins_heads(const Slot *table, uint32_t n, const uint32_t *pt_sl
 
 __global__ void k_ins_assign(Slot *table, uint32_t n, const uint32_t *pt_slot, const uint32_t *bkt_head,
                              const unsigned long long *flag64, const unsigned long long *scan64,
-                             uint32_t n_vox_before, unsigned long long *slab_key, uint32_t *bkt_off)
+                             const uint32_t *n_vox_dev, unsigned long long *slab_key, uint32_t *bkt_off)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t h = pt_slot[i];
     if (bkt_head[h] != i) return;
+    const uint32_t n_vox_before = *n_vox_dev;  // device-side voxel counter (bumped after this insert)
     const unsigned long long sc = scan64[i];
     bkt_off[h] = (uint32_t)(sc >> 32);
     if (flag64[i] & 1ull) {
@@ -286,6 +287,17 @@ __global__ void k_ins_assign(Slot *table, uint32_t n, const uint32_t *pt_slot, c
         table[h].slab = slab;
         slab_key[slab] = table[h].key;
     }
+}
+
+// n_vox += number of new voxels of the insert that just ran (low word of the 64-bit scan total)
+__global__ void k_nvox_bump(uint32_t *n_vox_dev, const unsigned long long *total64)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) *n_vox_dev += (uint32_t)(*total64);
+}
+
+__global__ void k_set_word(uint32_t *w, uint32_t v)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) *w = v;
 }
 
 __global__ void k_ins_scatter(uint32_t n, const uint32_t *pt_slot, const uint32_t *pt_pos,
@@ -480,8 +492,23 @@ static int table_alloc(lom_map *m, uint32_t cap, Slot **out)
     return LOM_OK;
 }
 
-// scratch words: [0..1] u64 scan total, [2] flag, [4] u32 scan total
+// scratch words: [0..1] u64 scan total, [2] flag, [4] u32 scan total, [6] device-side voxel counter
+static uint32_t *d_nvox(lom_map *m) { return (uint32_t *)m->scr[S_MISC].p + 6; }
 static uint32_t *d_word(lom_map *m, int i) { return (uint32_t *)m->scr[S_MISC].p + i; }
+
+int read_words(lom_map *m, int first, int n);
+
+// exact voxel count on the host (waits for pending inserts of this handle)
+static int refresh_nvox(lom_map *m)
+{
+    if (!m->n_vox_stale) return LOM_OK;
+    int rc = read_words(m, 6, 1);
+    if (rc != LOM_OK) return rc;
+    m->n_vox = m->h_flags[0];
+    m->n_vox_ub = m->n_vox;
+    m->n_vox_stale = false;
+    return LOM_OK;
+}
 
 static int rehash(lom_map *m, uint32_t new_cap)
 {
@@ -558,7 +585,7 @@ static int ensure_slabs(lom_map *m, uint64_t want)
     return LOM_OK;
 }
 
-static int read_words(lom_map *m, int first, int n)
+int read_words(lom_map *m, int first, int n)
 {
     LOM_HIP(m, hipMemcpyAsync(m->h_flags, d_word(m, first), (size_t)n * 4, hipMemcpyDeviceToHost, m->stream));
     LOM_HIP(m, hipStreamSynchronize(m->stream));
@@ -582,9 +609,11 @@ static int add_points_device(lom_map *m, const char *d_xyz, const char *d_nrm, s
         if (m->h_flags[0]) return set_error(m, LOM_ERR_RANGE, "coordinate / voxel_size out of range or not finite");
     }
     // 2. table capacity for the worst case (every point a new voxel); shrunk afterwards
-    const uint64_t worst = (uint64_t)m->n_vox + N;
+    uint64_t worst = (uint64_t)m->n_vox_ub + N;
     if ((uint64_t)m->cap < 2 * worst) {
-        if ((rc = rehash(m, next_pow2(4 * worst))) != LOM_OK) return rc;
+        if ((rc = refresh_nvox(m)) != LOM_OK) return rc;
+        worst = (uint64_t)m->n_vox + N;
+        if ((uint64_t)m->cap < 2 * worst && (rc = rehash(m, next_pow2(4 * worst))) != LOM_OK) return rc;
     }
     // 3. scratch
     if ((rc = ensure(m, m->scr[S_PT_SLOT], (size_t)N * 4)) != LOM_OK) return rc;
@@ -614,24 +643,62 @@ static int add_points_device(lom_map *m, const char *d_xyz, const char *d_nrm, s
     if ((rc = scan_exclusive<unsigned long long>(m, flag64, scan64, N, d_total64,
                                                  (unsigned long long *)m->scr[S_SCAN].p)) != LOM_OK)
         return rc;
-    if ((rc = read_words(m, 0, 1)) != LOM_OK) return rc;  // low word of the total = number of new voxels
-    const uint32_t n_new = m->h_flags[0];
-    if ((rc = ensure_slabs(m, (uint64_t)m->n_vox + n_new)) != LOM_OK) return rc;
-    hipLaunchKernelGGL(k_ins_assign, g, b, 0, m->stream, m->d_table, N, pt_slot, bhead, flag64, scan64, m->n_vox,
+    // If even the worst case fits the allocated slabs nothing below depends on a host decision:
+    // enqueue the rest and return (the voxel counter lives on the device).  Otherwise wait for the
+    // exact number of new voxels and grow the slabs first.
+    const bool no_wait = worst <= m->slab_cap;
+    uint32_t n_new = 0;
+    if (!no_wait) {
+        LOM_HIP(m, hipMemcpyAsync(m->h_flags, d_word(m, 0), 4, hipMemcpyDeviceToHost, m->stream));
+        LOM_HIP(m, hipMemcpyAsync(m->h_flags + 1, d_nvox(m), 4, hipMemcpyDeviceToHost, m->stream));
+        LOM_HIP(m, hipStreamSynchronize(m->stream));
+        n_new = m->h_flags[0];          // low word of the total = number of new voxels
+        m->n_vox = m->h_flags[1];       // exact: every earlier insert has bumped the counter
+        m->n_vox_ub = m->n_vox;
+        m->n_vox_stale = false;
+        if ((rc = ensure_slabs(m, (uint64_t)m->n_vox + n_new)) != LOM_OK) return rc;
+    }
+    hipLaunchKernelGGL(k_ins_assign, g, b, 0, m->stream, m->d_table, N, pt_slot, bhead, flag64, scan64, d_nvox(m),
                        m->d_slab_key, boff);
     hipLaunchKernelGGL(k_ins_scatter, g, b, 0, m->stream, N, pt_slot, pt_pos, boff, items);
     hipLaunchKernelGGL(k_ins_place, g, b, 0, m->stream, m->d_table, N, pt_slot, bcnt, boff, items, d_xyz, d_nrm,
                        stride, m->K, m->d_pts, m->d_nrm);
     hipLaunchKernelGGL(k_ins_finalize, g, b, 0, m->stream, m->d_table, N, pt_slot, bcnt, bhead, m->K,
                        m->d_slab_count);
+    hipLaunchKernelGGL(k_nvox_bump, dim3(1), dim3(1), 0, m->stream, d_nvox(m), d_total64);
     LOM_HIP(m, hipGetLastError());
+    if (no_wait) {
+        m->n_vox_ub = (uint32_t)worst;
+        m->n_vox_stale = true;
+        return LOM_OK;
+    }
     m->n_vox += n_new;
+    m->n_vox_ub = m->n_vox;
     // 4. keep the table dense enough to stay cache-resident: load factor in (1/16, 1/2]
     // (measured on C2/C3: 2 slots per voxel costs the search 5-10 %, 4..16 are equal within noise)
     const uint32_t target = std::max(m->min_cap, next_pow2(4ull * m->n_vox));
     if (m->cap > 4 * target) {
         if ((rc = rehash(m, target)) != LOM_OK) return rc;
     }
+    return LOM_OK;
+}
+
+// pinned bounce buffer: the caller's (pageable) memory is copied once on the CPU, the H2D copy is
+// then truly asynchronous and the call can return before the GPU has consumed it
+static int stage_pinned(lom_map *m, size_t bytes, char **out)
+{
+    if (m->stage_ev) LOM_HIP(m, hipEventSynchronize(m->stage_ev));  // the previous H2D has read the buffer
+    if (bytes > m->h_stage_bytes) {
+        if (m->h_stage) LOM_HIP(m, hipHostFree(m->h_stage));
+        m->h_stage = nullptr;
+        m->h_stage_bytes = 0;
+        const size_t nb = std::max(bytes + bytes / 2, (size_t)1 << 20);
+        hipError_t e = hipHostMalloc(&m->h_stage, nb, hipHostMallocDefault);
+        if (e != hipSuccess) return set_error(m, LOM_ERR_OOM, "hipHostMalloc(stage)", e);
+        m->h_stage_bytes = nb;
+    }
+    if (!m->stage_ev) LOM_HIP(m, hipEventCreateWithFlags(&m->stage_ev, hipEventDisableTiming));
+    *out = (char *)m->h_stage;
     return LOM_OK;
 }
 
@@ -643,23 +710,32 @@ static int stage_host_points(lom_map *m, const float *xyz, const float *nrm, siz
     int rc;
     const size_t bytes = (n - 1) * stride + 12;
     const char *hx = (const char *)xyz, *hn = (const char *)nrm;
+    char *pin = nullptr;
     *d_nrm = nullptr;
     if (nrm && hn >= hx && (size_t)(hn - hx) + 12 <= stride) {  // normals inside the same record
         const size_t all = (n - 1) * stride + (size_t)(hn - hx) + 12;
         if ((rc = ensure(m, m->scr[S_IN_XYZ], all)) != LOM_OK) return rc;
-        LOM_HIP(m, hipMemcpyAsync(m->scr[S_IN_XYZ].p, hx, all, hipMemcpyHostToDevice, m->stream));
+        if ((rc = stage_pinned(m, all, &pin)) != LOM_OK) return rc;
+        std::memcpy(pin, hx, all);
+        LOM_HIP(m, hipMemcpyAsync(m->scr[S_IN_XYZ].p, pin, all, hipMemcpyHostToDevice, m->stream));
+        LOM_HIP(m, hipEventRecord(m->stage_ev, m->stream));
         *d_xyz = (const char *)m->scr[S_IN_XYZ].p;
         *d_nrm = *d_xyz + (hn - hx);
         return LOM_OK;
     }
+    const size_t padded = (bytes + 255) & ~size_t(255);
     if ((rc = ensure(m, m->scr[S_IN_XYZ], bytes)) != LOM_OK) return rc;
-    LOM_HIP(m, hipMemcpyAsync(m->scr[S_IN_XYZ].p, hx, bytes, hipMemcpyHostToDevice, m->stream));
+    if (nrm && (rc = ensure(m, m->scr[S_IN_NRM], bytes)) != LOM_OK) return rc;
+    if ((rc = stage_pinned(m, nrm ? 2 * padded : padded, &pin)) != LOM_OK) return rc;
+    std::memcpy(pin, hx, bytes);
+    LOM_HIP(m, hipMemcpyAsync(m->scr[S_IN_XYZ].p, pin, bytes, hipMemcpyHostToDevice, m->stream));
     *d_xyz = (const char *)m->scr[S_IN_XYZ].p;
     if (nrm) {
-        if ((rc = ensure(m, m->scr[S_IN_NRM], bytes)) != LOM_OK) return rc;
-        LOM_HIP(m, hipMemcpyAsync(m->scr[S_IN_NRM].p, hn, bytes, hipMemcpyHostToDevice, m->stream));
+        std::memcpy(pin + padded, hn, bytes);
+        LOM_HIP(m, hipMemcpyAsync(m->scr[S_IN_NRM].p, pin + padded, bytes, hipMemcpyHostToDevice, m->stream));
         *d_nrm = (const char *)m->scr[S_IN_NRM].p;
     }
+    LOM_HIP(m, hipEventRecord(m->stage_ev, m->stream));
     return LOM_OK;
 }
 
@@ -791,6 +867,8 @@ void lom_map_destroy(lom_map *m)
     if (m->h_results) (void)hipHostFree(m->h_results);
     if (m->h_flags) (void)hipHostFree(m->h_flags);
     if (m->h_mail) (void)hipHostFree(m->h_mail);
+    if (m->h_stage) (void)hipHostFree(m->h_stage);
+    if (m->stage_ev) (void)hipEventDestroy(m->stage_ev);
     if (m->h_cmd) (void)hipHostFree(m->h_cmd);
     for (auto &e : m->prof_events)
         if (e) (void)hipEventDestroy(e);
@@ -820,8 +898,11 @@ int lom_map_clear(lom_map *m, float voxel_size)
     LOM_HIP(m, hipSetDevice(m->device));
     m->voxel_size = voxel_size;
     m->n_vox = 0;
+    m->n_vox_ub = 0;
+    m->n_vox_stale = false;
     m->n_points = 0;
     hipLaunchKernelGGL(k_table_init, dim3(blocks_for(m->cap)), dim3(kThreads), 0, m->stream, m->d_table, m->cap);
+    LOM_HIP(m, hipMemsetAsync(d_nvox(m), 0, 4, m->stream));
     LOM_HIP(m, hipGetLastError());
     return LOM_OK;
 }
@@ -830,6 +911,11 @@ int lom_map_set_max_points(lom_map *m, size_t max_points)
 {
     if (!m || max_points == 0 || max_points > 65535) return LOM_ERR_ARG;
     if (max_points == m->K) return LOM_OK;
+    LOM_HIP(m, hipSetDevice(m->device));
+    {
+        const int rcn = refresh_nvox(m);
+        if (rcn != LOM_OK) return rcn;
+    }
     if (m->n_vox != 0) return set_error(m, LOM_ERR_STATE, "max_points can only change while the map is empty");
     LOM_HIP(m, hipSetDevice(m->device));
     LOM_HIP(m, hipStreamSynchronize(m->stream));
@@ -877,19 +963,17 @@ int lom_map_add_points(lom_map *m, const float *xyz, const float *nrm, size_t n,
     const char *dx = nullptr, *dn = nullptr;
     int rc = stage_host_points(m, xyz, nrm, n, stride, &dx, &dn);
     if (rc != LOM_OK) return rc;
-    rc = add_points_device(m, dx, dn, n, stride, true);
-    // the staging copy reads the caller's buffer asynchronously: finish before returning
-    hipError_t e = hipStreamSynchronize(m->stream);
-    if (rc == LOM_OK && e != hipSuccess) return set_error(m, LOM_ERR_HIP, "hipStreamSynchronize", e);
-    return rc;
+    // the caller's buffer has been copied into the pinned bounce buffer: no need to wait for the GPU
+    return add_points_device(m, dx, dn, n, stride, true);
 }
 
 int lom_map_radius_cleanup(lom_map *m, const float center[3], float radius)
 {
     if (!m || !center) return LOM_ERR_ARG;
-    if (m->n_vox == 0) return LOM_OK;
     LOM_HIP(m, hipSetDevice(m->device));
     int rc;
+    if ((rc = refresh_nvox(m)) != LOM_OK) return rc;
+    if (m->n_vox == 0) return LOM_OK;
     const uint32_t nv = m->n_vox;
     if ((rc = ensure(m, m->scr[S_FLAG], (size_t)nv * 4)) != LOM_OK) return rc;
     if ((rc = ensure(m, m->scr[S_RANK], (size_t)nv * 4)) != LOM_OK) return rc;
@@ -930,6 +1014,8 @@ int lom_map_radius_cleanup(lom_map *m, const float center[3], float radius)
     std::swap(m->d_pts, m->alt_pts);
     std::swap(m->d_nrm, m->alt_nrm);
     m->n_vox = n_keep;
+    m->n_vox_ub = n_keep;
+    hipLaunchKernelGGL(k_set_word, dim3(1), dim3(1), 0, m->stream, d_nvox(m), n_keep);
     const MapView v = view_of(m);
     hipLaunchKernelGGL(k_table_init, dim3(blocks_for(m->cap)), dim3(kThreads), 0, m->stream, m->d_table, m->cap);
     if (n_keep) {
@@ -940,7 +1026,17 @@ int lom_map_radius_cleanup(lom_map *m, const float center[3], float radius)
     return LOM_OK;
 }
 
-int64_t lom_map_size(const lom_map *m) { return m ? (int64_t)m->n_vox : LOM_ERR_ARG; }
+int64_t lom_map_size(const lom_map *cm)
+{
+    lom_map *m = const_cast<lom_map *>(cm);
+    if (!m) return LOM_ERR_ARG;
+    if (m->n_vox_stale) {
+        if (hipSetDevice(m->device) != hipSuccess) return LOM_ERR_HIP;
+        const int rc = refresh_nvox(m);
+        if (rc != LOM_OK) return rc;
+    }
+    return (int64_t)m->n_vox;
+}
 
 int64_t lom_map_point_count(const lom_map *cm)
 {
@@ -1007,9 +1103,10 @@ int64_t lom_voxel_downsample(lom_map *ws, float voxel_size, const float *xyz, co
 int64_t lom_map_export(lom_map *m, int mode, float *xyz_out, float *nrm_out, size_t cap)
 {
     if (!m || mode < 0 || mode > 2) return LOM_ERR_ARG;
-    if (m->n_vox == 0) return 0;
     LOM_HIP(m, hipSetDevice(m->device));
     int rc;
+    if ((rc = refresh_nvox(m)) != LOM_OK) return rc;
+    if (m->n_vox == 0) return 0;
     const uint32_t nv = m->n_vox;
     if ((rc = ensure(m, m->scr[S_FLAG], (size_t)nv * 4)) != LOM_OK) return rc;
     if ((rc = ensure(m, m->scr[S_RANK], (size_t)nv * 4)) != LOM_OK) return rc;
