@@ -264,9 +264,10 @@ def main():
         return pose, matcher.stats
 
     # clocks and power state: a step is ~0.3 ms, so W of them do not bring an idle GPU up to its
-    # steady state; spin the same workload (untimed) for a quarter of a second first
-    t_spin = time.perf_counter()
-    while time.perf_counter() - t_spin < 0.25:
+    # steady state; run the same workload (untimed) for about a quarter of a second first
+    # (a fixed count, not a time limit: with several ranks every step is a sequence of exchanges
+    # and all ranks must take the same number of them)
+    for _ in range(600):
         step()
     for _ in range(args.warmup):
         step()
