@@ -164,6 +164,14 @@ int lom_match_align_device(lom_map *m, const float *d_src_xyz, size_t n, size_t 
                            const float guess_t[3], const float guess_q_wxyz[4], float out_t[3],
                            float out_q_wxyz[4], lom_align_stats *stats_or_null);
 
+/* `reps` independent aligns of the same device-resident scan from the same guess, back to back, as
+ * a compiled caller would issue them; `total` accumulates the counters and times of all of them
+ * (valid_last / final_cost / last_step_norm are the last align's).  Used by bench.py so that the
+ * timed region holds the hot path and not an interpreter's per-call overhead. */
+int lom_match_align_repeat(lom_map *m, const float *d_src_xyz, size_t n, size_t stride_bytes,
+                           const float guess_t[3], const float guess_q_wxyz[4], int reps, float out_t[3],
+                           float out_q_wxyz[4], lom_align_stats *total_or_null);
+
 /* record HIP events around the correspondence launches of lom_match_align* (stats->match_kernel_ms) */
 int lom_map_set_profiling(lom_map *m, int enabled);
 /* Roofline probe: `reps` back-to-back launches of the correspondence kernel on a device-resident

@@ -193,6 +193,17 @@ class VoxelGrid:
         capi.check(capi.lib().lom_map_set_profiling(self._h, 1 if on else 0), self._h)
 
 
+def align_repeat(keyframe, d_src_ptr, n, position_guess, reps, stride_bytes=12):
+    """`reps` back-to-back aligns of a device-resident scan issued from compiled code
+    (lom_match_align_repeat): (pose of the last one, accumulated stats)."""
+    ot, oq = (C.c_float * 3)(), (C.c_float * 4)()
+    st = capi.AlignStats()
+    capi.check(capi.lib().lom_match_align_repeat(
+        keyframe.handle, d_src_ptr, int(n), int(stride_bytes), capi.f3(position_guess.translation),
+        capi.f4(position_guess.rotation), int(reps), ot, oq, C.byref(st)), keyframe.handle)
+    return Pose3D(np.array(ot[:], np.float32), np.array(oq[:], np.float32)), st.asdict()
+
+
 class CloudMatcher:
     """reference src/cloud_matcher.h:13-17 / src/cloud_matcher.cpp:105-178."""
 

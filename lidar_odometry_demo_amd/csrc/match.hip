@@ -965,6 +965,39 @@ int lom_match_align_device(lom_map *m, const float *d_src, size_t n, size_t stri
     return align_device(m, (const char *)d_src, n, stride, guess_t, guess_q, out_t, out_q, stats);
 }
 
+int lom_match_align_repeat(lom_map *m, const float *d_src, size_t n, size_t stride, const float guess_t[3],
+                           const float guess_q[4], int reps, float out_t[3], float out_q[4],
+                           lom_align_stats *total)
+{
+    if (!m || (n && !d_src) || !guess_t || !guess_q || !out_t || !out_q || reps < 1 || stride < 12 || (stride & 3))
+        return LOM_ERR_ARG;
+    LOM_HIP(m, hipSetDevice(m->device));
+    m->last_error.clear();
+    lom_align_stats acc;
+    std::memset(&acc, 0, sizeof acc);
+    for (int r = 0; r < reps; r++) {
+        lom_align_stats st;
+        const int rc = align_device(m, (const char *)d_src, n, stride, guess_t, guess_q, out_t, out_q, &st);
+        if (rc != LOM_OK) return rc;
+        acc.outer_iterations += st.outer_iterations;
+        acc.lm_iterations += st.lm_iterations;
+        acc.evaluations += st.evaluations;
+        acc.match_launches += st.match_launches;
+        acc.queries += st.queries;
+        acc.valid_last = st.valid_last;
+        acc.cand_total += st.cand_total;
+        acc.occ_total += st.occ_total;
+        acc.final_cost = st.final_cost;
+        acc.last_step_norm = st.last_step_norm;
+        acc.match_kernel_ms += st.match_kernel_ms;
+        acc.algorithmic_bytes += st.algorithmic_bytes;
+        acc.host_launch_ms += st.host_launch_ms;
+        acc.host_wait_ms += st.host_wait_ms;
+    }
+    if (total) *total = acc;
+    return LOM_OK;
+}
+
 int lom_match_align(lom_map *m, const float *src, size_t n, size_t stride, const float guess_t[3],
                     const float guess_q[4], float out_t[3], float out_q[4], lom_align_stats *stats)
 {
