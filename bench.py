@@ -73,11 +73,16 @@ def build_workload(n_gpus, rank, config="C2"):
             scan, ring, az, _ = synth.make_scan(n_beams, 1800, boxes=boxes)
         finally:
             synth.beam_elevations = saved
-        order = np.lexsort((ring, az))
+        # sector-major order: the scan is stored as N azimuth sectors of 360/N degrees, beam-major inside
+        # a sector, and rank r takes the r-th N-th of that array (a contiguous index range).  Consecutive
+        # queries are then neighbours along a beam, as in the N = 1 workload, and a rank touches one
+        # sector of the map.
+        sector = az.astype(np.int64) * n_gpus // 1800
+        order = np.lexsort((az, ring, sector))
         scan = scan[order]
         lo, hi = len(scan) * rank // n_gpus, len(scan) * (rank + 1) // n_gpus
         shard = np.ascontiguousarray(scan[lo:hi])
-        name = (f"C2 weak-scaled: {n_beams}x1800 scan in {n_gpus} contiguous index ranges "
+        name = (f"C2 weak-scaled: {n_beams}x1800 scan, sector-major, in {n_gpus} contiguous index ranges "
                 f"vs replicated 500k-pt map, voxel 0.5 m, cap 20")
     map_xyz, map_nrm = synth.make_map_points(500_000, boxes=boxes)
     return dict(scan=scan, shard=shard, map_xyz=map_xyz, map_nrm=map_nrm, name=name)
