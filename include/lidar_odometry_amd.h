@@ -172,6 +172,13 @@ int lom_match_align_repeat(lom_map *m, const float *d_src_xyz, size_t n, size_t 
                            const float guess_t[3], const float guess_q_wxyz[4], int reps, float out_t[3],
                            float out_q_wxyz[4], lom_align_stats *total_or_null);
 
+/* Diagnostic build of the correspondence kernel with shader-clock stamps after each phase of every
+ * workgroup's first query (8 u64 per workgroup: entry, point transformed, slots probed, prefix in
+ * LDS, candidates scanned, minimum known, record stored, exit).  Not a timing of the product kernel. */
+int lom_debug_match_stamps(lom_map *m, const float *d_src_xyz, size_t n, size_t stride_bytes, const float t[3],
+                           const float q_wxyz[4], float max_dist, unsigned long long *stamps_out,
+                           size_t cap_blocks, uint32_t *n_blocks_out);
+
 /* record HIP events around the correspondence launches of lom_match_align* (stats->match_kernel_ms) */
 int lom_map_set_profiling(lom_map *m, int enabled);
 /* Roofline probe: `reps` back-to-back launches of the correspondence kernel on a device-resident

@@ -96,7 +96,7 @@ EXPORTED = [
     "lom_pose_relative_to", "lom_pose_rotation_matrix", "lom_transform_points", "lom_map_create",
     "lom_map_destroy", "lom_last_error", "lom_map_clear", "lom_map_set_max_points", "lom_map_add_points",
     "lom_map_add_points_device", "lom_map_radius_cleanup", "lom_map_size", "lom_map_point_count",
-    "lom_map_export", "lom_voxel_downsample", "lom_match_find_pairs", "lom_match_align", "lom_match_align_device", "lom_match_align_repeat",
+    "lom_map_export", "lom_voxel_downsample", "lom_match_find_pairs", "lom_match_align", "lom_match_align_device", "lom_match_align_repeat", "lom_debug_match_stamps",
     "lom_map_set_profiling", "lom_profile_match", "lom_map_set_stream", "lom_comm_unique_id", "lom_comm_init",
     "lom_comm_finalize", "lom_comm_host_id", "lom_host_comm_create", "lom_host_comm_allreduce",
     "lom_host_comm_destroy", "lom_comm_attach_host", "lom_align_with_hooks", "lom_point_time_normalize", "lom_transform_non_rigid",
@@ -173,6 +173,8 @@ def lib():
     L.lom_match_find_pairs.restype = C.c_int64
     L.lom_match_align.argtypes = [vp, vp, C.c_size_t, C.c_size_t, fp, fp, fp, fp, C.POINTER(AlignStats)]
     L.lom_match_align_device.argtypes = L.lom_match_align.argtypes
+    L.lom_debug_match_stamps.argtypes = [vp, vp, C.c_size_t, C.c_size_t, fp, fp, C.c_float, vp, C.c_size_t,
+                                         C.POINTER(C.c_uint32)]
     L.lom_match_align_repeat.argtypes = [vp, vp, C.c_size_t, C.c_size_t, fp, fp, C.c_int, fp, fp, C.POINTER(AlignStats)]
     L.lom_map_set_profiling.argtypes = [vp, C.c_int]
     L.lom_map_set_stream.argtypes = [vp, vp]

@@ -81,13 +81,45 @@ __device__ inline float axis_gap(float q, int i, float vs)
     return fmaxf(g - (1e-4f * vs + 1e-6f * fabsf(q)), 0.f);
 }
 
-template <int G, int kU, int kMinWaves>
+// kStamp = true is a diagnostic build (lom_debug_match_stamps): thread 0 of every workgroup records
+// the shader clock after each phase of its first query, every wait fully drained before a stamp.
+// Its run time is not representative; the product launches kStamp = false only.
+template <bool kOn>
+struct Stamper {  // product build: nothing
+    __device__ __forceinline__ void mark(int) {}
+    __device__ __forceinline__ void first_done() {}
+    __device__ __forceinline__ void flush(unsigned long long *) {}
+};
+template <>
+struct Stamper<true> {
+    unsigned long long t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    bool first = true;
+    __device__ __forceinline__ void mark(int i)
+    {
+        if (!first) return;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if (threadIdx.x == 0) t[i] = __builtin_amdgcn_s_memtime();
+    }
+    __device__ __forceinline__ void first_done() { first = false; }
+    __device__ __forceinline__ void flush(unsigned long long *out)
+    {
+        if (threadIdx.x != 0) return;
+        t[7] = __builtin_amdgcn_s_memtime();
+        for (int i = 0; i < 8; i++) out[(size_t)blockIdx.x * 8 + i] = t[i];
+    }
+};
+#define LOM_STAMP(i) stamper.mark(i)
+
+template <int G, int kU, int kMinWaves, bool kStamp = false>
 __global__ __launch_bounds__(kMatchThreads, kMinWaves) void k_match(MapView map, const char *__restrict__ src, size_t stride,
                                                          uint32_t n, PoseArgs P, int32_t *__restrict__ out_idx,
                                                          MatchRec *__restrict__ out_rec,
                                                          QStat *__restrict__ out_stat,
-                                                         uint32_t *__restrict__ block_counters)
+                                                         uint32_t *__restrict__ block_counters,
+                                                         unsigned long long *__restrict__ stamps = nullptr)
 {
+    Stamper<kStamp> stamper;
+    LOM_STAMP(0);
     constexpr int kGroups = kMatchThreads / G;
     constexpr int kSets = (27 + G - 1) / G;
     __shared__ uint32_t s_pref[kGroups][32];  // inclusive prefix of scanned counts, scan order; padded with total
@@ -96,7 +128,9 @@ __global__ __launch_bounds__(kMatchThreads, kMinWaves) void k_match(MapView map,
     const int gl = threadIdx.x % G;
     const int grp = threadIdx.x / G;
     const uint32_t groups_total = gridDim.x * kGroups;
-    uint32_t acc_cand = 0, acc_occ = 0, acc_valid = 0, acc_scanned = 0;
+    // per-group counters live in LDS (one ds_add per counter and query by the group's first lane):
+    // four fewer live registers keep the kernel at 64 VGPRs without spilling
+    if (gl < 4) s_cnt[grp][gl] = 0u;
 
     for (uint32_t q = blockIdx.x * kGroups + grp; q < n; q += groups_total) {
         const float *sp = reinterpret_cast<const float *>(src + (size_t)q * stride);
@@ -108,6 +142,7 @@ __global__ __launch_bounds__(kMatchThreads, kMinWaves) void k_match(MapView map,
         int ix = 0, iy = 0, iz = 0;
         const bool inr = voxel_index(qx, map.voxel_size, ix) && voxel_index(qy, map.voxel_size, iy) &&
                          voxel_index(qz, map.voxel_size, iz);
+        LOM_STAMP(1);  // source point loaded and transformed
         uint32_t cnt[kSets], scan_cnt[kSets], slab[kSets];
 #pragma unroll
         for (int s = 0; s < kSets; s++) {
@@ -143,6 +178,7 @@ __global__ __launch_bounds__(kMatchThreads, kMinWaves) void k_match(MapView map,
                 }
             }
         }
+        LOM_STAMP(2);  // 27 slots probed
         // group-wide prefix over the neighbours in scan order (set 0 = b < G, set 1 = b >= G)
         uint32_t n_occ = 0, n_cand = 0, run = 0;
 #pragma unroll
@@ -173,6 +209,7 @@ __global__ __launch_bounds__(kMatchThreads, kMinWaves) void k_match(MapView map,
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
+        LOM_STAMP(3);  // prefix in LDS
         float best = INFINITY, bpx = 0.f, bpy = 0.f, bpz = 0.f;
         uint32_t best_c = 0xFFFFFFFFu, best_idx = 0;
         const uint32_t *pref = s_pref[grp];
@@ -213,6 +250,7 @@ __global__ __launch_bounds__(kMatchThreads, kMinWaves) void k_match(MapView map,
                 }
             }
         }
+        LOM_STAMP(4);  // candidates scanned
         // lexicographic min over the group; d2 >= 0 so its bit pattern orders like the value
         unsigned long long keyv = ((unsigned long long)__float_as_uint(best) << 32) | best_c;
 #pragma unroll
@@ -225,6 +263,7 @@ __global__ __launch_bounds__(kMatchThreads, kMinWaves) void k_match(MapView map,
         const int w_lane = valid ? (int)(w_c % G) : 0;  // the lane that scanned the winner
         const uint32_t w_idx = __shfl(best_idx, w_lane, G);
         const float w_px = __shfl(bpx, w_lane, G), w_py = __shfl(bpy, w_lane, G), w_pz = __shfl(bpz, w_lane, G);
+        LOM_STAMP(5);  // group minimum known
         if (gl == 0) {
             int32_t idx = -1;
             float o0 = 0.f, o1 = 0.f, o2 = 0.f, n0 = 0.f, n1 = 0.f, n2 = 0.f;
@@ -251,23 +290,20 @@ __global__ __launch_bounds__(kMatchThreads, kMinWaves) void k_match(MapView map,
                 st.pad = 0;
                 out_stat[q] = st;
             }
-            acc_cand += n_cand;
-            acc_occ += n_occ;
-            acc_valid += valid ? 1 : 0;
-            acc_scanned += T;  // candidates actually read (after the exact pruning)
+            atomicAdd(&s_cnt[grp][0], valid ? 1u : 0u);
+            atomicAdd(&s_cnt[grp][1], n_cand);
+            atomicAdd(&s_cnt[grp][2], n_occ);
+            atomicAdd(&s_cnt[grp][3], T);  // candidates actually read (after the exact pruning)
         }
+        LOM_STAMP(6);  // winner's normal loaded, record stored
+        stamper.first_done();
         // the LDS tables are rewritten next iteration: all reads above are complete for this wave
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
+    stamper.flush(stamps);
     // per-block counters, summed in fixed order by k_finish (no same-address atomics:
     // one word saturates at ~88 atomics/us, MI355X_MICROARCH.md "dequeue")
-    if (gl == 0) {
-        s_cnt[grp][0] = acc_valid;
-        s_cnt[grp][1] = acc_cand;
-        s_cnt[grp][2] = acc_occ;
-        s_cnt[grp][3] = acc_scanned;
-    }
     __syncthreads();
     if (threadIdx.x < 4) {
         uint32_t v = 0;
@@ -963,6 +999,34 @@ int lom_match_align_device(lom_map *m, const float *d_src, size_t n, size_t stri
     LOM_HIP(m, hipSetDevice(m->device));
     m->last_error.clear();
     return align_device(m, (const char *)d_src, n, stride, guess_t, guess_q, out_t, out_q, stats);
+}
+
+// diagnostic: per-workgroup phase stamps of one correspondence launch (shader clock ticks)
+int lom_debug_match_stamps(lom_map *m, const float *d_src, size_t n, size_t stride, const float t[3],
+                           const float q[4], float max_dist, unsigned long long *stamps_out, size_t cap_blocks,
+                           uint32_t *n_blocks_out)
+{
+    if (!m || !d_src || !n || !t || !q || !stamps_out || !n_blocks_out) return LOM_ERR_ARG;
+    LOM_HIP(m, hipSetDevice(m->device));
+    int rc = scan_buffers(m, (uint32_t)n, false);
+    if (rc != LOM_OK) return rc;
+    server_stop(m);
+    const uint32_t nb = match_grid((uint32_t)n);
+    if (nb > cap_blocks) return LOM_ERR_ARG;
+    unsigned long long *d_st = nullptr;
+    LOM_HIP(m, hipMalloc(&d_st, (size_t)nb * 64));
+    PoseArgs P;
+    pose_args(t, q, max_dist, P);
+    for (int rep = 0; rep < 3; rep++)  // the last launch's stamps are kept (warm caches, like an align)
+        hipLaunchKernelGGL((k_match<kMatchG, 1, 8, true>), dim3(nb), dim3(kMatchThreads), 0, m->stream, view_of(m),
+                           (const char *)d_src, stride, (uint32_t)n, P, (int32_t *)m->scan_idx.p,
+                           (MatchRec *)m->scan_on.p, (QStat *)nullptr, d_block_counters(m), d_st);
+    hipError_t e = hipMemcpyAsync(stamps_out, d_st, (size_t)nb * 64, hipMemcpyDeviceToHost, m->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(m->stream);
+    (void)hipFree(d_st);
+    if (e != hipSuccess) return set_error(m, LOM_ERR_HIP, "stamp readback", e);
+    *n_blocks_out = nb;
+    return LOM_OK;
 }
 
 int lom_match_align_repeat(lom_map *m, const float *d_src, size_t n, size_t stride, const float guess_t[3],
