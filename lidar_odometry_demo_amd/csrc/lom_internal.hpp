@@ -52,6 +52,17 @@ __device__ inline bool voxel_index(float x, float voxel_size, int &out)
     return true;
 }
 
+// Same value, cheaper when the voxel size is a power of two (the reference's 0.5 / 1.0 / 0.25):
+// x * 2^-k IS the correctly rounded quotient x / 2^k (an exact scaling; where it would go
+// subnormal both truncate to 0).  inv == 0 selects the IEEE division.
+__device__ inline bool voxel_index_fast(float x, float voxel_size, float inv, int &out)
+{
+    const float f = (inv != 0.f) ? x * inv : __fdiv_rn(x, voxel_size);
+    if (!(f > -kIdxLimit && f < kIdxLimit)) return false;  // also NaN
+    out = (int)f;
+    return true;
+}
+
 struct MapView {
     const Slot *table;
     uint32_t mask;   // capacity - 1
@@ -60,6 +71,7 @@ struct MapView {
     const float *nrm;  // [slab][K][3]
     uint32_t K;
     float voxel_size;
+    float inv_voxel_size;  // 1 / voxel_size when that is exact (power of two), else 0
 };
 
 // pose as the kernels consume it

@@ -70,15 +70,73 @@ struct __attribute__((aligned(8))) QStat {
 //              then the lexicographic minimum of (sq_dist, candidate ordinal) over
 //              the group == "first encountered wins" of voxel_grid.h:183-191.
 // ---------------------------------------------------------------------------
-__device__ inline float axis_gap(float q, int i, float vs)
+// Pruning bound along one axis, once per query: squared lower bounds of |q - x| over the
+// coordinates x of the neighbour voxels i-1 (gm2) and i+1 (gp2).  Coordinates with
+// (int)(x / vs) == j lie in [lo_j, hi_j] (truncation: index 0 is double width), so voxel
+// i+1 starts at (i >= 0 ? i+1 : i) * vs and voxel i-1 ends at (i <= 0 ? i-1 : i) * vs.
+__device__ __forceinline__ void axis_gaps(float q, int i, float vs, float &gm2, float &gp2)
 {
-    // coordinates x with (int)(x / vs) == i lie in [lo, hi] (truncation: index 0 is
-    // double width); returns a lower bound of |q - x| over that range
-    const float lo = (i > 0) ? (float)i * vs : (float)(i - 1) * vs;
-    const float hi = (i < 0) ? (float)i * vs : (float)(i + 1) * vs;
-    const float g = fmaxf(fmaxf(lo - q, q - hi), 0.f);
+    const float fi = (float)i;
+    const float face_p = ((i >= 0) ? fi + 1.f : fi) * vs;
+    const float face_m = ((i <= 0) ? fi - 1.f : fi) * vs;
     // slack for the f32 rounding of x / vs at the voxel faces and of the distance itself
-    return fmaxf(g - (1e-4f * vs + 1e-6f * fabsf(q)), 0.f);
+    const float slack = 1e-4f * vs + 1e-6f * fabsf(q);
+    const float gp = fmaxf((face_p - q) - slack, 0.f);
+    const float gm = fmaxf((q - face_m) - slack, 0.f);
+    gm2 = gm * gm;
+    gp2 = gp * gp;
+}
+
+// One query group == one 16-lane DPP row: shifts, butterflies and mirrors inside the row are
+// VALU operand modifiers (no LDS crossbar trip, no index registers).  Lanes shifted in from
+// outside the row read 0.  Every lane of a row is active wherever these are used.
+template <int kCtrl>
+__device__ __forceinline__ uint32_t row_dpp(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, kCtrl, 0xF, 0xF, true);
+}
+constexpr int kDppXor1 = 0xB1, kDppXor2 = 0x4E, kDppHalfMirror = 0x141, kDppMirror = 0x140;
+__device__ __forceinline__ uint32_t row_scan_inclusive(uint32_t v)
+{
+    v += row_dpp<0x111>(v);  // row_shr:1
+    v += row_dpp<0x112>(v);  // row_shr:2
+    v += row_dpp<0x114>(v);  // row_shr:4
+    v += row_dpp<0x118>(v);  // row_shr:8
+    return v;
+}
+__device__ __forceinline__ uint32_t row_sum(uint32_t v)
+{
+    v += row_dpp<kDppXor1>(v);
+    v += row_dpp<kDppXor2>(v);
+    v += row_dpp<kDppHalfMirror>(v);  // pairs the two quads of a half
+    v += row_dpp<kDppMirror>(v);      // pairs the two halves
+    return v;
+}
+template <int kCtrl>
+__device__ __forceinline__ unsigned long long row_min_step(unsigned long long k)
+{
+    const unsigned long long o =
+        ((unsigned long long)row_dpp<kCtrl>((uint32_t)(k >> 32)) << 32) | row_dpp<kCtrl>((uint32_t)k);
+    return o < k ? o : k;
+}
+// lane 15 of the row, to every lane of the row (ds_swizzle bit mode: and 0x10, or 0x0F)
+__device__ __forceinline__ uint32_t row_last(uint32_t v) { return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x1F0); }
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+// Two 16-byte slot loads in flight together, each ONE dwordx4 (the compiler otherwise splits a
+// slot into a key load and a dependent count/slab load: two round trips per hit).
+__device__ __forceinline__ void load_slots2(const Slot *a, const Slot *b, u32x4 &ra, u32x4 &rb)
+{
+    asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %3, off\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(ra), "=&v"(rb)
+                 : "v"(a), "v"(b)
+                 : "memory");
+}
+__device__ __forceinline__ u32x4 load_slot(const Slot *a)
+{
+    u32x4 r;
+    asm volatile("global_load_dwordx4 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=&v"(r) : "v"(a) : "memory");
+    return r;
 }
 
 // kStamp = true is a diagnostic build (lom_debug_match_stamps): thread 0 of every workgroup records
@@ -118,92 +176,98 @@ __global__ __launch_bounds__(kMatchThreads, kMinWaves) void k_match(MapView map,
                                                          uint32_t *__restrict__ block_counters,
                                                          unsigned long long *__restrict__ stamps = nullptr)
 {
+    static_assert(G == 16 && kU == 1, "one query per 16-lane DPP row");
     Stamper<kStamp> stamper;
     LOM_STAMP(0);
     constexpr int kGroups = kMatchThreads / G;
-    constexpr int kSets = (27 + G - 1) / G;
+    constexpr int kSets = 2;                  // neighbours b = gl (set 0) and 16 + gl (set 1) < 27
     __shared__ uint32_t s_pref[kGroups][32];  // inclusive prefix of scanned counts, scan order; padded with total
     __shared__ uint32_t s_base[kGroups][32];  // slab * K - exclusive prefix: point index = s_base[b] + c
     __shared__ uint32_t s_cnt[kGroups][4];
     const int gl = threadIdx.x % G;
     const int grp = threadIdx.x / G;
     const uint32_t groups_total = gridDim.x * kGroups;
-    // per-group counters live in LDS (one ds_add per counter and query by the group's first lane):
+    // per-group counters live in LDS (one ds_add per counter and query by the writing lane):
     // four fewer live registers keep the kernel at 64 VGPRs without spilling
     if (gl < 4) s_cnt[grp][gl] = 0u;
+    const float prune_sq = P.max_sq * 1.0001f;
 
     for (uint32_t q = blockIdx.x * kGroups + grp; q < n; q += groups_total) {
         const float *sp = reinterpret_cast<const float *>(src + (size_t)q * stride);
-        const double p0 = (double)sp[0], p1 = (double)sp[1], p2 = (double)sp[2];
+        const float s0 = sp[0], s1 = sp[1], s2 = sp[2];
+        const double p0 = (double)s0, p1 = (double)s1, p2 = (double)s2;
         // voxel_grid.h:220-223: R*p + t in f64 (Eigen order a0 + (a1 + a2)), cast to f32
         const float qx = (float)((P.R[0] * p0 + (P.R[1] * p1 + P.R[2] * p2)) + P.t[0]);
         const float qy = (float)((P.R[3] * p0 + (P.R[4] * p1 + P.R[5] * p2)) + P.t[1]);
         const float qz = (float)((P.R[6] * p0 + (P.R[7] * p1 + P.R[8] * p2)) + P.t[2]);
         int ix = 0, iy = 0, iz = 0;
-        const bool inr = voxel_index(qx, map.voxel_size, ix) && voxel_index(qy, map.voxel_size, iy) &&
-                         voxel_index(qz, map.voxel_size, iz);
+        const bool inr = voxel_index_fast(qx, map.voxel_size, map.inv_voxel_size, ix) &&
+                         voxel_index_fast(qy, map.voxel_size, map.inv_voxel_size, iy) &&
+                         voxel_index_fast(qz, map.voxel_size, map.inv_voxel_size, iz);
+        float gmx, gpx, gmy, gpy, gmz, gpz;
+        axis_gaps(qx, ix, map.voxel_size, gmx, gpx);
+        axis_gaps(qy, iy, map.voxel_size, gmy, gpy);
+        axis_gaps(qz, iz, map.voxel_size, gmz, gpz);
         LOM_STAMP(1);  // source point loaded and transformed
+        // ---- probe: both sets' first slots in flight together ----
+        unsigned long long key[kSets];
+        uint32_t h[kSets];
+        bool act[kSets];
+        float lower[kSets];
+#pragma unroll
+        for (int s = 0; s < kSets; s++) {
+            const int b = gl + s * G;
+            const int dx = b / 9 - 1, dy = (b / 3) % 3 - 1, dz = b % 3 - 1;
+            const int nx = ix + dx, ny = iy + dy, nz = iz + dz;
+            // stored indices lie in (-2^20, 2^20); anything outside cannot exist
+            act[s] = inr && b < 27 && nx > -kIdxBias && nx < kIdxBias && ny > -kIdxBias && ny < kIdxBias &&
+                     nz > -kIdxBias && nz < kIdxBias;
+            key[s] = act[s] ? pack_key(nx, ny, nz) : 0ull;
+            h[s] = act[s] ? (hash_key(key[s], map.shift) & map.mask) : 0u;
+            const float sx = dx < 0 ? gmx : (dx > 0 ? gpx : 0.f);
+            const float sy = dy < 0 ? gmy : (dy > 0 ? gpy : 0.f);
+            const float sz = dz < 0 ? gmz : (dz > 0 ? gpz : 0.f);
+            lower[s] = sx + (sy + sz);
+        }
+        u32x4 raw[kSets];
+        load_slots2(map.table + h[0], map.table + h[1], raw[0], raw[1]);
         uint32_t cnt[kSets], scan_cnt[kSets], slab[kSets];
 #pragma unroll
         for (int s = 0; s < kSets; s++) {
             cnt[s] = 0;
-            scan_cnt[s] = 0;
             slab[s] = 0;
-            const int b = gl + s * G;
-            if (inr && b < 27) {
-                const int nx = ix + b / 9 - 1, ny = iy + (b / 3) % 3 - 1, nz = iz + b % 3 - 1;
-                // stored indices lie in (-2^20, 2^20); anything outside cannot exist
-                if (nx > -kIdxBias && nx < kIdxBias && ny > -kIdxBias && ny < kIdxBias && nz > -kIdxBias &&
-                    nz < kIdxBias) {
-                    const unsigned long long key = pack_key(nx, ny, nz);
-                    uint32_t h = hash_key(key, map.shift) & map.mask;
-                    for (uint32_t probe = 0; probe <= map.mask; probe++) {
-                        const uint4 raw = *reinterpret_cast<const uint4 *>(&map.table[h]);
-                        const unsigned long long k = ((unsigned long long)raw.y << 32) | raw.x;
-                        if (k == key) {
-                            cnt[s] = raw.z;
-                            slab[s] = raw.w;
-                            break;
-                        }
-                        if (k == kEmptyKey) break;
-                        h = (h + 1) & map.mask;
+            if (act[s]) {
+                u32x4 r = raw[s];
+                uint32_t hh = h[s];
+                for (uint32_t probe = 0; probe <= map.mask; probe++) {
+                    const unsigned long long k = ((unsigned long long)r.y << 32) | r.x;
+                    if (k == key[s]) {
+                        cnt[s] = r.z;
+                        slab[s] = r.w;
+                        break;
                     }
-                    if (cnt[s]) {
-                        const float gx = axis_gap(qx, nx, map.voxel_size);
-                        const float gy = axis_gap(qy, ny, map.voxel_size);
-                        const float gz = axis_gap(qz, nz, map.voxel_size);
-                        const float lower = gx * gx + (gy * gy + gz * gz);
-                        scan_cnt[s] = (lower > P.max_sq * 1.0001f) ? 0u : cnt[s];
-                    }
+                    if (k == kEmptyKey) break;
+                    hh = (hh + 1) & map.mask;
+                    r = load_slot(map.table + hh);
                 }
             }
+            // a neighbour voxel whose nearest face is provably farther than max_dist is not read
+            scan_cnt[s] = (lower[s] > prune_sq) ? 0u : cnt[s];
         }
         LOM_STAMP(2);  // 27 slots probed
-        // group-wide prefix over the neighbours in scan order (set 0 = b < G, set 1 = b >= G)
-        uint32_t n_occ = 0, n_cand = 0, run = 0;
+        // ---- group-wide prefix over the neighbours in scan order ----
+        uint32_t tot = 0, run = 0;
 #pragma unroll
         for (int s = 0; s < kSets; s++) {
-            uint32_t inc = scan_cnt[s], all = cnt[s], occ = cnt[s] ? 1u : 0u;
-#pragma unroll
-            for (int d = 1; d < G; d <<= 1) {
-                const uint32_t o = __shfl_up(inc, d, G);
-                if (gl >= d) inc += o;
-                all += __shfl_xor(all, d, G);
-                occ += __shfl_xor(occ, d, G);
-            }
-            const uint32_t set_total = __shfl(inc, G - 1, G);
+            const uint32_t inc = row_scan_inclusive(scan_cnt[s]);
+            // occupied voxels (<= 27) above bit 26, stored points (<= 27 K, K <= 2^20) below
+            tot += row_sum(cnt[s] | (cnt[s] ? (1u << 26) : 0u));
             const int b = gl + s * G;
-            if (b < 32) {
-                s_pref[grp][b] = (b < 27) ? run + inc : 0xFFFFFFFFu;
-                s_base[grp][b] = slab[s] * map.K - (run + inc - scan_cnt[s]);
-            }
-            run += set_total;
-            n_cand += all;
-            n_occ += occ;
+            s_pref[grp][b] = (b < 27) ? run + inc : 0xFFFFFFFFu;
+            s_base[grp][b] = slab[s] * map.K - (run + inc - scan_cnt[s]);
+            run += row_last(inc);
         }
-        if (kSets * G < 32) {  // G = 16 covers b < 32 with two sets; other G: pad the tail
-            for (int b = kSets * G + gl; b < 32; b += G) s_pref[grp][b] = 0xFFFFFFFFu;
-        }
+        const uint32_t n_cand = tot & ((1u << 26) - 1u), n_occ = tot >> 26;
         const uint32_t T = run;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -213,78 +277,59 @@ __global__ __launch_bounds__(kMatchThreads, kMinWaves) void k_match(MapView map,
         float best = INFINITY, bpx = 0.f, bpy = 0.f, bpz = 0.f;
         uint32_t best_c = 0xFFFFFFFFu, best_idx = 0;
         const uint32_t *pref = s_pref[grp];
-        // four candidates per lane and trip: their loads are issued together (one memory round
-        // trip for T <= 4G), then compared in candidate order (strict minimum, first wins)
-        for (uint32_t c0 = gl; c0 < T; c0 += kU * G) {
-            uint32_t pi[kU];
-            float ax[kU], ay[kU], az[kU];
-#pragma unroll
-            for (int u = 0; u < kU; u++) {
-                const uint32_t c = c0 + u * G;
-                const uint32_t cc = c < T ? c : T - 1;  // clamp: a valid address, result discarded below
-                // smallest b with pref[b] > cc
-                uint32_t b = 0;
-                b += (pref[b + 15] <= cc) ? 16u : 0u;
-                b += (pref[b + 7] <= cc) ? 8u : 0u;
-                b += (pref[b + 3] <= cc) ? 4u : 0u;
-                b += (pref[b + 1] <= cc) ? 2u : 0u;
-                b += (pref[b] <= cc) ? 1u : 0u;
-                pi[u] = s_base[grp][b] + cc;
-                const float *vp = map.pts + (size_t)pi[u] * 3;
-                ax[u] = vp[0];
-                ay[u] = vp[1];
-                az[u] = vp[2];
-            }
-#pragma unroll
-            for (int u = 0; u < kU; u++) {
-                const uint32_t c = c0 + u * G;
-                const float dx = qx - ax[u], dy = qy - ay[u], dz = qz - az[u];
-                const float d2 = dx * dx + (dy * dy + dz * dz);   // voxel_grid.h:184 f32 squaredNorm
-                if (c < T && d2 < P.max_sq && d2 < best) {        // :186-187 strict
-                    best = d2;
-                    best_c = c;
-                    best_idx = pi[u];
-                    bpx = ax[u];
-                    bpy = ay[u];
-                    bpz = az[u];
-                }
+        // lane l takes candidates l, l + 16, ... of the flattened sequence (scan order: strict
+        // minimum per lane, first wins)
+        for (uint32_t c = gl; c < T; c += G) {
+            // smallest b with pref[b] > c
+            uint32_t b = 0;
+            b += (pref[b + 15] <= c) ? 16u : 0u;
+            b += (pref[b + 7] <= c) ? 8u : 0u;
+            b += (pref[b + 3] <= c) ? 4u : 0u;
+            b += (pref[b + 1] <= c) ? 2u : 0u;
+            b += (pref[b] <= c) ? 1u : 0u;
+            const uint32_t pi = s_base[grp][b] + c;
+            const float *vp = map.pts + (size_t)pi * 3;
+            const float ax = vp[0], ay = vp[1], az = vp[2];
+            const float dx = qx - ax, dy = qy - ay, dz = qz - az;
+            const float d2 = dx * dx + (dy * dy + dz * dz);  // voxel_grid.h:184 f32 squaredNorm
+            if (d2 < P.max_sq && d2 < best) {                // :186-187 strict
+                best = d2;
+                best_c = c;
+                best_idx = pi;
+                bpx = ax;
+                bpy = ay;
+                bpz = az;
             }
         }
         LOM_STAMP(4);  // candidates scanned
         // lexicographic min over the group; d2 >= 0 so its bit pattern orders like the value
         unsigned long long keyv = ((unsigned long long)__float_as_uint(best) << 32) | best_c;
-#pragma unroll
-        for (int d = G / 2; d >= 1; d >>= 1) {
-            const unsigned long long o = __shfl_xor(keyv, d, G);
-            keyv = o < keyv ? o : keyv;
-        }
+        keyv = row_min_step<kDppXor1>(keyv);
+        keyv = row_min_step<kDppXor2>(keyv);
+        keyv = row_min_step<kDppHalfMirror>(keyv);
+        keyv = row_min_step<kDppMirror>(keyv);
         const uint32_t w_c = (uint32_t)keyv;
         const bool valid = w_c != 0xFFFFFFFFu;
-        const int w_lane = valid ? (int)(w_c % G) : 0;  // the lane that scanned the winner
-        const uint32_t w_idx = __shfl(best_idx, w_lane, G);
-        const float w_px = __shfl(bpx, w_lane, G), w_py = __shfl(bpy, w_lane, G), w_pz = __shfl(bpz, w_lane, G);
         LOM_STAMP(5);  // group minimum known
-        if (gl == 0) {
+        // the lane that scanned the winner holds its point in registers and writes the record
+        if (valid ? (best_c == w_c) : (gl == 0)) {
             int32_t idx = -1;
-            float o0 = 0.f, o1 = 0.f, o2 = 0.f, n0 = 0.f, n1 = 0.f, n2 = 0.f;
+            float n0 = 0.f, n1 = 0.f, n2 = 0.f;
             if (valid) {
-                const size_t pi = w_idx;
+                const size_t pi = best_idx;
                 idx = (int32_t)pi;
-                o0 = w_px;  // voxel_grid.h:197-198 (already in registers from the scan)
-                o1 = w_py;
-                o2 = w_pz;
-                n0 = map.nrm[pi * 3 + 0];
+                n0 = map.nrm[pi * 3 + 0];  // voxel_grid.h:197-198
                 n1 = map.nrm[pi * 3 + 1];
                 n2 = map.nrm[pi * 3 + 2];
             }
             out_idx[q] = idx;
             float4 *rec = reinterpret_cast<float4 *>(out_rec + q);
-            rec[0] = make_float4(sp[0], sp[1], sp[2], valid ? 1.f : 0.f);
-            rec[1] = make_float4(o0, o1, o2, n0);
+            rec[0] = make_float4(s0, s1, s2, valid ? 1.f : 0.f);
+            rec[1] = make_float4(bpx, bpy, bpz, n0);
             rec[2] = make_float4(n1, n2, 0.f, 0.f);
             if (out_stat) {
                 QStat st;
-                st.sq_dist = valid ? __uint_as_float((uint32_t)(keyv >> 32)) : 0.f;
+                st.sq_dist = valid ? best : 0.f;
                 st.n_cand = n_cand;
                 st.n_occ = n_occ;
                 st.pad = 0;

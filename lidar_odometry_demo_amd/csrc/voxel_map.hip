@@ -21,6 +21,7 @@
 // round like the reference's (plain -O3 x86-64 build, no FMA contraction).
 #include <algorithm>
 #include <cctype>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -79,6 +80,10 @@ MapView view_of(const lom_map *m)
     v.nrm = m->d_nrm;
     v.K = m->K;
     v.voxel_size = m->voxel_size;
+    int e = 0;
+    const float inv = 1.0f / m->voxel_size;
+    // power of two with a normal reciprocal: scaling by inv is exact
+    v.inv_voxel_size = (std::frexp(m->voxel_size, &e) == 0.5f && std::isnormal(inv)) ? inv : 0.f;
     return v;
 }
 

@@ -21,10 +21,11 @@ for name, (nb, naz, nmap) in {"C2": (16, 1800, 500_000), "C3": (64, 2048, 2_000_
     d = torch.from_numpy(scan).to("cuda:0")
     torch.cuda.synchronize()
     cases[name] = (g, d)
-for rep in range(3):
+REPS = int(os.environ.get("LOM_AB_REPS", "100"))
+for rep in range(int(os.environ.get("LOM_AB_ROUNDS", "3"))):
     for v in ("built-in",):
         row = []
         for name, (g, d) in cases.items():
-            us, by, rq = g.profileMatch(d.data_ptr(), d.shape[0], lom.Pose3D(), 0.3, reps=100)
+            us, by, rq = g.profileMatch(d.data_ptr(), d.shape[0], lom.Pose3D(), 0.3, reps=REPS)
             row.append(f"{name} {us:7.2f} us alg {by / us / 1e3:6.0f} GB/s req {rq / us / 1e3:6.0f} GB/s")
         print(f"variant {v}: " + " | ".join(row), flush=True)
