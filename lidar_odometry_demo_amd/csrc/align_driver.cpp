@@ -9,82 +9,19 @@
 // stacked least-squares system by QR over all residual rows, here the same
 // step comes from (S A S + D^2) y = S g on the reduced system.  Both are the
 // minimiser of the same damped quadratic; poses agree far inside the 1e-4 m /
-// 1e-4 rad bar (tests/test_align_driver.py, tests/test_gpu_parity.py).
+// 1e-4 rad bar (tests/test_host_exchange.py, tests/test_gpu_parity.py).  The policy itself lives in
+// lm_core.hpp, shared with the device-resident loop.
 #include <cfloat>
 #include <cmath>
 #include <cstring>
 
 #include "../../include/lidar_odometry_amd.h"
+#include "lm_core.hpp"
 #include "pose_math.hpp"
 
 namespace {
 
-constexpr double kPriorW = 10.0;  // cloud_matcher.cpp:153  diag(0.1,0.1,0.1).inverse()
-
-struct Normal {
-    double A[6][6];
-    double g[6];
-    double cost;
-};
-
-// sums (device layout, prior excluded) -> full normal equations incl. the
-// NormalPrior on translation (residual 10 (t - t_guess), Jacobian 10 I).
-void assemble(const double s[LOM_NSUMS], const double x[7], const double prior_b[3], Normal &n)
-{
-    int k = 0;
-    for (int a = 0; a < 6; a++)
-        for (int b = a; b < 6; b++) {
-            n.A[a][b] = s[k];
-            n.A[b][a] = s[k];
-            k++;
-        }
-    for (int a = 0; a < 6; a++) n.g[a] = s[21 + a];
-    n.cost = s[27];
-    for (int a = 0; a < 3; a++) {
-        const double r = kPriorW * (x[4 + a] - prior_b[a]);
-        n.A[3 + a][3 + a] += kPriorW * kPriorW;
-        n.g[3 + a] += kPriorW * r;
-        n.cost += 0.5 * r * r;
-    }
-}
-
-bool cholesky_solve6(const double M[6][6], const double b[6], double y[6])
-{
-    double L[6][6] = {};
-    for (int i = 0; i < 6; i++) {
-        for (int j = 0; j <= i; j++) {
-            double s = M[i][j];
-            for (int k = 0; k < j; k++) s -= L[i][k] * L[j][k];
-            if (i == j) {
-                if (!(s > 0.0)) return false;
-                L[i][i] = std::sqrt(s);
-            } else {
-                L[i][j] = s / L[j][j];
-            }
-        }
-    }
-    double z[6];
-    for (int i = 0; i < 6; i++) {
-        double s = b[i];
-        for (int k = 0; k < i; k++) s -= L[i][k] * z[k];
-        z[i] = s / L[i][i];
-    }
-    for (int i = 5; i >= 0; i--) {
-        double s = z[i];
-        for (int k = i + 1; k < 6; k++) s -= L[k][i] * y[k];
-        y[i] = s / L[i][i];
-    }
-    for (int i = 0; i < 6; i++)
-        if (!std::isfinite(y[i])) return false;
-    return true;
-}
-
-struct LmResult {
-    int recorded = 1;  // iteration 0
-    int evaluations = 0;
-    double last_step_norm = 0.0;
-    double cost = 0.0;
-};
+using lom::LmState;
 
 struct Evaluator {
     const lom_align_hooks *h;
@@ -102,111 +39,18 @@ struct Evaluator {
     }
 };
 
-// Ceres TrustRegionMinimizer + LevenbergMarquardtStrategy, library defaults
-// except max_num_iterations = 4, function_tolerance = 1e-5
-// (cloud_matcher.cpp:109-112).  `first` holds the sums of iteration 0.
-int lm_solve(Evaluator &ev, const double first[LOM_NSUMS], double x[7], const double prior_b[3],
-             LmResult &out)
+// one ceres::Solve (cloud_matcher.cpp:157-158): lm_core.hpp's state machine, fed by the hooks.
+// `first` holds the sums of iteration 0.
+int lm_solve(Evaluator &ev, const double first[LOM_NSUMS], double x[7], const double prior_b[3], LmState &S)
 {
-    const int max_iter = 4;
-    const double ftol = 1e-5, gtol = 1e-10, ptol = 1e-8;
-    const double min_rel_dec = 1e-3, min_diag = 1e-6, max_diag = 1e32, max_radius = 1e16;
-    double radius = 1e4, decrease_factor = 2.0;
-    bool reuse_diag = false;
-    double scale[6], diag[6];
-    Normal N;
-    assemble(first, x, prior_b, N);
-    // Jacobi scaling, computed once at iteration 0: 1 / (1 + ||column||)
-    for (int c = 0; c < 6; c++) scale[c] = 1.0 / (1.0 + std::sqrt(N.A[c][c]));
-    auto gmax_of = [](const Normal &n) {
-        double m = 0.0;
-        for (int c = 0; c < 6; c++) m = std::fmax(m, std::fabs(n.g[c]));
-        return m;
-    };
-    auto norm7 = [](const double *v) {
-        double s = 0.0;
-        for (int i = 0; i < 7; i++) s += v[i] * v[i];
-        return std::sqrt(s);
-    };
-    double x_norm = norm7(x);
-    out.cost = N.cost;
-    if (gmax_of(N) <= gtol) return LOM_OK;
-    int invalid_run = 0;
-    for (int iter = 1; iter <= max_iter; iter++) {
-        double As[6][6], gs[6];
-        for (int a = 0; a < 6; a++) {
-            gs[a] = N.g[a] * scale[a];
-            for (int b = 0; b < 6; b++) As[a][b] = N.A[a][b] * scale[a] * scale[b];
-        }
-        if (!reuse_diag)
-            for (int c = 0; c < 6; c++) diag[c] = std::fmin(std::fmax(As[c][c], min_diag), max_diag);
-        double M[6][6];
-        std::memcpy(M, As, sizeof M);
-        for (int c = 0; c < 6; c++) M[c][c] += diag[c] / radius;
-        double y[6], step[6];
-        const bool ok = cholesky_solve6(M, gs, y);
-        reuse_diag = true;
-        double model_change = 0.0;
-        if (ok) {
-            for (int c = 0; c < 6; c++) step[c] = -y[c];
-            // -(J s).(r + J s / 2) = -g.s - s^T A s / 2   (scaled space)
-            double gsdot = 0.0, quad = 0.0;
-            for (int a = 0; a < 6; a++) {
-                gsdot += gs[a] * step[a];
-                double row = 0.0;
-                for (int b = 0; b < 6; b++) row += As[a][b] * step[b];
-                quad += step[a] * row;
-            }
-            model_change = -gsdot - 0.5 * quad;
-        }
-        if (!ok || !(model_change > 0.0)) {
-            if (++invalid_run >= 5) break;
-            radius /= decrease_factor;
-            decrease_factor *= 2.0;
-            out.recorded++;
-            out.last_step_norm = 0.0;
-            continue;
-        }
-        invalid_run = 0;
-        double delta[6], cand[7];
-        for (int c = 0; c < 6; c++) delta[c] = step[c] * scale[c];
-        lom::manifold_plus(x, delta, cand);
-        // one evaluation at the candidate serves the accept test (cost) and, if
-        // accepted, the next iteration (Jacobian) -- the reference evaluates the
-        // cost first and the Jacobian after acceptance; same numbers, one pass.
+    int action = lom::lm_begin(S, first, x, prior_b);
+    while (action == lom::LM_EVAL) {
         double sums[LOM_NSUMS];
-        int rc = ev.evaluate(false, nullptr, nullptr, cand, sums);
+        const int rc = ev.evaluate(false, nullptr, nullptr, S.cand, sums);
         if (rc != LOM_OK) return rc;
-        out.evaluations++;
-        Normal C;
-        assemble(sums, cand, prior_b, C);
-        double d7[7];
-        for (int i = 0; i < 7; i++) d7[i] = x[i] - cand[i];
-        const double sn = norm7(d7);
-        if (sn <= ptol * (x_norm + ptol)) break;           // parameter tolerance: not recorded
-        const double cost_change = N.cost - C.cost;
-        if (std::fabs(cost_change) <= ftol * N.cost) break;  // function tolerance: not recorded
-        const double rel_dec = cost_change / model_change;
-        if (rel_dec > min_rel_dec) {
-            std::memcpy(x, cand, sizeof cand);
-            x_norm = norm7(x);
-            N = C;
-            const double d3 = 2.0 * rel_dec - 1.0;
-            radius = radius / std::fmax(1.0 / 3.0, 1.0 - d3 * d3 * d3);
-            radius = std::fmin(max_radius, radius);
-            decrease_factor = 2.0;
-            reuse_diag = false;
-        } else {
-            radius /= decrease_factor;
-            decrease_factor *= 2.0;
-            reuse_diag = true;
-        }
-        out.recorded++;
-        out.last_step_norm = sn;
-        out.cost = N.cost;
-        if (gmax_of(N) <= gtol) break;
+        action = lom::lm_feed(S, sums);
     }
-    out.cost = N.cost;
+    for (int i = 0; i < 7; i++) x[i] = S.x[i];
     return LOM_OK;
 }
 
@@ -278,8 +122,7 @@ int lom_align_with_hooks(const lom_align_hooks *hooks, const float guess_t[3], c
         double sums[LOM_NSUMS];
         int rc = ev.evaluate(true, pt, pq, x, sums);                 // :138-139 + iteration 0
         if (rc != LOM_OK) return rc;
-        LmResult lr;
-        lr.evaluations = 1;
+        LmState lr;
         rc = lm_solve(ev, sums, x, prior_b, lr);                     // :157-158
         if (rc != LOM_OK) return rc;
         st.outer_iterations = i + 1;

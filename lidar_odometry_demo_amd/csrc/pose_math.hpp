@@ -1,21 +1,28 @@
 // f32 SE(3) algebra of the boundary type Pose3D (reference src/pose_3d.h:10-59)
-// and the f64 manifold step used by the host solver.  Host code; compiled with
-// -ffp-contract=off so the f32 rotation matrix that feeds the device search is
-// rounded exactly like the reference's Eigen expressions on x86-64.
+// and the f64 manifold step used by the solver.  Host and device code (the device-resident
+// Levenberg-Marquardt loop uses the same functions); compiled with -ffp-contract=off so the
+// f32 rotation matrix that feeds the device search is rounded exactly like the reference's
+// Eigen expressions on x86-64.
 #pragma once
 #include <cmath>
 
 #include "../../include/lidar_odometry_amd.h"
 
+#if defined(__HIPCC__)
+#define LOM_HD __host__ __device__ inline
+#else
+#define LOM_HD inline
+#endif
+
 namespace lom {
 
 // Eigen reduces fixed-size-3 expressions as a0 + (a1 + a2).
-inline float sum3(float a, float b, float c) { return a + (b + c); }
-inline double sum3(double a, double b, double c) { return a + (b + c); }
+LOM_HD float sum3(float a, float b, float c) { return a + (b + c); }
+LOM_HD double sum3(double a, double b, double c) { return a + (b + c); }
 
 // Quaternion * vector as Eigen evaluates it: v + w*2(u x v) + u x 2(u x v).
 template <typename T>
-inline void quat_rotate(const T q[4], const T v[3], T out[3])
+LOM_HD void quat_rotate(const T q[4], const T v[3], T out[3])
 {
     const T w = q[0], x = q[1], y = q[2], z = q[3];
     T a0 = y * v[2] - z * v[1];
@@ -33,7 +40,7 @@ inline void quat_rotate(const T q[4], const T v[3], T out[3])
 }
 
 template <typename T>
-inline void quat_mul(const T a[4], const T b[4], T out[4])
+LOM_HD void quat_mul(const T a[4], const T b[4], T out[4])
 {
     const T r0 = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
     const T r1 = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
@@ -46,7 +53,7 @@ inline void quat_mul(const T a[4], const T b[4], T out[4])
 }
 
 // Quaternionf::toRotationMatrix (pose_3d.h:43), row-major.
-inline void rotation_matrix(const float q[4], float R[9])
+LOM_HD void rotation_matrix(const float q[4], float R[9])
 {
     const float w = q[0], x = q[1], y = q[2], z = q[3];
     const float tx = 2.f * x, ty = 2.f * y, tz = 2.f * z;
@@ -93,14 +100,14 @@ inline void pose_inverse(const lom_pose &a, lom_pose &out)
 
 // Ceres QuaternionManifold::Plus on [w,x,y,z] (delta = half-angle vector applied
 // on the left) followed by the Euclidean translation update.
-inline void manifold_plus(const double x[7], const double d[6], double out[7])
+LOM_HD void manifold_plus(const double x[7], const double d[6], double out[7])
 {
-    const double nd = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    const double nd = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
     if (nd == 0.0) {
         for (int i = 0; i < 4; i++) out[i] = x[i];
     } else {
-        const double s = std::sin(nd) / nd;
-        const double z[4] = {std::cos(nd), s * d[0], s * d[1], s * d[2]};
+        const double s = sin(nd) / nd;
+        const double z[4] = {cos(nd), s * d[0], s * d[1], s * d[2]};
         out[0] = z[0] * x[0] - z[1] * x[1] - z[2] * x[2] - z[3] * x[3];
         out[1] = z[0] * x[1] + z[1] * x[0] + z[2] * x[3] - z[3] * x[2];
         out[2] = z[0] * x[2] - z[1] * x[3] + z[2] * x[0] + z[3] * x[1];
