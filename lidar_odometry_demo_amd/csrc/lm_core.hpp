@@ -29,7 +29,7 @@ namespace lom {
 
 constexpr double kPriorW = 10.0;  // cloud_matcher.cpp:153  diag(0.1,0.1,0.1).inverse()
 
-enum { LM_DONE = 0, LM_EVAL = 1 };
+enum { LM_DONE = 0, LM_EVAL = 1, LM_PROPOSE = 2 };
 
 struct Normal {
     double A[6][6];
@@ -82,14 +82,12 @@ LOM_UNROLL
 
 LOM_HD bool lm_finite(double v) { return fabs(v) <= DBL_MAX; }  // false for NaN too
 
+// M y = b for a symmetric positive definite 6x6 M (lower triangle read).  One reciprocal per
+// column; every other "division" is a multiplication by it (divisions are the bulk of this
+// function's code and time on the GPU).
 LOM_HD bool cholesky_solve6(const double M[6][6], const double b[6], double y[6])
 {
-    double L[6][6];
-LOM_UNROLL
-    for (int i = 0; i < 6; i++) {
-LOM_UNROLL
-        for (int j = 0; j < 6; j++) L[i][j] = 0.0;
-    }
+    double L[6][6], inv[6];
     bool ok = true;
 LOM_UNROLL
     for (int i = 0; i < 6; i++) {
@@ -101,8 +99,9 @@ LOM_UNROLL
             if (i == j) {
                 if (!(s > 0.0)) ok = false;
                 L[i][i] = sqrt(s);
+                inv[i] = 1.0 / L[i][i];
             } else {
-                L[i][j] = s / L[j][j];
+                L[i][j] = s * inv[j];
             }
         }
     }
@@ -113,14 +112,14 @@ LOM_UNROLL
         double s = b[i];
 LOM_UNROLL
         for (int k = 0; k < i; k++) s -= L[i][k] * z[k];
-        z[i] = s / L[i][i];
+        z[i] = s * inv[i];
     }
 LOM_UNROLL
     for (int i = 5; i >= 0; i--) {
         double s = z[i];
 LOM_UNROLL
         for (int k = i + 1; k < 6; k++) s -= L[k][i] * y[k];
-        y[i] = s / L[i][i];
+        y[i] = s * inv[i];
     }
 LOM_UNROLL
     for (int i = 0; i < 6; i++)
@@ -165,11 +164,12 @@ LOM_UNROLL
 LOM_UNROLL
             for (int c = 0; c < 6; c++) S.diag[c] = fmin(fmax(As[c][c], kLmMinDiag), kLmMaxDiag);
         }
+        const double inv_radius = 1.0 / S.radius;
 LOM_UNROLL
         for (int a = 0; a < 6; a++) {
 LOM_UNROLL
             for (int b = 0; b < 6; b++) M[a][b] = As[a][b];
-            M[a][a] += S.diag[a] / S.radius;
+            M[a][a] += S.diag[a] * inv_radius;
         }
         double y[6], step[6];
         const bool ok = cholesky_solve6(M, gs, y);
@@ -211,8 +211,10 @@ LOM_UNROLL
     return LM_DONE;
 }
 
-// `first`: sums of the evaluation at x (iteration 0)
-LOM_HD int lm_begin(LmState &S, const double *first, const double x[7], const double prior_b[3])
+// `first`: sums of the evaluation at x (iteration 0).  The *_head functions return LM_DONE or
+// LM_PROPOSE (= call lm_propose next); the device loop calls them that way so that the solve code
+// exists once in the kernel.
+LOM_HD int lm_begin_head(LmState &S, const double *first, const double x[7], const double prior_b[3])
 {
 LOM_UNROLL
     for (int i = 0; i < 7; i++) S.x[i] = x[i];
@@ -238,13 +240,19 @@ LOM_UNROLL
     S.x_norm = lm_norm7(S.x);
     S.cost = S.N.cost;
     if (lm_gmax(S.N) <= kLmGtol) return LM_DONE;
-    return lm_propose(S);
+    return LM_PROPOSE;
+}
+
+LOM_HD int lm_begin(LmState &S, const double *first, const double x[7], const double prior_b[3])
+{
+    const int a = lm_begin_head(S, first, x, prior_b);
+    return a == LM_PROPOSE ? lm_propose(S) : a;
 }
 
 // `sums`: the evaluation at S.cand.  One evaluation at the candidate serves the accept test (cost)
 // and, if accepted, the next iteration (Jacobian) -- the reference evaluates the cost first and the
 // Jacobian after acceptance; same numbers, one pass.
-LOM_HD int lm_feed(LmState &S, const double *sums)
+LOM_HD int lm_feed_head(LmState &S, const double *sums)
 {
     S.evaluations++;
     Normal C;
@@ -278,7 +286,13 @@ LOM_UNROLL
     S.cost = S.N.cost;
     if (lm_gmax(S.N) <= kLmGtol) return LM_DONE;
     S.iter++;
-    return lm_propose(S);
+    return LM_PROPOSE;
+}
+
+LOM_HD int lm_feed(LmState &S, const double *sums)
+{
+    const int a = lm_feed_head(S, sums);
+    return a == LM_PROPOSE ? lm_propose(S) : a;
 }
 
 }  // namespace lom

@@ -86,6 +86,34 @@ struct EvalArgs {
     double t[3];
 };
 
+// Single-GPU align: the outer loop's state lives in HBM between the kernels of one align.  k_lm's
+// workgroup 0 writes it at the end of an outer iteration; the next k_match takes its pose from P,
+// the next k_lm continues from pose_t / pose_q -- the host enqueues the kernels of several outer
+// iterations without waiting for any of them.
+struct AlignState {
+    PoseArgs P;        // pose of the next correspondence search
+    float pose_t[3];   // f32 pose after the write-back (cloud_matcher.cpp:161-167)
+    float pose_q[4];
+    int32_t finished;  // converged (:169-172) or 35 iterations done: later kernels of the chain do nothing
+    int32_t error;     // a workgroup gave up waiting for the others
+    int32_t outer_done;
+    int32_t lm_iterations, evaluations;
+    int32_t pad;
+    double valid_last, valid_total, cand_total, occ_total, queries_total;
+    double final_cost, last_step_norm;
+};
+
+// what the host reads back (pinned host memory): a copy of the scalar part of AlignState, written
+// by k_lm's workgroup 0 after every outer iteration, sequence word last
+struct AlignReport {
+    unsigned long long seq;
+    int32_t finished, error, outer_done, lm_iterations, evaluations, pad;
+    float pose_t[3], pose_q[4];
+    float pad2;
+    double valid_last, valid_total, cand_total, occ_total, queries_total;
+    double final_cost, last_step_norm;
+};
+
 // ---- host-side handle ---------------------------------------------------------
 struct DeviceBuf {
     void *p = nullptr;
@@ -147,6 +175,11 @@ struct lom_map {
     void *h_cmd = nullptr, *d_cmd = nullptr;
     bool server_alive = false;
     bool eval_attr_set = false;
+    // device-resident outer loop (single GPU): state in HBM, exchange records of k_lm's workgroups,
+    // report in pinned host memory
+    lom::DeviceBuf align_state, xrec;
+    void *h_report = nullptr, *d_report = nullptr;
+    unsigned long long report_seq = 0, lm_seq = 0;
     double last_counters[4] = {0, 0, 0, 0};  // valid, cand, occ, queries of the last k_match
 
     bool profiling = false;

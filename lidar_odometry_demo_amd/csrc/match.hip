@@ -25,6 +25,7 @@
 #include <ctime>
 #include <vector>
 
+#include "lm_core.hpp"
 #include "lom_internal.hpp"
 #include "pose_math.hpp"
 
@@ -168,15 +169,39 @@ struct Stamper<true> {
 };
 #define LOM_STAMP(i) stamper.mark(i)
 
-template <int G, int kU, int kMinWaves, bool kStamp = false>
+// kChained: the pose comes from the AlignState a previous k_lm left in HBM (read through the
+// constant address space: scalar loads, like kernel arguments), and the launch does nothing once
+// the outer loop has finished -- the host enqueues several outer iterations ahead.
+template <int G, int kU, int kMinWaves, bool kStamp = false, bool kChained = false>
 __global__ __launch_bounds__(kMatchThreads, kMinWaves) void k_match(MapView map, const char *__restrict__ src, size_t stride,
-                                                         uint32_t n, PoseArgs P, int32_t *__restrict__ out_idx,
+                                                         uint32_t n, PoseArgs Parg, int32_t *__restrict__ out_idx,
                                                          MatchRec *__restrict__ out_rec,
                                                          QStat *__restrict__ out_stat,
                                                          uint32_t *__restrict__ block_counters,
-                                                         unsigned long long *__restrict__ stamps = nullptr)
+                                                         unsigned long long *__restrict__ stamps = nullptr,
+                                                         const AlignState *state = nullptr)
 {
     static_assert(G == 16 && kU == 1, "one query per 16-lane DPP row");
+    struct {
+        double R[9], t[3];
+        float max_sq;
+    } P;
+    if constexpr (kChained) {
+        typedef const __attribute__((address_space(4))) AlignState *ConstState;
+        ConstState cs = (ConstState)(state);
+        if (cs->finished | cs->error) return;
+#pragma unroll
+        for (int i = 0; i < 9; i++) P.R[i] = cs->P.R[i];
+#pragma unroll
+        for (int i = 0; i < 3; i++) P.t[i] = cs->P.t[i];
+        P.max_sq = cs->P.max_sq;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 9; i++) P.R[i] = Parg.R[i];
+#pragma unroll
+        for (int i = 0; i < 3; i++) P.t[i] = Parg.t[i];
+        P.max_sq = Parg.max_sq;
+    }
     Stamper<kStamp> stamper;
     LOM_STAMP(0);
     constexpr int kGroups = kMatchThreads / G;
@@ -390,6 +415,8 @@ struct EvalCmd {  // pinned host memory, written by the host only
     double t[3];
 };
 constexpr unsigned int kCmdEval = 1, kCmdStop = 2;
+constexpr int kPublishPlain = 0, kPublishHost = 1, kPublishDevice = 2;
+constexpr uint32_t kMaxLmBlocks = 64;  // workgroups of k_lm (one lane of a wave watches each record)
 
 // cloud_matcher.cpp:48-102 for one correspondence, accumulated into the 28 sums
 __device__ __forceinline__ void accumulate_point(const float4 ra, const float4 rb, const float4 rc,
@@ -463,7 +490,7 @@ __device__ __forceinline__ void accumulate_point(const float4 ra, const float4 r
 __device__ __forceinline__ void reduce_and_publish(const double acc[28], double *s_acc, unsigned long long *s_cnt,
                                                    const uint32_t *__restrict__ block_counters,
                                                    uint32_t n_match_blocks, double *out_rec,
-                                                   unsigned long long seq, int to_host)
+                                                   unsigned long long seq, int mode)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #pragma unroll
@@ -512,7 +539,7 @@ __device__ __forceinline__ void reduce_and_publish(const double acc[28], double 
         else if (tid < 31)
             o = n_match_blocks ? (double)s_cnt[tid - 28] : 0.0;
         double *dst = out_rec + (size_t)blockIdx.x * kRecWords;
-        if (to_host) {
+        if (mode == kPublishHost) {
             // payload as system-scope (write-through) stores, wait until they have left the wave,
             // then the sequence word: the same order a system-scope release gives, without its
             // L2 write-back pass (nothing this wave wrote is cached)
@@ -521,6 +548,15 @@ __device__ __forceinline__ void reduce_and_publish(const double acc[28], double 
             if (tid == 31)
                 __hip_atomic_store(reinterpret_cast<unsigned long long *>(dst + 31), seq, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_SYSTEM);
+        } else if (mode == kPublishDevice) {
+            // to the other workgroups of this launch (any XCD): every store of the record
+            // agent-coherent and drained before the sequence word; the readers use
+            // agent-coherent loads for both
+            if (tid < 31) __hip_atomic_store(dst + tid, o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (tid == 31)
+                __hip_atomic_store(reinterpret_cast<unsigned long long *>(dst + 31), seq, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
         } else if (tid < 31) {
             dst[tid] = o;
         }
@@ -543,7 +579,7 @@ __global__ __launch_bounds__(kEvalThreads) void k_eval(const MatchRec *__restric
         const float4 ra = r4[0], rb = r4[1], rc = r4[2];
         if (ra.w != 0.f) accumulate_point(ra, rb, rc, E.q[0], E.q[1], E.q[2], E.q[3], E.t[0], E.t[1], E.t[2], acc);
     }
-    reduce_and_publish(acc, s_acc, s_cnt, block_counters, n_match_blocks, out_rec, seq, 0);
+    reduce_and_publish(acc, s_acc, s_cnt, block_counters, n_match_blocks, out_rec, seq, kPublishPlain);
 }
 
 __global__ __launch_bounds__(kEvalThreads) void k_eval_server(const MatchRec *__restrict__ rec, uint32_t n,
@@ -578,7 +614,7 @@ __global__ __launch_bounds__(kEvalThreads) void k_eval_server(const MatchRec *__
             const float4 xa = r4[0], xb = r4[1], xc = r4[2];
             if (xa.w != 0.f) accumulate_point(xa, xb, xc, q0, q1, q2, q3, t0, t1, t2, acc);
         }
-        reduce_and_publish(acc, s_acc, s_cnt, block_counters, counters_from, out_rec, seq, 1);
+        reduce_and_publish(acc, s_acc, s_cnt, block_counters, counters_from, out_rec, seq, kPublishHost);
         counters_from = 0;
         // wait for the next command from the host (bounded: the grid always drains).  The first
         // wave reads the 72-byte command with ONE instruction per poll (lanes 0..8, one word each,
@@ -616,6 +652,303 @@ __global__ __launch_bounds__(kEvalThreads) void k_eval_server(const MatchRec *__
         cmd_seen = s_cmd.seq;
         __syncthreads();  // s_cmd is rewritten by thread 0 in the next round
     }
+}
+
+// Exchange word of k_lm: a value and a check word = sequence number XOR the value's bits.  A reader
+// accepts the pair only when check ^ bits == the sequence number it waits for, so the two 8-byte
+// words need no ordering between them and no separate "record complete" flag: publishing is one
+// memory round trip and reading is one more.
+struct __attribute__((aligned(16))) XWord {
+    unsigned long long bits, check;
+};
+
+__device__ __forceinline__ void xword_store(XWord *dst, double v, unsigned long long seq)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    __hip_atomic_store(&dst->bits, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&dst->check, seq ^ b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// k_lm's evaluation epilogue: workgroup reduction of the 28 per-lane sums through LDS in a fixed
+// order, every row total published straight from the lane that holds it (plus the workgroup's
+// slice of k_match's counters), then all workgroups' words gathered and added in workgroup order
+// into s_tot[0..30] -- bitwise the same on every workgroup.
+//   s_acc: dynamic LDS, 28 rows of kAccStride doubles;  s_part: kEvalThreads doubles.
+__device__ __forceinline__ void reduce_and_exchange(const double acc[28], double *s_acc, unsigned long long *s_cnt,
+                                                    double *s_part, const uint32_t *__restrict__ block_counters,
+                                                    uint32_t n_match_blocks, XWord *set, uint32_t nb,
+                                                    unsigned long long seq, unsigned long long timeout_ticks,
+                                                    double *s_tot, int *s_failed)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    XWord *mine = set + (size_t)blockIdx.x * kRecWords;
+#pragma unroll
+    for (int k = 0; k < 28; k++) s_acc[k * kAccStride + tid] = acc[k];
+    if (wave == 7) {  // the last wave carries no row of the reduction below (28 rows x 16 lanes = 448)
+        unsigned long long c0 = 0, c1 = 0, c2 = 0;
+        if (n_match_blocks) {
+            const uint32_t chunk = (n_match_blocks + gridDim.x - 1) / gridDim.x;
+            const uint32_t lo = blockIdx.x * chunk;
+            const uint32_t hi = min(lo + chunk, n_match_blocks);
+            for (uint32_t b = lo + lane; b < hi; b += 64) {
+                const uint4 r = *reinterpret_cast<const uint4 *>(block_counters + (size_t)b * 4);
+                c0 += r.x;
+                c1 += r.y;
+                c2 += r.z;
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                c0 += __shfl_xor(c0, d, 64);
+                c1 += __shfl_xor(c1, d, 64);
+                c2 += __shfl_xor(c2, d, 64);
+            }
+        }
+        if (lane < 3) xword_store(mine + 28 + lane, (double)(lane == 0 ? c0 : (lane == 1 ? c1 : c2)), seq);
+    }
+    __syncthreads();
+    // thread (k = tid / 16, j = tid % 16) adds row k's elements j, j+16, ... in order
+    {
+        const int k = tid >> 4, j = tid & 15;
+        double v = 0.0;
+        if (k < 28) {
+            const double *row = s_acc + k * kAccStride + j;
+#pragma unroll 8
+            for (int i = 0; i < kEvalThreads / 16; i++) v += row[i * 16];
+        }
+#pragma unroll
+        for (int d = 8; d >= 1; d >>= 1) v += __shfl_xor(v, d, 16);
+        if (j == 0 && k < 28) xword_store(mine + k, v, seq);
+    }
+    // gather: thread (g = tid / 32, k = tid % 32) takes word k of workgroups 4g .. 4g+3
+    {
+        const int k = tid & 31, g = tid >> 5;
+        unsigned long long vb[4] = {0, 0, 0, 0};
+        bool ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) ok[u] = (k >= 31) || ((uint32_t)(g * 4 + u) >= nb);
+        const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+        for (;;) {
+            unsigned long long cb[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (!ok[u]) {
+                    const XWord *w = set + (size_t)(g * 4 + u) * kRecWords + k;
+                    vb[u] = __hip_atomic_load(&w->bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    cb[u] = __hip_atomic_load(&w->check, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            bool all = true;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (!ok[u]) ok[u] = (cb[u] ^ vb[u]) == seq;
+                all = all && ok[u];
+            }
+            if (all) break;
+            if (__builtin_amdgcn_s_memrealtime() - t_start > timeout_ticks) {
+                *s_failed = 1;  // some workgroup never published: give up (the grid drains)
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        double part = 0.0;
+#pragma unroll
+        for (int u = 0; u < 4; u++) part += __longlong_as_double((long long)vb[u]);  // absent workgroups add +0.0
+        s_part[tid] = part;
+    }
+    __syncthreads();
+    if (tid < 31) {
+        double v = 0.0;
+#pragma unroll
+        for (int g = 0; g < kEvalThreads / 32; g++) v += s_part[g * 32 + tid];
+        s_tot[tid] = v;
+    }
+    __syncthreads();  // s_acc / s_part may be rewritten by the next evaluation; s_tot is complete
+}
+
+// ---------------------------------------------------------------------------
+// k_lm: one whole ceres::Solve (cloud_matcher.cpp:157-158) of the single-GPU align, resident
+// on the GPU.  Launched behind k_match once per outer iteration.  Every evaluation the
+// Levenberg-Marquardt policy (lm_core.hpp) asks for is done by the whole grid:
+//   each workgroup reduces its points to one 256-byte record and publishes it in HBM
+//   (agent-coherent stores, sequence word last; two record sets alternate), waits until
+//   the records of all workgroups carry the evaluation's sequence number, and adds them
+//   in workgroup order -- every workgroup holds the same totals bit for bit and runs the
+//   same policy step (one lane), so no decision has to be broadcast and nothing returns to
+//   the host between the evaluations of a solve.
+// Workgroup 0 then writes the f32 pose back (:161-167), prepares the pose of the next
+// k_match in AlignState, decides convergence (:169-172) and copies the state to the report in
+// pinned host memory.  Every wait is bounded (s_memrealtime); a workgroup that gives up sets
+// the error flags and leaves, the others follow.
+// ---------------------------------------------------------------------------
+struct LmInit {
+    float t[3], q[4];   // initial guess (cloud_matcher.cpp:107), used when `first`
+    double prior_b[3];  // NormalPrior anchor = the guess's translation (:153)
+    float max_sq;       // max_correspondence_distance^2 of the searches (:139, voxel_grid.h:215)
+};
+
+__device__ __forceinline__ void accumulate_all(const MatchRec *__restrict__ rec, uint32_t n, uint32_t first,
+                                               uint32_t step, const float4 ra, const float4 rb, const float4 rc,
+                                               const double *x, double acc[28])
+{
+    const double q0 = x[0], q1 = x[1], q2 = x[2], q3 = x[3], t0 = x[4], t1 = x[5], t2 = x[6];
+#pragma unroll
+    for (int k = 0; k < 28; k++) acc[k] = 0.0;
+    if (ra.w != 0.f) accumulate_point(ra, rb, rc, q0, q1, q2, q3, t0, t1, t2, acc);
+    for (uint32_t i = first + step; i < n; i += step) {
+        const float4 *r4 = reinterpret_cast<const float4 *>(rec + i);
+        const float4 xa = r4[0], xb = r4[1], xc = r4[2];
+        if (xa.w != 0.f) accumulate_point(xa, xb, xc, q0, q1, q2, q3, t0, t1, t2, acc);
+    }
+}
+
+__global__ __launch_bounds__(kEvalThreads) void k_lm(const MatchRec *__restrict__ rec, uint32_t n, AlignState *state,
+                                                     LmInit init, int first_outer,
+                                                     const uint32_t *__restrict__ block_counters,
+                                                     uint32_t n_match_blocks, XWord *xrec,
+                                                     unsigned long long seq_base, AlignReport *report,
+                                                     unsigned long long report_seq,
+                                                     unsigned long long timeout_ticks,
+                                                     unsigned long long *dbg_stamps)
+{
+    extern __shared__ __attribute__((aligned(16))) double s_acc[];
+    __shared__ unsigned long long s_cnt[3];
+    __shared__ double s_tot[kRecWords];
+    __shared__ double s_part[kEvalThreads];
+    __shared__ double s_x[7];
+    __shared__ LmState s_lm;
+    __shared__ int s_action, s_failed;
+    if (!first_outer && (state->finished | state->error)) return;  // chained launch after the end
+    const int tid = threadIdx.x;
+    const uint32_t nb = gridDim.x;
+    const uint32_t first = blockIdx.x * blockDim.x + tid, step = nb * blockDim.x;
+    // this lane's first point stays in registers for every evaluation of the solve
+    float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra, rc = ra;
+    if (first < n) {
+        const float4 *r4 = reinterpret_cast<const float4 *>(rec + first);
+        ra = r4[0];
+        rb = r4[1];
+        rc = r4[2];
+    }
+    if (tid < 7) {
+        float v;
+        if (first_outer)
+            v = tid < 4 ? init.q[tid] : init.t[tid - 4];
+        else
+            v = tid < 4 ? state->pose_q[tid] : state->pose_t[tid - 4];
+        s_x[tid] = (double)v;  // cloud_matcher.cpp:122-131
+    }
+    if (tid == 0) s_failed = 0;
+    __syncthreads();
+    unsigned long long seq = seq_base;
+    uint32_t counters_from = n_match_blocks;  // k_match's counters are folded by the first evaluation only
+    double counters[3] = {0.0, 0.0, 0.0};
+    int action = LM_EVAL;
+    // LOM_DEBUG_LM: shader-clock stamps of workgroup 0's first lane, 5 per evaluation
+#define LM_STAMP(k)                                                                            \
+    if (dbg_stamps && blockIdx.x == 0 && tid == 0 && ev < 6) {                                 \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                            \
+        dbg_stamps[ev * 5 + (k)] = __builtin_amdgcn_s_memtime();                               \
+    }
+    for (int ev = 0; action == LM_EVAL; ev++) {
+        double acc[28];
+        LM_STAMP(0);
+        accumulate_all(rec, n, first, step, ra, rb, rc, s_x, acc);
+        LM_STAMP(1);
+        seq++;
+        XWord *set = xrec + (size_t)(seq & 1) * kMaxLmBlocks * kRecWords;
+        reduce_and_exchange(acc, s_acc, s_cnt, s_part, block_counters, counters_from, set, nb, seq, timeout_ticks,
+                            s_tot, &s_failed);
+        counters_from = 0;
+        LM_STAMP(2);
+        LM_STAMP(3);
+        if (s_failed) {  // uniform over the workgroup
+            if (tid == 0) {
+                __hip_atomic_store(&state->error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&report->error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            return;
+        }
+        LM_STAMP(3);
+        if (tid == 0) {
+            LmState S;
+            if (ev == 0) {
+                counters[0] = s_tot[28];
+                counters[1] = s_tot[29];
+                counters[2] = s_tot[30];
+                double x[7];
+#pragma unroll
+                for (int i = 0; i < 7; i++) x[i] = s_x[i];
+                action = lm_begin_head(S, s_tot, x, init.prior_b);
+            } else {
+                S = s_lm;
+                action = lm_feed_head(S, s_tot);
+            }
+            if (action == LM_PROPOSE) action = lm_propose(S);
+            s_lm = S;
+#pragma unroll
+            for (int i = 0; i < 7; i++) s_x[i] = S.cand[i];
+            s_action = action;
+        }
+        LM_STAMP(4);
+        __syncthreads();
+        action = s_action;
+    }
+#undef LM_STAMP
+    if (blockIdx.x != 0 || tid != 0) return;
+    // ---- end of the outer iteration (workgroup 0, one lane) ----
+    const LmState S = s_lm;
+    const int outer = first_outer ? 0 : state->outer_done;
+    float pq[4], pt[3];
+    for (int a = 0; a < 4; a++) pq[a] = (float)S.x[a];      // :161-164
+    for (int a = 0; a < 3; a++) pt[a] = (float)S.x[4 + a];  // :165-167
+    const int finished = ((S.last_step_norm < 1e-4 && outer > 3) || outer + 1 >= 35) ? 1 : 0;  // :117, :169-172
+    AlignState st;
+    float R[9];
+    rotation_matrix(pq, R);  // voxel_grid.h:212
+    for (int i = 0; i < 9; i++) st.P.R[i] = (double)R[i];
+    for (int i = 0; i < 3; i++) st.P.t[i] = (double)pt[i];
+    st.P.max_sq = init.max_sq;
+    for (int a = 0; a < 3; a++) st.pose_t[a] = pt[a];
+    for (int a = 0; a < 4; a++) st.pose_q[a] = pq[a];
+    st.finished = finished;
+    st.error = 0;
+    st.outer_done = outer + 1;
+    st.lm_iterations = (first_outer ? 0 : state->lm_iterations) + S.recorded;
+    st.evaluations = (first_outer ? 0 : state->evaluations) + S.evaluations;
+    st.pad = 0;
+    st.valid_last = counters[0];
+    st.valid_total = (first_outer ? 0.0 : state->valid_total) + counters[0];
+    st.cand_total = (first_outer ? 0.0 : state->cand_total) + counters[1];
+    st.occ_total = (first_outer ? 0.0 : state->occ_total) + counters[2];
+    st.queries_total = (first_outer ? 0.0 : state->queries_total) + (double)n;
+    st.final_cost = S.cost;
+    st.last_step_norm = S.last_step_norm;
+    *state = st;
+    // report: payload as system-scope stores, drained, then the sequence word
+    unsigned long long *dst_w = reinterpret_cast<unsigned long long *>(report);
+    auto put = [&](size_t byte_off, unsigned long long v) {
+        __hip_atomic_store(dst_w + byte_off / 8, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    };
+    auto two_i = [](int lo, int hi) { return (unsigned long long)(uint32_t)lo | ((unsigned long long)(uint32_t)hi << 32); };
+    auto two_f = [](float lo, float hi) {
+        return (unsigned long long)__float_as_uint(lo) | ((unsigned long long)__float_as_uint(hi) << 32);
+    };
+    put(offsetof(AlignReport, finished), two_i(st.finished, 0));
+    put(offsetof(AlignReport, outer_done), two_i(st.outer_done, st.lm_iterations));
+    put(offsetof(AlignReport, evaluations), two_i(st.evaluations, 0));
+    put(offsetof(AlignReport, pose_t), two_f(pt[0], pt[1]));
+    put(offsetof(AlignReport, pose_t) + 8, two_f(pt[2], pq[0]));
+    put(offsetof(AlignReport, pose_t) + 16, two_f(pq[1], pq[2]));
+    put(offsetof(AlignReport, pose_t) + 24, two_f(pq[3], 0.f));
+    put(offsetof(AlignReport, valid_last), (unsigned long long)__double_as_longlong(st.valid_last));
+    put(offsetof(AlignReport, valid_total), (unsigned long long)__double_as_longlong(st.valid_total));
+    put(offsetof(AlignReport, cand_total), (unsigned long long)__double_as_longlong(st.cand_total));
+    put(offsetof(AlignReport, occ_total), (unsigned long long)__double_as_longlong(st.occ_total));
+    put(offsetof(AlignReport, queries_total), (unsigned long long)__double_as_longlong(st.queries_total));
+    put(offsetof(AlignReport, final_cost), (unsigned long long)__double_as_longlong(st.final_cost));
+    put(offsetof(AlignReport, last_step_norm), (unsigned long long)__double_as_longlong(st.last_step_norm));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(dst_w, report_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // multi-GPU path: fold the records of one launch in workgroup order -> LOM_NSUMS doubles in HBM
@@ -702,11 +1035,14 @@ static double *d_sums(lom_map *m) { return (double *)m->results.p; }
 
 static void server_stop(lom_map *m);
 
-static int launch_match(ScanCtx &c, const float t[3], const float q[4], float max_dist, bool stats)
+// chained: the pose comes from the AlignState in HBM (t, q unused)
+static int launch_match(ScanCtx &c, const float t[3], const float q[4], float max_dist, bool stats,
+                        bool chained = false)
 {
     lom_map *m = c.m;
     PoseArgs P;
-    pose_args(t, q, max_dist, P);
+    std::memset(&P, 0, sizeof P);
+    if (!chained) pose_args(t, q, max_dist, P);
     c.match_blocks = c.n ? match_grid(c.n) : 0;
     server_stop(m);  // the previous outer iteration's evaluation server leaves before the new search
     const double t_launch = now_s();
@@ -727,9 +1063,16 @@ static int launch_match(ScanCtx &c, const float t[3], const float q[4], float ma
         // <lanes per query, candidates per lane and trip, min waves per SIMD>: measured on C2 / C3
         // (tools/ab_match.py): <16,1,8> 9.2 / 37.3 us, <16,2,1> 8.9 / 41.0, <16,4,1> 10.0 / 43.5,
         // <16,2,8> and <16,4,8> spill and lose; 8 lanes per query 12.3 / 44.1, 32 lanes 10.1 / 44.5
-        hipLaunchKernelGGL((k_match<kMatchG, 1, 8>), dim3(c.match_blocks), dim3(kMatchThreads), 0, m->stream,
-                           view_of(m), c.d_src, c.stride, c.n, P, (int32_t *)m->scan_idx.p, (MatchRec *)m->scan_on.p,
-                           stats ? (QStat *)m->scan_stats.p : (QStat *)nullptr, d_block_counters(m));
+        if (chained)
+            hipLaunchKernelGGL((k_match<kMatchG, 1, 8, false, true>), dim3(c.match_blocks), dim3(kMatchThreads), 0,
+                               m->stream, view_of(m), c.d_src, c.stride, c.n, P, (int32_t *)m->scan_idx.p,
+                               (MatchRec *)m->scan_on.p, (QStat *)nullptr, d_block_counters(m),
+                               (unsigned long long *)nullptr, (const AlignState *)m->align_state.p);
+        else
+            hipLaunchKernelGGL((k_match<kMatchG, 1, 8>), dim3(c.match_blocks), dim3(kMatchThreads), 0, m->stream,
+                               view_of(m), c.d_src, c.stride, c.n, P, (int32_t *)m->scan_idx.p,
+                               (MatchRec *)m->scan_on.p, stats ? (QStat *)m->scan_stats.p : (QStat *)nullptr,
+                               d_block_counters(m), (unsigned long long *)nullptr, (const AlignState *)nullptr);
         LOM_HIP(m, hipGetLastError());
         if (m->profiling) LOM_HIP(m, hipEventRecord(e1, m->stream));
     }
@@ -756,6 +1099,8 @@ static int eval_kernel_attrs(lom_map *m)
                                    (int)kEvalLdsBytes));
     LOM_HIP(m, hipFuncSetAttribute(reinterpret_cast<const void *>(k_eval_server),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEvalLdsBytes));
+    LOM_HIP(m, hipFuncSetAttribute(reinterpret_cast<const void *>(k_lm), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)kEvalLdsBytes));
     m->eval_attr_set = true;
     return LOM_OK;
 }
@@ -906,10 +1251,144 @@ static int hook_eval_fixed(void *user, const double q[4], const double t[3], dou
     return launch_eval(c, q, t, false, out);
 }
 
+// Single GPU, no exchange: the outer loop runs on the device.  One (k_match, k_lm) pair per outer
+// iteration; the pose travels from pair to pair through AlignState in HBM, so the host enqueues
+// pairs without waiting for results.  cloud_matcher.cpp:169-172 cannot stop before the fifth outer
+// iteration (i > 3): five pairs go out at once, then one pair per report until `finished`.
+static int align_chained(lom_map *m, const char *d_src, size_t n, size_t stride, const float guess_t[3],
+                         const float guess_q[4], float out_t[3], float out_q[4], lom_align_stats *stats)
+{
+    static_assert(offsetof(AlignReport, finished) == 8 && offsetof(AlignReport, outer_done) == 16 &&
+                      offsetof(AlignReport, evaluations) == 24 && offsetof(AlignReport, pose_t) == 32 &&
+                      offsetof(AlignReport, valid_last) == 64 && sizeof(AlignReport) <= 256,
+                  "AlignReport is written as 64-bit words");
+    int rc = scan_buffers(m, (uint32_t)n, false);
+    if (rc != LOM_OK) return rc;
+    if ((rc = ensure(m, m->align_state, sizeof(AlignState))) != LOM_OK) return rc;
+    if (!m->xrec.p) {
+        const size_t bytes = (size_t)2 * kMaxLmBlocks * kRecWords * sizeof(XWord);
+        if ((rc = ensure(m, m->xrec, bytes)) != LOM_OK) return rc;
+        LOM_HIP(m, hipMemsetAsync(m->xrec.p, 0, bytes, m->stream));
+    }
+    if ((rc = eval_kernel_attrs(m)) != LOM_OK) return rc;
+    ScanCtx c{m, d_src, stride, (uint32_t)n, 0};
+    LmInit init;
+    for (int a = 0; a < 3; a++) init.t[a] = guess_t[a];  // cloud_matcher.cpp:107
+    for (int a = 0; a < 4; a++) init.q[a] = guess_q[a];
+    for (int a = 0; a < 3; a++) init.prior_b[a] = (double)guess_t[a];  // :153
+    init.max_sq = 0.3f * 0.3f;                                          // :139, voxel_grid.h:215
+    const uint32_t nb = std::min(eval_grid(std::max<uint32_t>(c.n, 1u)), kMaxLmBlocks);
+    volatile AlignReport *rp = reinterpret_cast<volatile AlignReport *>(m->h_report);
+    rp->error = 0;
+    const unsigned long long seq0 = m->report_seq;
+    int launched = 0;
+    unsigned long long *dbg = nullptr;  // LOM_DEBUG_LM: phase stamps of the last k_lm of the align
+    if (getenv("LOM_DEBUG_LM")) {
+        if ((rc = ensure(m, m->scr[0], 4096)) != LOM_OK) return rc;
+        dbg = (unsigned long long *)m->scr[0].p;
+        LOM_HIP(m, hipMemsetAsync(dbg, 0, 30 * 8, m->stream));
+    }
+    auto launch_pair = [&]() -> int {
+        const int i = launched;
+        int r = launch_match(c, guess_t, guess_q, 0.3f, false, i > 0);
+        if (r != LOM_OK) return r;
+        const double t_l = now_s();
+        m->lm_seq += 8;  // a solve spends at most 5 evaluations
+        hipLaunchKernelGGL(k_lm, dim3(nb), dim3(kEvalThreads), kEvalLdsBytes, m->stream,
+                           (const MatchRec *)m->scan_on.p, c.n, (AlignState *)m->align_state.p, init, i == 0 ? 1 : 0,
+                           (const uint32_t *)d_block_counters(m), c.match_blocks, (XWord *)m->xrec.p, m->lm_seq,
+                           reinterpret_cast<AlignReport *>(m->d_report), seq0 + (unsigned long long)i + 1,
+                           server_timeout_ticks(), dbg);
+        LOM_HIP(m, hipGetLastError());
+        c.launch_s += now_s() - t_l;
+        launched++;
+        return LOM_OK;
+    };
+    for (int i = 0; i < 5; i++)
+        if ((rc = launch_pair()) != LOM_OK) return rc;
+    for (;;) {
+        const double t_w = now_s();
+        const unsigned long long want = seq0 + (unsigned long long)launched;
+        uint64_t spins = 0;
+        while (rp->seq != want) {
+            __builtin_ia32_pause();
+            if (rp->error) break;
+            if ((++spins & 0x3FFF) == 0) {
+                const hipError_t e = hipStreamQuery(m->stream);
+                if (e == hipSuccess) {
+                    if (rp->seq == want) break;
+                    m->report_seq = want;
+                    return set_error(m, LOM_ERR_HIP, "device solve ended without a report");
+                } else if (e != hipErrorNotReady) {
+                    m->report_seq = want;
+                    return set_error(m, LOM_ERR_HIP, "stream failed during the device solve", e);
+                }
+            }
+        }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        c.wait_s += now_s() - t_w;
+        if (rp->error) {
+            (void)hipStreamSynchronize(m->stream);
+            m->report_seq = want;
+            return set_error(m, LOM_ERR_HIP, "device solve: a workgroup timed out waiting for the others");
+        }
+        if (rp->finished || launched >= 35) break;
+        if ((rc = launch_pair()) != LOM_OK) return rc;
+    }
+    m->report_seq = seq0 + (unsigned long long)launched;
+    lom_align_stats st;
+    std::memset(&st, 0, sizeof st);
+    st.outer_iterations = rp->outer_done;
+    st.match_launches = rp->outer_done;
+    st.lm_iterations = rp->lm_iterations;
+    st.evaluations = rp->evaluations;
+    st.valid_last = (int64_t)rp->valid_last;
+    st.cand_total = (int64_t)rp->cand_total;
+    st.occ_total = (int64_t)rp->occ_total;
+    st.queries = (int64_t)rp->queries_total;
+    // B(q) = 12 + 27*16 + 12*cand(q) + 12*valid(q)
+    st.algorithmic_bytes = 444.0 * rp->queries_total + 12.0 * rp->cand_total + 12.0 * rp->valid_total;
+    st.final_cost = rp->final_cost;
+    st.last_step_norm = rp->last_step_norm;
+    float pq[4] = {rp->pose_q[0], rp->pose_q[1], rp->pose_q[2], rp->pose_q[3]};
+    {   // cloud_matcher.cpp:175 rotation.normalize(), f32
+        const float n2 = (pq[0] * pq[0] + pq[1] * pq[1]) + (pq[2] * pq[2] + pq[3] * pq[3]);
+        const float nn = std::sqrt(n2);
+        for (int a = 0; a < 4; a++) pq[a] = pq[a] / nn;
+    }
+    for (int a = 0; a < 3; a++) out_t[a] = rp->pose_t[a];
+    for (int a = 0; a < 4; a++) out_q[a] = pq[a];
+    if (m->profiling && c.prof_used) {
+        LOM_HIP(m, hipStreamSynchronize(m->stream));
+        for (int i = 0; i < c.prof_used; i++) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, m->prof_events[(size_t)i * 2], m->prof_events[(size_t)i * 2 + 1]) == hipSuccess)
+                st.match_kernel_ms += ms;
+        }
+    }
+    st.host_launch_ms = c.launch_s * 1e3;
+    st.host_wait_ms = c.wait_s * 1e3;
+    if (stats) *stats = st;
+    if (dbg) {
+        unsigned long long h[30];
+        LOM_HIP(m, hipMemcpyAsync(h, dbg, sizeof h, hipMemcpyDeviceToHost, m->stream));
+        LOM_HIP(m, hipStreamSynchronize(m->stream));
+        for (int ev = 0; ev < 6 && h[ev * 5]; ev++)
+            fprintf(stderr, "k_lm eval %d: at %llu: accumulate %llu reduce+exchange %llu policy %llu cycles\n", ev,
+                    h[ev * 5] - h[0], h[ev * 5 + 1] - h[ev * 5], h[ev * 5 + 2] - h[ev * 5 + 1],
+                    h[ev * 5 + 4] - h[ev * 5 + 3]);
+    }
+    return LOM_OK;
+}
+
 static int align_device(lom_map *m, const char *d_src, size_t n, size_t stride, const float guess_t[3],
                         const float guess_q[4], float out_t[3], float out_q[4], lom_align_stats *stats)
 {
     if (n >= 0x7FFFFFFFull) return set_error(m, LOM_ERR_ARG, "too many source points");
+    if (!m->comm && !m->host_comm && !getenv("LOM_HOST_LM")) {
+        server_stop(m);
+        return align_chained(m, d_src, n, stride, guess_t, guess_q, out_t, out_q, stats);
+    }
     int rc = scan_buffers(m, (uint32_t)n, false);
     if (rc != LOM_OK) return rc;
     ScanCtx c{m, d_src, stride, (uint32_t)n, 0};

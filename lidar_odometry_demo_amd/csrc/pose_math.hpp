@@ -98,6 +98,42 @@ inline void pose_inverse(const lom_pose &a, lom_pose &out)
     out = r;
 }
 
+// sin(a)/a and cos(a) for the rotation step of the manifold update.  LM steps are small angles:
+// below 0.5 rad both come from their Taylor series (terms to a^20: truncation below 1e-22
+// relative), which keeps the device-resident solve free of the math library's argument reduction
+// (and its scratch memory); larger angles use sin / cos.  Host and device run this same code.
+LOM_HD void sinc_cos(double a, double &sinc, double &c)
+{
+    if (a < 0.5) {
+        const double z = a * a;
+        double s = 1.0 / 51090942171709440000.0;  // 1/21!
+        s = 1.0 / 121645100408832000.0 - z * s;   // 1/19!
+        s = 1.0 / 355687428096000.0 - z * s;      // 1/17!
+        s = 1.0 / 1307674368000.0 - z * s;        // 1/15!
+        s = 1.0 / 6227020800.0 - z * s;           // 1/13!
+        s = 1.0 / 39916800.0 - z * s;             // 1/11!
+        s = 1.0 / 362880.0 - z * s;               // 1/9!
+        s = 1.0 / 5040.0 - z * s;                 // 1/7!
+        s = 1.0 / 120.0 - z * s;                  // 1/5!
+        s = 1.0 / 6.0 - z * s;                    // 1/3!
+        sinc = 1.0 - z * s;
+        double k = 1.0 / 2432902008176640000.0;   // 1/20!
+        k = 1.0 / 6402373705728000.0 - z * k;     // 1/18!
+        k = 1.0 / 20922789888000.0 - z * k;       // 1/16!
+        k = 1.0 / 87178291200.0 - z * k;          // 1/14!
+        k = 1.0 / 479001600.0 - z * k;            // 1/12!
+        k = 1.0 / 3628800.0 - z * k;              // 1/10!
+        k = 1.0 / 40320.0 - z * k;                // 1/8!
+        k = 1.0 / 720.0 - z * k;                  // 1/6!
+        k = 1.0 / 24.0 - z * k;                   // 1/4!
+        k = 1.0 / 2.0 - z * k;                    // 1/2!
+        c = 1.0 - z * k;
+    } else {
+        sinc = sin(a) / a;
+        c = cos(a);
+    }
+}
+
 // Ceres QuaternionManifold::Plus on [w,x,y,z] (delta = half-angle vector applied
 // on the left) followed by the Euclidean translation update.
 LOM_HD void manifold_plus(const double x[7], const double d[6], double out[7])
@@ -106,8 +142,9 @@ LOM_HD void manifold_plus(const double x[7], const double d[6], double out[7])
     if (nd == 0.0) {
         for (int i = 0; i < 4; i++) out[i] = x[i];
     } else {
-        const double s = sin(nd) / nd;
-        const double z[4] = {cos(nd), s * d[0], s * d[1], s * d[2]};
+        double s, c;
+        sinc_cos(nd, s, c);
+        const double z[4] = {c, s * d[0], s * d[1], s * d[2]};
         out[0] = z[0] * x[0] - z[1] * x[1] - z[2] * x[2] - z[3] * x[3];
         out[1] = z[0] * x[1] + z[1] * x[0] + z[2] * x[3] - z[3] * x[2];
         out[2] = z[0] * x[2] - z[1] * x[3] + z[2] * x[0] + z[3] * x[1];

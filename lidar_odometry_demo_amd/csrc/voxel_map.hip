@@ -823,7 +823,9 @@ int lom_map_create(float voxel_size, size_t max_points, size_t capacity_hint, in
             hipSuccess ||
         (e = hipHostGetDevicePointer((void **)&m->d_mail, m->h_mail, 0)) != hipSuccess ||
         (e = hipHostMalloc(&m->h_cmd, 256, hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess ||
-        (e = hipHostGetDevicePointer(&m->d_cmd, m->h_cmd, 0)) != hipSuccess) {
+        (e = hipHostGetDevicePointer(&m->d_cmd, m->h_cmd, 0)) != hipSuccess ||
+        (e = hipHostMalloc(&m->h_report, 256, hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess ||
+        (e = hipHostGetDevicePointer(&m->d_report, m->h_report, 0)) != hipSuccess) {
         set_error(nullptr, LOM_ERR_HIP, "handle setup", e);
         lom_map_destroy(m);
         return LOM_ERR_HIP;
@@ -831,6 +833,7 @@ int lom_map_create(float voxel_size, size_t max_points, size_t capacity_hint, in
     m->stream = m->own_stream;
     std::memset(m->h_mail, 0, 64 * 32 * sizeof(double));
     std::memset(m->h_cmd, 0, 256);
+    std::memset(m->h_report, 0, 256);
     m->min_cap = next_pow2(4ull * std::max<size_t>(capacity_hint, 256));
     int rc = ensure(m, m->scr[S_MISC], 256);
     if (rc == LOM_OK) {
@@ -867,7 +870,8 @@ void lom_map_destroy(lom_map *m)
     slabs_free(alt);
     for (auto &b : m->scr)
         if (b.p) (void)hipFree(b.p);
-    for (DeviceBuf *b : {&m->scan_src, &m->scan_idx, &m->scan_on, &m->scan_stats, &m->partials, &m->results, &m->gather})
+    for (DeviceBuf *b : {&m->scan_src, &m->scan_idx, &m->scan_on, &m->scan_stats, &m->partials, &m->results, &m->gather,
+                         &m->align_state, &m->xrec})
         if (b->p) (void)hipFree(b->p);
     if (m->h_results) (void)hipHostFree(m->h_results);
     if (m->h_flags) (void)hipHostFree(m->h_flags);
@@ -875,6 +879,7 @@ void lom_map_destroy(lom_map *m)
     if (m->h_stage) (void)hipHostFree(m->h_stage);
     if (m->stage_ev) (void)hipEventDestroy(m->stage_ev);
     if (m->h_cmd) (void)hipHostFree(m->h_cmd);
+    if (m->h_report) (void)hipHostFree(m->h_report);
     for (auto &e : m->prof_events)
         if (e) (void)hipEventDestroy(e);
     if (m->own_stream) (void)hipStreamDestroy(m->own_stream);

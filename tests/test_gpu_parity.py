@@ -324,9 +324,29 @@ def test_align_parity_synth(lom, oracle):
     assert dt < POSE_TOL_M and dr < POSE_TOL_RAD
 
 
+def test_host_driven_path_matches_device_loop(lom, monkeypatch):
+    """LOM_HOST_LM=1 keeps the outer loop and the LM policy on the host (resident evaluation server,
+    the path the multi-GPU exchange uses); the default single-GPU path runs both on the device.
+    Same policy source (lm_core.hpp): same iteration counts, poses within the bar."""
+    sm = scenes.small_synth_case()
+    g = lom.VoxelGrid(0.5, 20)
+    g.addCloud(sm["map_xyz"], sm["map_nrm"])
+    m = lom.CloudMatcher()
+    dev = m.align(g, sm["scan"], lom.Pose3D())
+    dev_stats = dict(m.stats)
+    monkeypatch.setenv("LOM_HOST_LM", "1")
+    host = m.align(g, sm["scan"], lom.Pose3D())
+    dt, dr = scenes.pose_delta(dev.translation, dev.rotation, host.translation, host.rotation)
+    assert dt < 1e-6 and dr < 1e-6, (dt, dr)
+    for k in ("outer_iterations", "lm_iterations", "evaluations", "queries", "cand_total", "occ_total", "valid_last"):
+        assert m.stats[k] == dev_stats[k], k
+
+
 def test_evaluation_server_timeout_recovery(lom, monkeypatch):
-    """The resident evaluation server leaves when the host stays away (bounded spin); the host
-    then relaunches it.  With a 1-tick timeout every LM iteration takes that path: same bits."""
+    """Host-driven path: the resident evaluation server leaves when the host stays away (bounded
+    spin); the host then relaunches it.  With a 1-tick timeout every LM iteration takes that path:
+    same bits."""
+    monkeypatch.setenv("LOM_HOST_LM", "1")
     sm = scenes.small_synth_case()
     g = lom.VoxelGrid(0.5, 20)
     g.addCloud(sm["map_xyz"], sm["map_nrm"])
@@ -342,6 +362,24 @@ def test_evaluation_server_timeout_recovery(lom, monkeypatch):
     monkeypatch.delenv("LOM_TEST_SERVER_TIMEOUT_TICKS")
     again = m.align(g, sm["scan"], lom.Pose3D())
     assert again.translation.tobytes() == ref.translation.tobytes()
+
+
+def test_device_loop_gives_up_cleanly_and_recovers(lom, monkeypatch):
+    """Every wait inside the device-resident solve is bounded: with a 1-tick patience the
+    workgroups give up waiting for each other, the grid drains, the call returns an error instead
+    of hanging -- and the handle works again afterwards (same bits as before)."""
+    sm = scenes.small_synth_case()
+    g = lom.VoxelGrid(0.5, 20)
+    g.addCloud(sm["map_xyz"], sm["map_nrm"])
+    m = lom.CloudMatcher()
+    ref = m.align(g, sm["scan"], lom.Pose3D())
+    monkeypatch.setenv("LOM_TEST_SERVER_TIMEOUT_TICKS", "1")
+    with pytest.raises(lom.LomError):
+        m.align(g, sm["scan"], lom.Pose3D())
+    monkeypatch.delenv("LOM_TEST_SERVER_TIMEOUT_TICKS")
+    again = m.align(g, sm["scan"], lom.Pose3D())
+    assert again.translation.tobytes() == ref.translation.tobytes()
+    assert again.rotation.tobytes() == ref.rotation.tobytes()
 
 
 def test_comm_path_single_rank(lom):
