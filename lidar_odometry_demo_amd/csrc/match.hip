@@ -678,8 +678,14 @@ __device__ __forceinline__ void reduce_and_exchange(const double acc[28], double
                                                     double *s_part, const uint32_t *__restrict__ block_counters,
                                                     uint32_t n_match_blocks, XWord *set, uint32_t nb,
                                                     unsigned long long seq, unsigned long long timeout_ticks,
-                                                    double *s_tot, int *s_failed)
+                                                    double *s_tot, int *s_failed, unsigned long long *dbg = nullptr)
 {
+#define RX_STAMP(k)                                                     \
+    if (dbg && blockIdx.x == 0 && threadIdx.x == 0) {                   \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     \
+        dbg[k] = __builtin_amdgcn_s_memtime();                          \
+    }
+    RX_STAMP(0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     XWord *mine = set + (size_t)blockIdx.x * kRecWords;
 #pragma unroll
@@ -717,8 +723,10 @@ __device__ __forceinline__ void reduce_and_exchange(const double acc[28], double
         }
 #pragma unroll
         for (int d = 8; d >= 1; d >>= 1) v += __shfl_xor(v, d, 16);
+        RX_STAMP(1);
         if (j == 0 && k < 28) xword_store(mine + k, v, seq);
     }
+    RX_STAMP(2);
     // gather: thread (g = tid / 32, k = tid % 32) takes word k of workgroups 4g .. 4g+3
     {
         const int k = tid & 31, g = tid >> 5;
@@ -755,6 +763,7 @@ __device__ __forceinline__ void reduce_and_exchange(const double acc[28], double
         for (int u = 0; u < 4; u++) part += __longlong_as_double((long long)vb[u]);  // absent workgroups add +0.0
         s_part[tid] = part;
     }
+    RX_STAMP(3);
     __syncthreads();
     if (tid < 31) {
         double v = 0.0;
@@ -763,6 +772,8 @@ __device__ __forceinline__ void reduce_and_exchange(const double acc[28], double
         s_tot[tid] = v;
     }
     __syncthreads();  // s_acc / s_part may be rewritten by the next evaluation; s_tot is complete
+    RX_STAMP(4);
+#undef RX_STAMP
 }
 
 // ---------------------------------------------------------------------------
@@ -780,6 +791,320 @@ __device__ __forceinline__ void reduce_and_exchange(const double acc[28], double
 // pinned host memory.  Every wait is bounded (s_memrealtime); a workgroup that gives up sets
 // the error flags and leaves, the others follow.
 // ---------------------------------------------------------------------------
+// ---- lm_core.hpp's policy, executed by one wave ---------------------------------------------
+// Same decisions, same operation order as lm_begin_head / lm_feed_head / lm_propose, but a single
+// lane issuing ~1500 f64 instructions costs ~4 us per step on a 64-wide SIMD.  Here lane r < 6
+// owns row r of the 6x6 system; values another row needs travel by v_readlane (uniform
+// broadcasts), so a step is ~400 instructions.  Differences from the serial code are at rounding
+// level only: sqrt / reciprocal of the Cholesky pivots come from v_rsq_f64 + two Goldschmidt steps
+// instead of the correctly rounded library calls.  All 64 lanes run the code (uniform control
+// flow); lanes >= 6 compute unused values and never store.
+__device__ __forceinline__ double lane_bcast(double v, int k)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), k);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), k);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ void sqrt_and_inverse(double d, double &root, double &inv)
+{
+    const double y = __builtin_amdgcn_rsq(d);
+    double g = d * y, h = 0.5 * y;
+    double e = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, e, g);
+    h = __builtin_fma(h, e, h);
+    e = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, e, g);
+    h = __builtin_fma(h, e, h);
+    const double dd = __builtin_fma(-g, g, d);
+    root = __builtin_fma(dd, h, g);
+    inv = h + h;
+}
+
+// lm_assemble for lane r: its row of A, its g, and the (uniform) cost
+__device__ __forceinline__ void lmw_assemble(const double *s, const double *xx, const double *prior_b, int r,
+                                             double Arow[6], double &g_r, double &cost)
+{
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        const int a = r < j ? r : j, b = r < j ? j : r;
+        Arow[j] = s[a * 6 - (a * (a - 1)) / 2 + (b - a)];  // upper-triangle index of (a,b)
+    }
+    g_r = s[21 + r];
+    cost = s[27];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const double res = kPriorW * (xx[4 + a] - prior_b[a]);
+        if (r == 3 + a) {
+            Arow[3 + a] += kPriorW * kPriorW;
+            g_r += kPriorW * res;
+        }
+        cost += 0.5 * res * res;
+    }
+}
+
+__device__ __forceinline__ double lmw_pick(const double v[6], int r)  // v[r], r varies by lane
+{
+    double o = v[0];
+#pragma unroll
+    for (int j = 1; j < 6; j++) o = (r == j) ? v[j] : o;
+    return o;
+}
+
+__device__ __forceinline__ double lmw_gmax(double g_r)
+{
+    double m = 0.0;
+#pragma unroll
+    for (int c = 0; c < 6; c++) m = fmax(m, fabs(lane_bcast(g_r, c)));
+    return m;
+}
+
+__device__ __forceinline__ void lmw_store_normal(LmState &S, int lane, int r, const double Arow[6], double g_r,
+                                                 double cost)
+{
+    if (lane < 6) {
+#pragma unroll
+        for (int j = 0; j < 6; j++) S.N.A[r][j] = Arow[j];
+        S.N.g[r] = g_r;
+    }
+    if (lane == 0) S.N.cost = cost;
+}
+
+// lm_begin_head
+__device__ __forceinline__ int lmw_begin(LmState &S, const double *first, const double *x, const double *prior_b,
+                                         int lane)
+{
+    const int r = lane < 6 ? lane : 5;
+    double Arow[6], g_r, cost;
+    double pb[3] = {prior_b[0], prior_b[1], prior_b[2]};
+    lmw_assemble(first, x, pb, r, Arow, g_r, cost);
+    const double scale_r = 1.0 / (1.0 + sqrt(lmw_pick(Arow, r)));
+    double xs[7];
+#pragma unroll
+    for (int i = 0; i < 7; i++) xs[i] = x[i];
+    const double x_norm = lm_norm7(xs);
+    lmw_store_normal(S, lane, r, Arow, g_r, cost);
+    if (lane < 6) {
+        S.scale[r] = scale_r;
+        S.diag[r] = 0.0;
+    }
+    if (lane < 7) {
+        S.x[lane] = xs[0] * 0.0 + x[lane];
+        S.cand[lane] = x[lane];
+    }
+    if (lane < 3) S.prior_b[lane] = prior_b[lane];
+    if (lane == 0) {
+        S.x_norm = x_norm;
+        S.radius = 1e4;
+        S.decrease_factor = 2.0;
+        S.reuse_diag = 0;
+        S.invalid_run = 0;
+        S.iter = 1;
+        S.recorded = 1;
+        S.evaluations = 1;
+        S.last_step_norm = 0.0;
+        S.model_change = 0.0;
+        S.cost = cost;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (lmw_gmax(g_r) <= kLmGtol) return LM_DONE;
+    return LM_PROPOSE;
+}
+
+// lm_feed_head
+__device__ __forceinline__ int lmw_feed(LmState &S, const double *sums, int lane)
+{
+    const int r = lane < 6 ? lane : 5;
+    double xs[7], cs[7], pb[3];
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+        xs[i] = S.x[i];
+        cs[i] = S.cand[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; i++) pb[i] = S.prior_b[i];
+    const double n_cost = S.N.cost, x_norm = S.x_norm, model_change = S.model_change;
+    double radius = S.radius, decrease_factor = S.decrease_factor;
+    const int evaluations = S.evaluations + 1, recorded = S.recorded, iter = S.iter;
+    double Crow[6], cg_r, c_cost;
+    lmw_assemble(sums, cs, pb, r, Crow, cg_r, c_cost);
+    double d7[7];
+#pragma unroll
+    for (int i = 0; i < 7; i++) d7[i] = xs[i] - cs[i];
+    const double sn = lm_norm7(d7);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();  // every lane has read the state: lane 0 may now update it
+    if (lane == 0) {
+        S.evaluations = evaluations;
+        S.cost = n_cost;
+    }
+    if (sn <= kLmPtol * (x_norm + kLmPtol)) return LM_DONE;           // parameter tolerance: not recorded
+    const double cost_change = n_cost - c_cost;
+    if (fabs(cost_change) <= kLmFtol * n_cost) return LM_DONE;        // function tolerance: not recorded
+    const double rel_dec = cost_change / model_change;
+    const bool accept = rel_dec > kLmMinRelDec;
+    double g_now = S.N.g[r];
+    double cost_now = n_cost;
+    __builtin_amdgcn_wave_barrier();
+    if (accept) {
+        lmw_store_normal(S, lane, r, Crow, cg_r, c_cost);
+        if (lane < 7) S.x[lane] = S.cand[lane];
+        const double d3 = 2.0 * rel_dec - 1.0;
+        radius = radius / fmax(1.0 / 3.0, 1.0 - d3 * d3 * d3);
+        radius = fmin(kLmMaxRadius, radius);
+        decrease_factor = 2.0;
+        g_now = cg_r;
+        cost_now = c_cost;
+    } else {
+        radius /= decrease_factor;
+        decrease_factor *= 2.0;
+    }
+    if (lane == 0) {
+        if (accept) S.x_norm = lm_norm7(cs);
+        S.radius = radius;
+        S.decrease_factor = decrease_factor;
+        S.reuse_diag = accept ? 0 : 1;
+        S.recorded = recorded + 1;
+        S.last_step_norm = sn;
+        S.cost = cost_now;
+    }
+    const bool done = lmw_gmax(g_now) <= kLmGtol;
+    if (!done && lane == 0) S.iter = iter + 1;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    return done ? LM_DONE : LM_PROPOSE;
+}
+
+// lm_propose
+__device__ __forceinline__ int lmw_propose(LmState &S, int lane)
+{
+    const int r = lane < 6 ? lane : 5;
+    double Arow[6];
+#pragma unroll
+    for (int j = 0; j < 6; j++) Arow[j] = S.N.A[r][j];
+    const double g_r = S.N.g[r], scale_r = S.scale[r];
+    double diag_r = S.diag[r];
+    double radius = S.radius, decrease_factor = S.decrease_factor;
+    int reuse_diag = S.reuse_diag, invalid_run = S.invalid_run, iter = S.iter, recorded = S.recorded;
+    double last_step_norm = S.last_step_norm;
+    double xs[7];
+#pragma unroll
+    for (int i = 0; i < 7; i++) xs[i] = S.x[i];
+    double scale_c[6];
+#pragma unroll
+    for (int j = 0; j < 6; j++) scale_c[j] = lane_bcast(scale_r, j);
+    double As[6];
+#pragma unroll
+    for (int j = 0; j < 6; j++) As[j] = Arow[j] * scale_r * scale_c[j];
+    const double gs_r = g_r * scale_r;
+    int result = LM_DONE;
+    double cand[7] = {0, 0, 0, 0, 0, 0, 0}, model_change = 0.0;
+    while (iter <= kLmMaxIter) {
+        if (!reuse_diag) diag_r = fmin(fmax(lmw_pick(As, r), kLmMinDiag), kLmMaxDiag);
+        const double inv_radius = 1.0 / radius;
+        double M[6];
+#pragma unroll
+        for (int j = 0; j < 6; j++) M[j] = (r == j) ? As[j] + diag_r * inv_radius : As[j];
+        // Cholesky, column by column: lane r ends with row r of L in M[0..r]; Lt[j] of lane k = L[j][k]
+        double inv[6], Lt[6] = {0, 0, 0, 0, 0, 0};
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            const double d = lane_bcast(M[k], k);
+            if (!(d > 0.0)) ok = false;
+            double root, invk;
+            sqrt_and_inverse(d, root, invk);
+            inv[k] = invk;
+            const double Lrk = M[k] * invk;  // L[r][k] for r > k
+#pragma unroll
+            for (int j = k + 1; j < 6; j++) {
+                const double Ljk = lane_bcast(Lrk, j);
+                M[j] -= Lrk * Ljk;
+                Lt[j] = (r == k) ? Ljk : Lt[j];
+            }
+            M[k] = (r == k) ? root : Lrk;
+        }
+        double y[6];
+        if (ok) {
+            double s_r = gs_r, zv = 0.0;
+#pragma unroll
+            for (int m = 0; m < 6; m++) {  // L z = gs
+                const double zm = lane_bcast(s_r, m) * inv[m];
+                s_r -= M[m] * zm;
+                zv = (r == m) ? zm : zv;
+            }
+            double t_r = zv;
+#pragma unroll
+            for (int m = 5; m >= 0; m--) {  // L^T y = z
+                const double ym = lane_bcast(t_r, m) * inv[m];
+                t_r -= Lt[m] * ym;
+                y[m] = ym;
+            }
+#pragma unroll
+            for (int i = 0; i < 6; i++)
+                if (!lm_finite(y[i])) ok = false;
+        }
+        reuse_diag = 1;
+        double step[6];
+        model_change = 0.0;
+        if (ok) {
+            double gsdot = 0.0, quad = 0.0, row = 0.0;
+#pragma unroll
+            for (int c = 0; c < 6; c++) step[c] = -y[c];
+#pragma unroll
+            for (int b = 0; b < 6; b++) row += As[b] * step[b];
+#pragma unroll
+            for (int a = 0; a < 6; a++) {
+                gsdot += lane_bcast(gs_r, a) * step[a];
+                quad += step[a] * lane_bcast(row, a);
+            }
+            model_change = -gsdot - 0.5 * quad;
+        }
+        if (!ok || !(model_change > 0.0)) {
+            if (++invalid_run >= 5) break;
+            radius /= decrease_factor;
+            decrease_factor *= 2.0;
+            recorded++;
+            last_step_norm = 0.0;
+            iter++;
+            continue;
+        }
+        invalid_run = 0;
+        double delta[6];
+#pragma unroll
+        for (int c = 0; c < 6; c++) delta[c] = step[c] * scale_c[c];
+        manifold_plus(xs, delta, cand);
+        result = LM_EVAL;
+        break;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();  // every lane has read the state
+    if (lane < 6) S.diag[r] = diag_r;
+    if (lane == 0) {
+        S.radius = radius;
+        S.decrease_factor = decrease_factor;
+        S.reuse_diag = reuse_diag;
+        S.invalid_run = invalid_run;
+        S.iter = iter;
+        S.recorded = recorded;
+        S.last_step_norm = last_step_norm;
+        if (result == LM_EVAL) {
+#pragma unroll
+            for (int i = 0; i < 7; i++) S.cand[i] = cand[i];
+            S.model_change = model_change;
+        } else {
+            S.cost = S.N.cost;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    return result;
+}
+
 struct LmInit {
     float t[3], q[4];   // initial guess (cloud_matcher.cpp:107), used when `first`
     double prior_b[3];  // NormalPrior anchor = the guess's translation (:153)
@@ -818,7 +1143,7 @@ __global__ __launch_bounds__(kEvalThreads) void k_lm(const MatchRec *__restrict_
     __shared__ LmState s_lm;
     __shared__ int s_action, s_failed;
     if (!first_outer && (state->finished | state->error)) return;  // chained launch after the end
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t nb = gridDim.x;
     const uint32_t first = blockIdx.x * blockDim.x + tid, step = nb * blockDim.x;
     // this lane's first point stays in registers for every evaluation of the solve
@@ -845,7 +1170,7 @@ __global__ __launch_bounds__(kEvalThreads) void k_lm(const MatchRec *__restrict_
     int action = LM_EVAL;
     // LOM_DEBUG_LM: shader-clock stamps of workgroup 0's first lane, 5 per evaluation
 #define LM_STAMP(k)                                                                            \
-    if (dbg_stamps && blockIdx.x == 0 && tid == 0 && ev < 6) {                                 \
+    if (dbg_stamps && blockIdx.x == 0 && tid == 0 && ev < 5) {                                 \
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                            \
         dbg_stamps[ev * 5 + (k)] = __builtin_amdgcn_s_memtime();                               \
     }
@@ -857,7 +1182,7 @@ __global__ __launch_bounds__(kEvalThreads) void k_lm(const MatchRec *__restrict_
         seq++;
         XWord *set = xrec + (size_t)(seq & 1) * kMaxLmBlocks * kRecWords;
         reduce_and_exchange(acc, s_acc, s_cnt, s_part, block_counters, counters_from, set, nb, seq, timeout_ticks,
-                            s_tot, &s_failed);
+                            s_tot, &s_failed, (dbg_stamps && ev == 1) ? dbg_stamps + 32 : nullptr);
         counters_from = 0;
         LM_STAMP(2);
         LM_STAMP(3);
@@ -869,25 +1194,22 @@ __global__ __launch_bounds__(kEvalThreads) void k_lm(const MatchRec *__restrict_
             return;
         }
         LM_STAMP(3);
-        if (tid == 0) {
-            LmState S;
+        if (wave == 0) {
+            // the policy (lm_core.hpp's, lane-parallel: lmw_* below) on the state in LDS
+            int a;
             if (ev == 0) {
-                counters[0] = s_tot[28];
-                counters[1] = s_tot[29];
-                counters[2] = s_tot[30];
-                double x[7];
-#pragma unroll
-                for (int i = 0; i < 7; i++) x[i] = s_x[i];
-                action = lm_begin_head(S, s_tot, x, init.prior_b);
+                if (lane == 0) {
+                    counters[0] = s_tot[28];
+                    counters[1] = s_tot[29];
+                    counters[2] = s_tot[30];
+                }
+                a = lmw_begin(s_lm, s_tot, s_x, init.prior_b, lane);
             } else {
-                S = s_lm;
-                action = lm_feed_head(S, s_tot);
+                a = lmw_feed(s_lm, s_tot, lane);
             }
-            if (action == LM_PROPOSE) action = lm_propose(S);
-            s_lm = S;
-#pragma unroll
-            for (int i = 0; i < 7; i++) s_x[i] = S.cand[i];
-            s_action = action;
+            if (a == LM_PROPOSE) a = lmw_propose(s_lm, lane);
+            if (lane < 7) s_x[lane] = s_lm.cand[lane];
+            if (lane == 0) s_action = a;
         }
         LM_STAMP(4);
         __syncthreads();
@@ -1286,7 +1608,7 @@ static int align_chained(lom_map *m, const char *d_src, size_t n, size_t stride,
     if (getenv("LOM_DEBUG_LM")) {
         if ((rc = ensure(m, m->scr[0], 4096)) != LOM_OK) return rc;
         dbg = (unsigned long long *)m->scr[0].p;
-        LOM_HIP(m, hipMemsetAsync(dbg, 0, 30 * 8, m->stream));
+        LOM_HIP(m, hipMemsetAsync(dbg, 0, 40 * 8, m->stream));
     }
     auto launch_pair = [&]() -> int {
         const int i = launched;
@@ -1299,6 +1621,7 @@ static int align_chained(lom_map *m, const char *d_src, size_t n, size_t stride,
                            (const uint32_t *)d_block_counters(m), c.match_blocks, (XWord *)m->xrec.p, m->lm_seq,
                            reinterpret_cast<AlignReport *>(m->d_report), seq0 + (unsigned long long)i + 1,
                            server_timeout_ticks(), dbg);
+        (void)0;
         LOM_HIP(m, hipGetLastError());
         c.launch_s += now_s() - t_l;
         launched++;
@@ -1370,10 +1693,12 @@ static int align_chained(lom_map *m, const char *d_src, size_t n, size_t stride,
     st.host_wait_ms = c.wait_s * 1e3;
     if (stats) *stats = st;
     if (dbg) {
-        unsigned long long h[30];
+        unsigned long long h[40];
         LOM_HIP(m, hipMemcpyAsync(h, dbg, sizeof h, hipMemcpyDeviceToHost, m->stream));
         LOM_HIP(m, hipStreamSynchronize(m->stream));
-        for (int ev = 0; ev < 6 && h[ev * 5]; ev++)
+        fprintf(stderr, "k_lm eval 1 reduce+exchange: LDS rows %llu, publish %llu, gather %llu, final sum %llu cycles\n",
+                h[33] - h[32], h[34] - h[33], h[35] - h[34], h[36] - h[35]);
+        for (int ev = 0; ev < 5 && h[ev * 5]; ev++)
             fprintf(stderr, "k_lm eval %d: at %llu: accumulate %llu reduce+exchange %llu policy %llu cycles\n", ev,
                     h[ev * 5] - h[0], h[ev * 5 + 1] - h[ev * 5], h[ev * 5 + 2] - h[ev * 5 + 1],
                     h[ev * 5 + 4] - h[ev * 5 + 3]);

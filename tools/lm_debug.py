@@ -12,5 +12,6 @@ guess = lom.Pose3D((0.05, -0.04, 0.02), (0.99996, 0.0, 0.0017, 0.0087))
 for i in range(3):
     p = m.align(g, scan, guess)
 os.environ["LOM_DEBUG_LM"] = "1"
+if os.environ.get("LOM_EXP_DUMMY"): os.environ["LOM_TEST_SERVER_TIMEOUT_TICKS"] = "12345"
 p = m.align(g, scan, guess)
 print(m.stats)
