@@ -85,7 +85,7 @@ class VoxelGrid:
 
     def __del__(self):
         h = getattr(self, "_h", None)
-        if h:
+        if h and capi is not None:          # at interpreter shutdown the module may already be gone
             capi.lib().lom_map_destroy(h)
             self._h = None
 
@@ -300,7 +300,7 @@ class LidarOdometry:
 
     def __del__(self):
         h = getattr(self, "_h", None)
-        if h:
+        if h and capi is not None:
             capi.lib().lom_odometry_destroy(h)
             self._h = None
 

@@ -672,10 +672,12 @@ __device__ __forceinline__ void xword_store(XWord *dst, double v, unsigned long 
 // k_lm's evaluation epilogue: workgroup reduction of the 28 per-lane sums through LDS in a fixed
 // order, every row total published straight from the lane that holds it (plus the workgroup's
 // slice of k_match's counters), then all workgroups' words gathered and added in workgroup order
-// into s_tot[0..30] -- bitwise the same on every workgroup.
+// into s_tot[0..30] -- bitwise the same on every workgroup.  Only the first wave may read s_tot
+// afterwards (no workgroup barrier behind the final sum); the caller's next __syncthreads()
+// releases s_acc / s_part for the following evaluation.
 //   s_acc: dynamic LDS, 28 rows of kAccStride doubles;  s_part: kEvalThreads doubles.
-__device__ __forceinline__ void reduce_and_exchange(const double acc[28], double *s_acc, unsigned long long *s_cnt,
-                                                    double *s_part, const uint32_t *__restrict__ block_counters,
+__device__ __forceinline__ void reduce_and_exchange(const double acc[28], double *s_acc, double *s_part,
+                                                    const uint32_t *__restrict__ block_counters,
                                                     uint32_t n_match_blocks, XWord *set, uint32_t nb,
                                                     unsigned long long seq, unsigned long long timeout_ticks,
                                                     double *s_tot, int *s_failed, unsigned long long *dbg = nullptr)
@@ -765,13 +767,17 @@ __device__ __forceinline__ void reduce_and_exchange(const double acc[28], double
     }
     RX_STAMP(3);
     __syncthreads();
-    if (tid < 31) {
-        double v = 0.0;
+    if (tid < 64) {  // the first wave adds the 16 partial sums in order and keeps the totals to itself
+        if (tid < 31) {
+            double v = 0.0;
 #pragma unroll
-        for (int g = 0; g < kEvalThreads / 32; g++) v += s_part[g * 32 + tid];
-        s_tot[tid] = v;
+            for (int g = 0; g < kEvalThreads / 32; g++) v += s_part[g * 32 + tid];
+            s_tot[tid] = v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    __syncthreads();  // s_acc / s_part may be rewritten by the next evaluation; s_tot is complete
     RX_STAMP(4);
 #undef RX_STAMP
 }
@@ -1136,7 +1142,6 @@ __global__ __launch_bounds__(kEvalThreads) void k_lm(const MatchRec *__restrict_
                                                      unsigned long long *dbg_stamps)
 {
     extern __shared__ __attribute__((aligned(16))) double s_acc[];
-    __shared__ unsigned long long s_cnt[3];
     __shared__ double s_tot[kRecWords];
     __shared__ double s_part[kEvalThreads];
     __shared__ double s_x[7];
@@ -1168,7 +1173,8 @@ __global__ __launch_bounds__(kEvalThreads) void k_lm(const MatchRec *__restrict_
     uint32_t counters_from = n_match_blocks;  // k_match's counters are folded by the first evaluation only
     double counters[3] = {0.0, 0.0, 0.0};
     int action = LM_EVAL;
-    // LOM_DEBUG_LM: shader-clock stamps of workgroup 0's first lane, 5 per evaluation
+    // LOM_DEBUG_LM: shader-clock stamps of workgroup 0's first lane (0 start, 1 accumulated,
+    // 3 totals known, 4 policy done); entries of different launches of one align overwrite each other
 #define LM_STAMP(k)                                                                            \
     if (dbg_stamps && blockIdx.x == 0 && tid == 0 && ev < 5) {                                 \
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                            \
@@ -1181,21 +1187,13 @@ __global__ __launch_bounds__(kEvalThreads) void k_lm(const MatchRec *__restrict_
         LM_STAMP(1);
         seq++;
         XWord *set = xrec + (size_t)(seq & 1) * kMaxLmBlocks * kRecWords;
-        reduce_and_exchange(acc, s_acc, s_cnt, s_part, block_counters, counters_from, set, nb, seq, timeout_ticks,
+        reduce_and_exchange(acc, s_acc, s_part, block_counters, counters_from, set, nb, seq, timeout_ticks,
                             s_tot, &s_failed, (dbg_stamps && ev == 1) ? dbg_stamps + 32 : nullptr);
         counters_from = 0;
-        LM_STAMP(2);
         LM_STAMP(3);
-        if (s_failed) {  // uniform over the workgroup
-            if (tid == 0) {
-                __hip_atomic_store(&state->error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&report->error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-            return;
-        }
-        LM_STAMP(3);
-        if (wave == 0) {
-            // the policy (lm_core.hpp's, lane-parallel: lmw_* below) on the state in LDS
+        if (wave == 0 && !s_failed) {
+            // the first wave holds the totals (s_tot) and runs the policy (lm_core.hpp's,
+            // lane-parallel: lmw_* above) on the state in LDS
             int a;
             if (ev == 0) {
                 if (lane == 0) {
@@ -1213,6 +1211,13 @@ __global__ __launch_bounds__(kEvalThreads) void k_lm(const MatchRec *__restrict_
         }
         LM_STAMP(4);
         __syncthreads();
+        if (s_failed) {  // uniform over the workgroup
+            if (tid == 0) {
+                __hip_atomic_store(&state->error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&report->error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            return;
+        }
         action = s_action;
     }
 #undef LM_STAMP
@@ -1700,7 +1705,7 @@ static int align_chained(lom_map *m, const char *d_src, size_t n, size_t stride,
                 h[33] - h[32], h[34] - h[33], h[35] - h[34], h[36] - h[35]);
         for (int ev = 0; ev < 5 && h[ev * 5]; ev++)
             fprintf(stderr, "k_lm eval %d: at %llu: accumulate %llu reduce+exchange %llu policy %llu cycles\n", ev,
-                    h[ev * 5] - h[0], h[ev * 5 + 1] - h[ev * 5], h[ev * 5 + 2] - h[ev * 5 + 1],
+                    h[ev * 5] - h[0], h[ev * 5 + 1] - h[ev * 5], h[ev * 5 + 3] - h[ev * 5 + 1],
                     h[ev * 5 + 4] - h[ev * 5 + 3]);
     }
     return LOM_OK;
