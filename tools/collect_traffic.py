@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Turn the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs, as
+MI355X_MICROARCH.md prescribes) of `bench.py --steps 5 --warmup 1 --no-cpu-baseline` into
+profiles/traffic_<tag>.json:   collect_traffic.py <fetch_dir> <write_dir> <out.json>
+
+FETCH_SIZE / WRITE_SIZE count kilobytes.  On gfx950 FETCH_SIZE under-counts 16-B/lane streams by
+1/2 (guide, HBM section; checked in this repo on k_eval's clean stream, profiles history r01_c), so
+it is doubled.  k_lm's reading is reported next to its known record stream, but k_lm also issues
+agent-coherent exchange loads and is not used for calibration."""
+import csv, glob, json, os, sys
+from collections import defaultdict
+
+
+def per_kernel(root, counter):
+    acc = defaultdict(list)
+    for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
+        with open(f) as fh:
+            for r in csv.DictReader(fh):
+                if r["Counter_Name"] != counter:
+                    continue
+                name = r["Kernel_Name"]
+                key = "k_match" if "k_match" in name else ("k_lm" if "k_lm" in name else None)
+                if key:
+                    acc[key].append(float(r["Counter_Value"]))
+    return acc
+
+
+fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
+n_queries = 26642
+out = {"command": "rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE (separate passes) --output-format csv -- "
+                  "python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline",
+       "workload": "C2 (26,642 queries vs 499,975-pt map)", "raw_counters_kb_per_dispatch": {}}
+for name, acc in (("FETCH_SIZE", fetch), ("WRITE_SIZE", write)):
+    for k, v in acc.items():
+        out["raw_counters_kb_per_dispatch"][f"{k}.{name}"] = {
+            "dispatches": len(v), "mean_kb": sum(v) / len(v), "min_kb": min(v), "max_kb": max(v)}
+lm_fetch = sum(fetch["k_lm"]) / len(fetch["k_lm"]) * 1024.0
+known = n_queries * 48.0
+out["calibration"] = ("FETCH_SIZE is doubled as MI355X_MICROARCH.md (HBM section) prescribes for gfx950; the 1/2 factor was "
+                      "checked in this repo on k_eval's clean 16-B/lane stream (1,278,816 B known, 0.57x read; profiles "
+                      f"history r01_c). k_lm is not a clean reference (its record stream of {known:.0f} B plus agent-coherent "
+                      f"exchange loads read {lm_fetch:.0f} B raw), so it is reported but not used for calibration.")
+mf = sum(fetch["k_match"]) / len(fetch["k_match"]) * 1024.0
+mw = sum(write["k_match"]) / len(write["k_match"]) * 1024.0
+out["k_match_fetch_bytes_raw"] = mf
+out["k_match_fetch_bytes_corrected"] = 2.0 * mf
+out["k_match_write_bytes"] = mw
+out["hbm_bytes_per_launch"] = 2.0 * mf + mw
+out["note"] = ("k_match's own loads are 16-B slots and 4-B dwords, a width the guide calls uncalibrated; the corrected "
+               "figure (FETCH_SIZE doubled) is an upper estimate. HBM-side traffic stays below the algorithmic bytes: "
+               "neighbouring queries share voxels in L2 / Infinity Cache, nothing is re-read from HBM.")
+with open(sys.argv[3], "w") as fh:
+    json.dump(out, fh, indent=1)
+print(json.dumps({k: out[k] for k in ("calibration", "hbm_bytes_per_launch")}, indent=1))
