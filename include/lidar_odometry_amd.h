@@ -113,6 +113,23 @@ int64_t lom_map_export(lom_map *m, int mode, float *xyz_out, float *nrm_out, siz
 int64_t lom_voxel_downsample(lom_map *workspace, float voxel_size, const float *xyz, const float *nrm, size_t n,
                              size_t stride_bytes, float *xyz_out, float *nrm_out, size_t cap);
 
+/* ---- device-resident variants: a caller that keeps a frame in HBM (processCloud does) ---- */
+/* Copy host points (and normals) into the handle's device staging buffers; the device pointers
+ * stay valid until the next lom_upload_points / host-input call on this handle.  Records keep the
+ * caller's stride. */
+int lom_upload_points(lom_map *m, const float *xyz, const float *nrm, size_t n, size_t stride_bytes,
+                      const float **d_xyz_out, const float **d_nrm_out);
+/* lom_voxel_downsample with input and output in device memory: returns the number of voxels and
+ * device pointers to packed 12-byte points (and normals, if d_nrm_out != NULL; zero normals when
+ * d_nrm == NULL) inside the workspace handle, valid until the next call on that workspace. */
+int64_t lom_voxel_downsample_device(lom_map *workspace, float voxel_size, const float *d_xyz, const float *d_nrm,
+                                    size_t n, size_t stride_bytes, const float **d_xyz_out,
+                                    const float **d_nrm_out);
+/* lom_transform_points on the device (same f32 arithmetic): packed 12-byte output in the handle's
+ * staging buffers, valid until the next upload / host-input call on this handle. */
+int lom_transform_points_device(lom_map *m, const lom_pose *pose, const float *d_xyz, const float *d_nrm, size_t n,
+                                size_t stride_bytes, const float **d_xyz_out, const float **d_nrm_out);
+
 /* ---- getCorrespondence / findMatchingPairs (voxel_grid.h:164-234) -------- */
 typedef struct {
     int64_t index;   /* voxel_creation_index * max_points + in_voxel_index, or -1 */
@@ -192,6 +209,8 @@ int lom_profile_match(lom_map *m, const float *d_src_xyz, size_t n, size_t strid
                       double *algorithmic_bytes_out, double *requested_bytes_out);
 /* run the handle's work on a caller-owned hipStream_t (NULL = handle's own stream) */
 int lom_map_set_stream(lom_map *m, void *hip_stream);
+/* the hipStream_t the handle currently works on (to put several handles on one stream) */
+void *lom_map_get_stream(lom_map *m);
 
 /* ---- multi-GPU: source points range-sharded, map replicated ------------- */
 /* One all-gather of LOM_NSUMS f64 per residual evaluation over RCCL, summed in

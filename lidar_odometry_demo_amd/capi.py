@@ -96,7 +96,8 @@ EXPORTED = [
     "lom_pose_relative_to", "lom_pose_rotation_matrix", "lom_transform_points", "lom_map_create",
     "lom_map_destroy", "lom_last_error", "lom_map_clear", "lom_map_set_max_points", "lom_map_add_points",
     "lom_map_add_points_device", "lom_map_radius_cleanup", "lom_map_size", "lom_map_point_count",
-    "lom_map_export", "lom_voxel_downsample", "lom_match_find_pairs", "lom_match_align", "lom_match_align_device", "lom_match_align_repeat", "lom_debug_match_stamps",
+    "lom_map_export", "lom_voxel_downsample", "lom_voxel_downsample_device", "lom_upload_points",
+    "lom_transform_points_device", "lom_map_get_stream", "lom_match_find_pairs", "lom_match_align", "lom_match_align_device", "lom_match_align_repeat", "lom_debug_match_stamps",
     "lom_map_set_profiling", "lom_profile_match", "lom_map_set_stream", "lom_comm_unique_id", "lom_comm_init",
     "lom_comm_finalize", "lom_comm_host_id", "lom_host_comm_create", "lom_host_comm_allreduce",
     "lom_host_comm_destroy", "lom_comm_attach_host", "lom_align_with_hooks", "lom_point_time_normalize", "lom_transform_non_rigid",
@@ -169,6 +170,14 @@ def lib():
     L.lom_map_export.restype = C.c_int64
     L.lom_voxel_downsample.argtypes = [vp, C.c_float, vp, vp, C.c_size_t, C.c_size_t, vp, vp, C.c_size_t]
     L.lom_voxel_downsample.restype = C.c_int64
+    L.lom_voxel_downsample_device.argtypes = [vp, C.c_float, vp, vp, C.c_size_t, C.c_size_t, C.POINTER(vp), C.POINTER(vp)]
+    L.lom_voxel_downsample_device.restype = C.c_int64
+    L.lom_upload_points.argtypes = [vp, vp, vp, C.c_size_t, C.c_size_t, C.POINTER(vp), C.POINTER(vp)]
+    L.lom_upload_points.restype = C.c_int
+    L.lom_transform_points_device.argtypes = [vp, vp, vp, vp, C.c_size_t, C.c_size_t, C.POINTER(vp), C.POINTER(vp)]
+    L.lom_transform_points_device.restype = C.c_int
+    L.lom_map_get_stream.argtypes = [vp]
+    L.lom_map_get_stream.restype = vp
     L.lom_match_find_pairs.argtypes = [vp, vp, C.c_size_t, C.c_size_t, fp, fp, C.c_float, vp]
     L.lom_match_find_pairs.restype = C.c_int64
     L.lom_match_align.argtypes = [vp, vp, C.c_size_t, C.c_size_t, fp, fp, fp, fp, C.POINTER(AlignStats)]

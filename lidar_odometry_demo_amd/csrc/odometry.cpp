@@ -447,6 +447,10 @@ int lom_odometry_create(const lom_odometry_params *params, int device, lom_odome
                             &o->keyframe);  // :18-19
     if (rc == LOM_OK) rc = lom_map_create(params->keyframe_update_voxel_size, 1, 1 << 15, device, &o->update_ds);
     if (rc == LOM_OK) rc = lom_map_create(params->keyframe_matching_voxel_size, 1, 1 << 14, device, &o->matching_ds);
+    // one stream for the three handles: a frame stays in HBM from the upload of the filtered cloud to
+    // the keyframe update, each step consuming the previous one's device buffers in stream order
+    if (rc == LOM_OK) rc = lom_map_set_stream(o->update_ds, lom_map_get_stream(o->keyframe));
+    if (rc == LOM_OK) rc = lom_map_set_stream(o->matching_ds, lom_map_get_stream(o->keyframe));
     if (rc != LOM_OK) {
         lom_odometry_destroy(o);
         return rc;
@@ -458,9 +462,9 @@ int lom_odometry_create(const lom_odometry_params *params, int device, lom_odome
 void lom_odometry_destroy(lom_odometry *o)
 {
     if (!o) return;
-    lom_map_destroy(o->keyframe);
-    lom_map_destroy(o->update_ds);
+    lom_map_destroy(o->update_ds);  // the down-samplers run on the keyframe handle's stream: they go first
     lom_map_destroy(o->matching_ds);
+    lom_map_destroy(o->keyframe);
     delete o;
 }
 
@@ -513,32 +517,37 @@ int lom_odometry_process_cloud(lom_odometry *o, const lom_point_xyzirt *pts, siz
         o->last.filtered_points = (int64_t)nf;
         tm.lap("classify+filter");
         int rc;
+        // From here on the frame lives in HBM: one upload of the filtered cloud, both down-samplers,
+        // the align, the rigid transform and the keyframe update consume device buffers in stream order.
+        const float *d_fx = nullptr, *d_fn = nullptr;
+        if ((rc = lom_upload_points(o->update_ds, o->filtered.data(), o->filtered_n.data(), nf, 12, &d_fx, &d_fn)) !=
+            LOM_OK)
+            return fail(rc, o->update_ds);
         // VoxelGrid keyframe_downsampler(update_voxel_size, 1); addCloud(filtered); getCloud()   :37-38,42,69
-        o->down.resize((nf ? nf : 1) * 3);
-        o->down_n.resize((nf ? nf : 1) * 3);
-        const int64_t nd = lom_voxel_downsample(o->update_ds, o->cfg.keyframe_update_voxel_size, o->filtered.data(),
-                                                o->filtered_n.data(), nf, 12, o->down.data(), o->down_n.data(), nf);
+        const float *d_down = nullptr, *d_down_n = nullptr;
+        const int64_t nd = lom_voxel_downsample_device(o->update_ds, o->cfg.keyframe_update_voxel_size, d_fx, d_fn, nf,
+                                                       12, &d_down, &d_down_n);
         if (nd < 0) return fail((int)nd, o->update_ds);
         o->last.update_points = nd;
         tm.lap("update_ds");
         if (lom_map_size(o->keyframe) == 0) {  // :40-44 init keyframe
-            if ((rc = lom_map_add_points(o->keyframe, o->down.data(), o->down_n.data(), (size_t)nd, 12)) != LOM_OK)
+            if ((rc = lom_map_add_points_device(o->keyframe, d_down, d_down_n, (size_t)nd, 12)) != LOM_OK)
                 return fail(rc, o->keyframe);
             o->last.initialised_keyframe = 1;
             o->last.keyframe_voxels = lom_map_size(o->keyframe);
             return LOM_OK;
         }
         // VoxelGrid matching_downsampler(matching_voxel_size, 1); addCloud(filtered); getCloudWithoutNormals()   :46-47,50
-        o->match.resize((nf ? nf : 1) * 3);
-        const int64_t nm = lom_voxel_downsample(o->matching_ds, o->cfg.keyframe_matching_voxel_size,
-                                                o->filtered.data(), nullptr, nf, 12, o->match.data(), nullptr, nf);
+        const float *d_match = nullptr;
+        const int64_t nm = lom_voxel_downsample_device(o->matching_ds, o->cfg.keyframe_matching_voxel_size, d_fx,
+                                                       nullptr, nf, 12, &d_match, nullptr);
         if (nm < 0) return fail((int)nm, o->matching_ds);
         o->last.matching_points = nm;
         tm.lap("matching_ds");
         lom_pose_compose(&o->current, &relative, &guess);  // :51
         lom_align_stats ast;
-        if ((rc = lom_match_align(o->keyframe, o->match.data(), (size_t)nm, 12, guess.t, guess.q, result.t, result.q,
-                                  &ast)) != LOM_OK)  // :49-51
+        if ((rc = lom_match_align_device(o->keyframe, d_match, (size_t)nm, 12, guess.t, guess.q, result.t, result.q,
+                                         &ast)) != LOM_OK)  // :49-51
             return fail(rc, o->keyframe);
         o->last.outer_iterations = ast.outer_iterations;
         o->last.queries = ast.queries;
@@ -558,11 +567,11 @@ int lom_odometry_process_cloud(lom_odometry *o, const lom_point_xyzirt *pts, siz
         if ((rc = lom_map_radius_cleanup(o->keyframe, o->current.t, o->cfg.keyframe_cleanup_range)) != LOM_OK)  // :67
             return fail(rc, o->keyframe);
         tm.lap("cleanup");
-        o->upd.resize((size_t)(nd ? nd : 1) * 3);
-        o->upd_n.resize((size_t)(nd ? nd : 1) * 3);
-        lom_transform_points(&o->current, o->down.data(), o->down_n.data(), (size_t)nd, 12, o->upd.data(),
-                             o->upd_n.data(), 12);  // :69
-        if ((rc = lom_map_add_points(o->keyframe, o->upd.data(), o->upd_n.data(), (size_t)nd, 12)) != LOM_OK)  // :70
+        const float *d_upd = nullptr, *d_upd_n = nullptr;
+        if ((rc = lom_transform_points_device(o->keyframe, &o->current, d_down, d_down_n, (size_t)nd, 12, &d_upd,
+                                              &d_upd_n)) != LOM_OK)  // :69
+            return fail(rc, o->keyframe);
+        if ((rc = lom_map_add_points_device(o->keyframe, d_upd, d_upd_n, (size_t)nd, 12)) != LOM_OK)  // :70
             return fail(rc, o->keyframe);
         o->last.keyframe_voxels = lom_map_size(o->keyframe);
         tm.lap("keyframe add");

@@ -28,6 +28,7 @@
 #include <new>
 
 #include "lom_internal.hpp"
+#include "pose_math.hpp"
 
 namespace lom {
 
@@ -368,15 +369,17 @@ __global__ void k_ins_finalize(Slot *table, uint32_t n, const uint32_t *pt_slot,
 // index is that minimum, compact them by a scan over the input.  No payload slabs are touched.
 // ---------------------------------------------------------------------------
 __global__ void k_ds_claim(Slot *table, uint32_t mask, uint32_t shift, const char *xyz, size_t stride, uint32_t n,
-                           float vs, uint32_t *pt_slot, uint32_t *head)
+                           float vs, uint32_t *pt_slot, uint32_t *head, uint32_t *bad)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float *p = point_at(xyz, i, stride);
     int ix = 0, iy = 0, iz = 0;
-    voxel_index(p[0], vs, ix);
-    voxel_index(p[1], vs, iy);
-    voxel_index(p[2], vs, iz);
+    if (!voxel_index(p[0], vs, ix) || !voxel_index(p[1], vs, iy) || !voxel_index(p[2], vs, iz)) {
+        *bad = 1u;  // out of range / not finite: the call fails, nothing is returned
+        pt_slot[i] = 0xFFFFFFFFu;
+        return;
+    }
     const uint32_t h = claim_slot(table, mask, shift, pack_key(ix, iy, iz));
     pt_slot[i] = h;
     atomicMin(&head[h], i);
@@ -385,7 +388,36 @@ __global__ void k_ds_claim(Slot *table, uint32_t mask, uint32_t shift, const cha
 __global__ void k_ds_flag(uint32_t n, const uint32_t *pt_slot, const uint32_t *head, uint32_t *flag)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) flag[i] = head[pt_slot[i]] == i ? 1u : 0u;
+    if (i < n) {
+        const uint32_t h = pt_slot[i];
+        flag[i] = (h != 0xFFFFFFFFu && head[h] == i) ? 1u : 0u;
+    }
+}
+
+// CloudTransformer::transform / transformWithNormals (utils/cloud_transform.h:43-97) on the device:
+// the same f32 expressions as lom_transform_points, R and t prepared on the host
+struct RigidArgs {
+    float R[9], t[3];
+};
+__global__ void k_transform(const char *xyz, const char *nrm, size_t stride, uint32_t n, RigidArgs A, float *out_xyz,
+                            float *out_nrm)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float *p = point_at(xyz, i, stride);
+    const float p0 = p[0], p1 = p[1], p2 = p[2];
+    float *o = out_xyz + (size_t)i * 3;
+    o[0] = (A.R[0] * p0 + (A.R[1] * p1 + A.R[2] * p2)) + A.t[0];
+    o[1] = (A.R[3] * p0 + (A.R[4] * p1 + A.R[5] * p2)) + A.t[1];
+    o[2] = (A.R[6] * p0 + (A.R[7] * p1 + A.R[8] * p2)) + A.t[2];
+    if (nrm && out_nrm) {
+        const float *q = point_at(nrm, i, stride);
+        const float n0 = q[0], n1 = q[1], n2 = q[2];
+        float *no = out_nrm + (size_t)i * 3;
+        no[0] = A.R[0] * n0 + (A.R[1] * n1 + A.R[2] * n2);
+        no[1] = A.R[3] * n0 + (A.R[4] * n1 + A.R[5] * n2);
+        no[2] = A.R[6] * n0 + (A.R[7] * n1 + A.R[8] * n2);
+    }
 }
 
 __global__ void k_ds_write(uint32_t n, const uint32_t *flag, const uint32_t *rank, const char *xyz, const char *nrm,
@@ -1054,28 +1086,15 @@ int64_t lom_map_point_count(const lom_map *cm)
     return lom_map_export(const_cast<lom_map *>(cm), LOM_EXPORT_FULL_NO_NORMALS, nullptr, nullptr, 0);
 }
 
-int64_t lom_voxel_downsample(lom_map *ws, float voxel_size, const float *xyz, const float *nrm, size_t n,
-                             size_t stride, float *xyz_out, float *nrm_out, size_t cap)
+// shared body of the down-samplers: device input, results left in the workspace's scratch
+// (S_ITEMS: xyz, S_PT_POS: normals), voxel count in word 4, range flag in word 5 of S_MISC
+static int downsample_core(lom_map *m, float voxel_size, const char *dx, const char *dn, uint32_t N, size_t stride,
+                           bool want_normals)
 {
-    lom_map *m = ws;
-    if (!m || !(voxel_size > 0.f) || (n && !xyz) || stride < 12 || (stride & 3) || (n && !xyz_out)) return LOM_ERR_ARG;
-    if (n >= 0x7FFFFFFFull) return LOM_ERR_ARG;
-    LOM_HIP(m, hipSetDevice(m->device));
-    int rc = lom_map_clear(m, voxel_size);  // the workspace grid ends up cleared, like a fresh VoxelGrid(voxel, 1)
-    if (rc != LOM_OK || n == 0) return rc;
-    const uint32_t N = (uint32_t)n;
-    for (size_t i = 0; i < n; i++) {  // same range rule as addCloud (host-resident input: checked here)
-        const float *p = reinterpret_cast<const float *>(reinterpret_cast<const char *>(xyz) + i * stride);
-        const float fx = p[0] / voxel_size, fy = p[1] / voxel_size, fz = p[2] / voxel_size;
-        if (!(fx > -kIdxLimit && fx < kIdxLimit) || !(fy > -kIdxLimit && fy < kIdxLimit) ||
-            !(fz > -kIdxLimit && fz < kIdxLimit))
-            return set_error(m, LOM_ERR_RANGE, "coordinate / voxel_size out of range or not finite");
-    }
+    int rc;
     if ((uint64_t)m->cap < 2ull * N) {
         if ((rc = rehash(m, next_pow2(4ull * N))) != LOM_OK) return rc;
     }
-    const char *dx = nullptr, *dn = nullptr;
-    if ((rc = stage_host_points(m, xyz, nrm, n, stride, &dx, &dn)) != LOM_OK) return rc;
     if ((rc = ensure(m, m->scr[S_PT_SLOT], (size_t)N * 4)) != LOM_OK) return rc;
     if ((rc = ensure(m, m->scr[S_FLAG], (size_t)N * 4)) != LOM_OK) return rc;
     if ((rc = ensure(m, m->scr[S_RANK], (size_t)N * 4)) != LOM_OK) return rc;
@@ -1085,30 +1104,110 @@ int64_t lom_voxel_downsample(lom_map *ws, float voxel_size, const float *xyz, co
     if ((rc = ensure(m, m->scr[S_PT_POS], (size_t)N * 12)) != LOM_OK) return rc;    // compacted normals
     uint32_t *pt_slot = (uint32_t *)m->scr[S_PT_SLOT].p, *flag = (uint32_t *)m->scr[S_FLAG].p;
     uint32_t *rank = (uint32_t *)m->scr[S_RANK].p, *head = (uint32_t *)m->scr[S_BKT_HEAD].p;
-    float *oxyz = (float *)m->scr[S_ITEMS].p, *onrm = nrm_out ? (float *)m->scr[S_PT_POS].p : nullptr;
+    float *oxyz = (float *)m->scr[S_ITEMS].p, *onrm = want_normals ? (float *)m->scr[S_PT_POS].p : nullptr;
     LOM_HIP(m, hipMemsetAsync(head, 0xFF, (size_t)m->cap * 4, m->stream));
+    LOM_HIP(m, hipMemsetAsync(d_word(m, 5), 0, 4, m->stream));
     const MapView v = view_of(m);
     const dim3 g(blocks_for(N)), b(kThreads);
     hipLaunchKernelGGL(k_ds_claim, g, b, 0, m->stream, m->d_table, v.mask, v.shift, dx, stride, N, voxel_size, pt_slot,
-                       head);
+                       head, d_word(m, 5));
     hipLaunchKernelGGL(k_ds_flag, g, b, 0, m->stream, N, pt_slot, head, flag);
     LOM_HIP(m, hipGetLastError());
     if ((rc = scan_exclusive(m, flag, rank, N, d_word(m, 4), (uint32_t *)m->scr[S_SCAN].p)) != LOM_OK) return rc;
     hipLaunchKernelGGL(k_ds_write, g, b, 0, m->stream, N, flag, rank, dx, dn, stride, oxyz, onrm);
-    LOM_HIP(m, hipGetLastError());
-    if ((rc = read_words(m, 4, 1)) != LOM_OK) return rc;
-    const size_t total = m->h_flags[0];
-    const size_t take = std::min(total, cap);
-    if (take) {
-        LOM_HIP(m, hipMemcpyAsync(xyz_out, oxyz, take * 12, hipMemcpyDeviceToHost, m->stream));
-        if (nrm_out) LOM_HIP(m, hipMemcpyAsync(nrm_out, onrm, take * 12, hipMemcpyDeviceToHost, m->stream));
-    }
     // leave the workspace empty again (its table holds claimed keys without payload)
     hipLaunchKernelGGL(k_table_init, dim3(blocks_for(m->cap)), dim3(kThreads), 0, m->stream, m->d_table, m->cap);
     LOM_HIP(m, hipGetLastError());
-    LOM_HIP(m, hipStreamSynchronize(m->stream));
+    if ((rc = read_words(m, 4, 2)) != LOM_OK) return rc;  // [0] voxels, [1] range flag
+    if (m->h_flags[1]) return set_error(m, LOM_ERR_RANGE, "coordinate / voxel_size out of range or not finite");
+    return LOM_OK;
+}
+
+int64_t lom_voxel_downsample(lom_map *ws, float voxel_size, const float *xyz, const float *nrm, size_t n,
+                             size_t stride, float *xyz_out, float *nrm_out, size_t cap)
+{
+    lom_map *m = ws;
+    if (!m || !(voxel_size > 0.f) || (n && !xyz) || stride < 12 || (stride & 3) || (n && !xyz_out)) return LOM_ERR_ARG;
+    if (n >= 0x7FFFFFFFull) return LOM_ERR_ARG;
+    LOM_HIP(m, hipSetDevice(m->device));
+    int rc = lom_map_clear(m, voxel_size);  // the workspace grid ends up cleared, like a fresh VoxelGrid(voxel, 1)
+    if (rc != LOM_OK || n == 0) return rc;
+    const char *dx = nullptr, *dn = nullptr;
+    if ((rc = stage_host_points(m, xyz, nrm, n, stride, &dx, &dn)) != LOM_OK) return rc;
+    // the range rule of addCloud is checked by the claim kernel (flag read back with the count)
+    if ((rc = downsample_core(m, voxel_size, dx, dn, (uint32_t)n, stride, nrm_out != nullptr)) != LOM_OK) return rc;
+    const size_t total = m->h_flags[0];
+    const size_t take = std::min(total, cap);
+    if (take) {
+        LOM_HIP(m, hipMemcpyAsync(xyz_out, m->scr[S_ITEMS].p, take * 12, hipMemcpyDeviceToHost, m->stream));
+        if (nrm_out)
+            LOM_HIP(m, hipMemcpyAsync(nrm_out, m->scr[S_PT_POS].p, take * 12, hipMemcpyDeviceToHost, m->stream));
+        LOM_HIP(m, hipStreamSynchronize(m->stream));
+    }
     return (int64_t)total;
 }
+
+int64_t lom_voxel_downsample_device(lom_map *ws, float voxel_size, const float *d_xyz, const float *d_nrm, size_t n,
+                                    size_t stride, const float **d_xyz_out, const float **d_nrm_out)
+{
+    lom_map *m = ws;
+    if (!m || !(voxel_size > 0.f) || (n && !d_xyz) || stride < 12 || (stride & 3) || !d_xyz_out) return LOM_ERR_ARG;
+    if (n >= 0x7FFFFFFFull) return LOM_ERR_ARG;
+    LOM_HIP(m, hipSetDevice(m->device));
+    *d_xyz_out = nullptr;
+    if (d_nrm_out) *d_nrm_out = nullptr;
+    int rc = lom_map_clear(m, voxel_size);
+    if (rc != LOM_OK || n == 0) return rc;
+    if ((rc = downsample_core(m, voxel_size, (const char *)d_xyz, (const char *)d_nrm, (uint32_t)n, stride,
+                              d_nrm_out != nullptr)) != LOM_OK)
+        return rc;
+    *d_xyz_out = (const float *)m->scr[S_ITEMS].p;
+    if (d_nrm_out) *d_nrm_out = (const float *)m->scr[S_PT_POS].p;
+    return (int64_t)m->h_flags[0];
+}
+
+int lom_upload_points(lom_map *m, const float *xyz, const float *nrm, size_t n, size_t stride, const float **d_xyz_out,
+                      const float **d_nrm_out)
+{
+    if (!m || (n && !xyz) || stride < 12 || (stride & 3) || !d_xyz_out) return LOM_ERR_ARG;
+    LOM_HIP(m, hipSetDevice(m->device));
+    *d_xyz_out = nullptr;
+    if (d_nrm_out) *d_nrm_out = nullptr;
+    if (n == 0) return LOM_OK;
+    const char *dx = nullptr, *dn = nullptr;
+    const int rc = stage_host_points(m, xyz, nrm, n, stride, &dx, &dn);
+    if (rc != LOM_OK) return rc;
+    *d_xyz_out = (const float *)dx;
+    if (d_nrm_out) *d_nrm_out = (const float *)dn;
+    return LOM_OK;
+}
+
+int lom_transform_points_device(lom_map *m, const lom_pose *pose, const float *d_xyz, const float *d_nrm, size_t n,
+                                size_t stride, const float **d_xyz_out, const float **d_nrm_out)
+{
+    if (!m || !pose || (n && !d_xyz) || stride < 12 || (stride & 3) || !d_xyz_out) return LOM_ERR_ARG;
+    if (n >= 0x7FFFFFFFull) return LOM_ERR_ARG;
+    LOM_HIP(m, hipSetDevice(m->device));
+    *d_xyz_out = nullptr;
+    if (d_nrm_out) *d_nrm_out = nullptr;
+    if (n == 0) return LOM_OK;
+    int rc;
+    const bool with_n = d_nrm && d_nrm_out;
+    if ((rc = ensure(m, m->scr[S_IN_XYZ], n * 12)) != LOM_OK) return rc;
+    if (with_n && (rc = ensure(m, m->scr[S_IN_NRM], n * 12)) != LOM_OK) return rc;
+    RigidArgs A;
+    rotation_matrix(pose->q, A.R);
+    for (int i = 0; i < 3; i++) A.t[i] = pose->t[i];
+    hipLaunchKernelGGL(k_transform, dim3(blocks_for((uint32_t)n)), dim3(kThreads), 0, m->stream, (const char *)d_xyz,
+                       (const char *)d_nrm, stride, (uint32_t)n, A, (float *)m->scr[S_IN_XYZ].p,
+                       with_n ? (float *)m->scr[S_IN_NRM].p : (float *)nullptr);
+    LOM_HIP(m, hipGetLastError());
+    *d_xyz_out = (const float *)m->scr[S_IN_XYZ].p;
+    if (with_n) *d_nrm_out = (const float *)m->scr[S_IN_NRM].p;
+    return LOM_OK;
+}
+
+void *lom_map_get_stream(lom_map *m) { return m ? (void *)m->stream : nullptr; }
 
 int64_t lom_map_export(lom_map *m, int mode, float *xyz_out, float *nrm_out, size_t cap)
 {

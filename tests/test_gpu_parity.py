@@ -324,6 +324,54 @@ def test_align_parity_synth(lom, oracle):
     assert dt < POSE_TOL_M and dr < POSE_TOL_RAD
 
 
+@pytest.mark.parametrize("seed", range(5))
+def test_align_parity_randomized(lom, oracle, seed):
+    """Random sub-scans, voxel sizes (power of two: exact-reciprocal index; others: IEEE division),
+    caps and guess poses -- small guesses converge in the minimum five outer iterations, larger ones
+    need more (the device loop then enqueues pair by pair): same iteration counts, poses within the bar."""
+    rng = np.random.default_rng(500 + seed)
+    sm = scenes.small_synth_case()
+    voxel = float(rng.choice([0.5, 0.37, 1.0, 0.25]))
+    K = int(rng.choice([20, 7, 33]))
+    g, og = _both(lom, oracle, voxel, K)
+    g.addCloud(sm["map_xyz"], sm["map_nrm"])
+    og.addCloud(sm["map_xyz"], sm["map_nrm"])
+    m, om = lom.CloudMatcher(), oracle.CloudMatcher()
+    outers = []
+    for trial in range(4):
+        n = int(rng.choice([1, 7, 63, 500, len(sm["scan"])]))
+        sel = np.sort(rng.choice(len(sm["scan"]), n, replace=False))
+        scan = np.ascontiguousarray(sm["scan"][sel])
+        scale = float(rng.choice([0.02, 0.15, 0.25]))
+        t = rng.uniform(-1, 1, 3) * scale
+        q = scenes.angle_axis_q(rng.uniform(-0.2, 0.2) * scale, scenes._unit(rng.standard_normal(3)))
+        got = m.align(g, scan, lom.Pose3D(t, q))
+        ref = om.align(og, scan, oracle.Pose3D(t, q))
+        dt, dr = scenes.pose_delta(got.translation, got.rotation, ref.translation, ref.rotation)
+        assert dt < POSE_TOL_M and dr < POSE_TOL_RAD, (seed, trial, n, voxel, dt, dr)
+        for k in ("outer_iterations", "queries", "cand_total", "occ_total", "valid_last"):
+            assert m.stats[k] == om.stats[k], (seed, trial, k)
+        outers.append(m.stats["outer_iterations"])
+    assert min(outers) >= 5
+
+
+def test_align_beyond_the_five_enqueued_iterations(lom, oracle):
+    """A guess 0.28 m off needs a sixth outer iteration: the device loop enqueues five pairs ahead and
+    then one pair per report until the stop rule fires."""
+    sm = scenes.small_synth_case()
+    g, og = _both(lom, oracle, 0.5, 20)
+    g.addCloud(sm["map_xyz"], sm["map_nrm"])
+    og.addCloud(sm["map_xyz"], sm["map_nrm"])
+    m, om = lom.CloudMatcher(), oracle.CloudMatcher()
+    guess_q = scenes.angle_axis_q(0.01, (0, 0, 1))
+    got = m.align(g, sm["scan"], lom.Pose3D((0.2, -0.2, 0.0), guess_q))
+    ref = om.align(og, sm["scan"], oracle.Pose3D((0.2, -0.2, 0.0), guess_q))
+    assert om.stats["outer_iterations"] > 5
+    assert m.stats["outer_iterations"] == om.stats["outer_iterations"]
+    dt, dr = scenes.pose_delta(got.translation, got.rotation, ref.translation, ref.rotation)
+    assert dt < POSE_TOL_M and dr < POSE_TOL_RAD, (dt, dr)
+
+
 def test_host_driven_path_matches_device_loop(lom, monkeypatch):
     """LOM_HOST_LM=1 keeps the outer loop and the LM policy on the host (resident evaluation server,
     the path the multi-GPU exchange uses); the default single-GPU path runs both on the device.
