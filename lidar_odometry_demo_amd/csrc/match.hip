@@ -216,6 +216,14 @@ __global__ __launch_bounds__(kMatchThreads, kMinWaves) void k_match(MapView map,
     // four fewer live registers keep the kernel at 64 VGPRs without spilling
     if (gl < 4) s_cnt[grp][gl] = 0u;
     const float prune_sq = P.max_sq * 1.0001f;
+    int nb_dx[kSets], nb_dy[kSets], nb_dz[kSets];  // neighbour offsets of this lane, scan order ix, iy, iz
+#pragma unroll
+    for (int s = 0; s < kSets; s++) {
+        const int b = gl + s * G;
+        nb_dx[s] = b / 9 - 1;
+        nb_dy[s] = (b / 3) % 3 - 1;
+        nb_dz[s] = b % 3 - 1;
+    }
 
     for (uint32_t q = blockIdx.x * kGroups + grp; q < n; q += groups_total) {
         const float *sp = reinterpret_cast<const float *>(src + (size_t)q * stride);
@@ -242,7 +250,10 @@ __global__ __launch_bounds__(kMatchThreads, kMinWaves) void k_match(MapView map,
 #pragma unroll
         for (int s = 0; s < kSets; s++) {
             const int b = gl + s * G;
-            const int dx = b / 9 - 1, dy = (b / 3) % 3 - 1, dz = b % 3 - 1;
+            int dx = nb_dx[s], dy = nb_dy[s], dz = nb_dz[s];
+            // keep the lane-constant comparisons below inside the loop: hoisted, their twelve
+            // lane masks do not fit the scalar registers and get spilled lane by lane
+            asm volatile("" : "+v"(dx), "+v"(dy), "+v"(dz));
             const int nx = ix + dx, ny = iy + dy, nz = iz + dz;
             // stored indices lie in (-2^20, 2^20); anything outside cannot exist
             act[s] = inr && b < 27 && nx > -kIdxBias && nx < kIdxBias && ny > -kIdxBias && ny < kIdxBias &&

@@ -1,17 +1,26 @@
-import os, sys
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
-import numpy as np, torch
-import lidar_odometry_demo_amd as lom
-from lidar_odometry_demo_amd import synth
+#!/usr/bin/env python3
+"""Phase stamps of the device-resident solve (k_lm) on the C2 workload: LOM_DEBUG_LM=1 makes the align
+print, for workgroup 0's first lane, the shader-clock cycles of accumulate / reduce+exchange / policy
+per evaluation and the split of one reduce+exchange (stderr).  Entries of the different k_lm launches
+of one align overwrite each other: read them as samples, not as one timeline."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: F401,E402  (shares its HIP runtime with the library)
+import lidar_odometry_demo_amd as lom  # noqa: E402
+from lidar_odometry_demo_amd import synth  # noqa: E402
+
 boxes = synth.make_boxes()
 scan, _, _, _ = synth.make_scan(16, 1800, boxes=boxes)
 mp, mn = synth.make_map_points(500_000, boxes=boxes)
-g = lom.VoxelGrid(0.5, 20); g.addCloud(mp, mn)
+g = lom.VoxelGrid(0.5, 20)
+g.addCloud(mp, mn)
 m = lom.CloudMatcher()
 guess = lom.Pose3D((0.05, -0.04, 0.02), (0.99996, 0.0, 0.0017, 0.0087))
-for i in range(3):
-    p = m.align(g, scan, guess)
+for _ in range(3):
+    m.align(g, scan, guess)
 os.environ["LOM_DEBUG_LM"] = "1"
-if os.environ.get("LOM_EXP_DUMMY"): os.environ["LOM_TEST_SERVER_TIMEOUT_TICKS"] = "12345"
-p = m.align(g, scan, guess)
+m.align(g, scan, guess)
 print(m.stats)
