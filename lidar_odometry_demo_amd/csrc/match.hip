@@ -906,7 +906,7 @@ __device__ __forceinline__ int lmw_begin(LmState &S, const double *first, const 
         S.diag[r] = 0.0;
     }
     if (lane < 7) {
-        S.x[lane] = xs[0] * 0.0 + x[lane];
+        S.x[lane] = x[lane];
         S.cand[lane] = x[lane];
     }
     if (lane < 3) S.prior_b[lane] = prior_b[lane];
@@ -1158,11 +1158,11 @@ __global__ __launch_bounds__(kEvalThreads) void k_lm(const MatchRec *__restrict_
     __shared__ double s_x[7];
     __shared__ LmState s_lm;
     __shared__ int s_action, s_failed;
-    if (!first_outer && (state->finished | state->error)) return;  // chained launch after the end
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t nb = gridDim.x;
     const uint32_t first = blockIdx.x * blockDim.x + tid, step = nb * blockDim.x;
-    // this lane's first point stays in registers for every evaluation of the solve
+    // start-up loads issued together (one memory round trip, not three): this lane's first point --
+    // it stays in registers for every evaluation of the solve --, the pose, the chain's stop flags
     float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra, rc = ra;
     if (first < n) {
         const float4 *r4 = reinterpret_cast<const float4 *>(rec + first);
@@ -1170,14 +1170,15 @@ __global__ __launch_bounds__(kEvalThreads) void k_lm(const MatchRec *__restrict_
         rb = r4[1];
         rc = r4[2];
     }
+    float x0 = 0.f;
     if (tid < 7) {
-        float v;
         if (first_outer)
-            v = tid < 4 ? init.q[tid] : init.t[tid - 4];
+            x0 = tid < 4 ? init.q[tid] : init.t[tid - 4];
         else
-            v = tid < 4 ? state->pose_q[tid] : state->pose_t[tid - 4];
-        s_x[tid] = (double)v;  // cloud_matcher.cpp:122-131
+            x0 = tid < 4 ? state->pose_q[tid] : state->pose_t[tid - 4];
     }
+    if (!first_outer && (state->finished | state->error)) return;  // chained launch after the end
+    if (tid < 7) s_x[tid] = (double)x0;  // cloud_matcher.cpp:122-131
     if (tid == 0) s_failed = 0;
     __syncthreads();
     unsigned long long seq = seq_base;
