@@ -123,6 +123,13 @@ __device__ __forceinline__ unsigned long long row_min_step(unsigned long long k)
 // lane 15 of the row, to every lane of the row (ds_swizzle bit mode: and 0x10, or 0x0F)
 __device__ __forceinline__ uint32_t row_last(uint32_t v) { return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x1F0); }
 
+template <int kCtrl>
+__device__ __forceinline__ double dpp_f64(double v)  // the value of the DPP partner lane
+{
+    return __hiloint2double((int)row_dpp<kCtrl>((uint32_t)__double2hiint(v)),
+                            (int)row_dpp<kCtrl>((uint32_t)__double2loint(v)));
+}
+
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // Two 16-byte slot loads in flight together, each ONE dwordx4 (the compiler otherwise splits a
 // slot into a key load and a dependent count/slab load: two round trips per hit).
@@ -701,8 +708,15 @@ __device__ __forceinline__ void reduce_and_exchange(const double acc[28], double
     RX_STAMP(0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     XWord *mine = set + (size_t)blockIdx.x * kRecWords;
+    // first level in registers: the four lanes of a quad add up (two DPP steps per value), so the
+    // LDS rows are a quarter as long (LDS bandwidth was the bulk of this phase)
 #pragma unroll
-    for (int k = 0; k < 28; k++) s_acc[k * kAccStride + tid] = acc[k];
+    for (int k = 0; k < 28; k++) {
+        double v = acc[k];
+        v += dpp_f64<kDppXor1>(v);
+        v += dpp_f64<kDppXor2>(v);
+        if ((tid & 3) == 0) s_acc[k * kAccStride + (tid >> 2)] = v;
+    }
     if (wave == 7) {  // the last wave carries no row of the reduction below (28 rows x 16 lanes = 448)
         unsigned long long c0 = 0, c1 = 0, c2 = 0;
         if (n_match_blocks) {
@@ -725,17 +739,19 @@ __device__ __forceinline__ void reduce_and_exchange(const double acc[28], double
         if (lane < 3) xword_store(mine + 28 + lane, (double)(lane == 0 ? c0 : (lane == 1 ? c1 : c2)), seq);
     }
     __syncthreads();
-    // thread (k = tid / 16, j = tid % 16) adds row k's elements j, j+16, ... in order
+    // thread (k = tid / 16, j = tid % 16) adds row k's quad sums j, j+16, ... in order
     {
         const int k = tid >> 4, j = tid & 15;
         double v = 0.0;
         if (k < 28) {
             const double *row = s_acc + k * kAccStride + j;
-#pragma unroll 8
-            for (int i = 0; i < kEvalThreads / 16; i++) v += row[i * 16];
-        }
 #pragma unroll
-        for (int d = 8; d >= 1; d >>= 1) v += __shfl_xor(v, d, 16);
+            for (int i = 0; i < kEvalThreads / 64; i++) v += row[i * 16];
+        }
+        v += dpp_f64<kDppXor1>(v);  // the 16 lanes of a row: DPP butterflies, no LDS crossbar
+        v += dpp_f64<kDppXor2>(v);
+        v += dpp_f64<kDppHalfMirror>(v);
+        v += dpp_f64<kDppMirror>(v);
         RX_STAMP(1);
         if (j == 0 && k < 28) xword_store(mine + k, v, seq);
     }
