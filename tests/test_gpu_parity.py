@@ -275,6 +275,27 @@ def test_find_pairs_parity_synth_and_golden(lom, oracle):
                        og.findMatchingPairs(sm["scan"], oracle.Pose3D(*pose), 0.3))
 
 
+def test_find_pairs_at_the_index_range_limit(lom, oracle):
+    """Voxels in the outermost index layer (|i| = 2^20 - 1): their outward neighbours cannot exist;
+    the search must neither wrap nor read them.  Same pairs as the oracle."""
+    voxel = 0.25
+    edge = (2 ** 20 - 1) * voxel                      # first coordinate of the last voxel layer
+    rng = np.random.default_rng(77)
+    base = np.array([edge + 0.1, -edge - 0.1, 0.0])
+    pts = (base + rng.uniform(-0.6, 0.1, (4000, 3)) * np.array([1, -1, 1])).astype(np.float32)
+    pts = pts[(np.abs(pts / np.float32(voxel)) < 2 ** 20).all(axis=1)]
+    nrm = rng.standard_normal((len(pts), 3)).astype(np.float32)
+    g, og = _both(lom, oracle, voxel, 20)
+    g.addCloud(pts, nrm)
+    og.addCloud(pts, nrm)
+    _assert_same_map(g, og)
+    q = (base + rng.uniform(-0.7, 0.12, (3000, 3)) * np.array([1, -1, 1])).astype(np.float32)
+    q = q[(np.abs(q / np.float32(voxel)) < 2 ** 20).all(axis=1)]
+    c, oc = g.findMatchingPairs(q, lom.Pose3D(), 0.3), og.findMatchingPairs(q, oracle.Pose3D(), 0.3)
+    _assert_same_pairs(c, oc)
+    assert (c["index"] >= 0).sum() > 100
+
+
 def test_zero_normals_are_valid_matches(lom):
     g = lom.VoxelGrid(0.5, 20)
     g.addCloudWithoutNormals(scenes.UNIQUE_POINTS)
