@@ -173,6 +173,13 @@ typedef struct {
     double host_wait_ms;       /* host time spent waiting for evaluation results               */
 } lom_align_stats;
 
+/* Replaces CloudMatcher::align (cloud_matcher.h:15-16): up to 35 outer iterations of
+ * {correspondence search, Levenberg-Marquardt solve with max 4 iterations}, f32 pose write-back and
+ * the reference's stop rule.  On one GPU the whole loop runs on the device (a chain of kernels
+ * enqueued ahead of time, pose handed from kernel to kernel in HBM); with an attached exchange
+ * (below) or LOM_HOST_LM=1 in the environment the loop is driven from the host, one round trip per
+ * LM iteration.  Same policy source either way (csrc/lm_core.hpp).  Zero correspondences is not an
+ * error: the prior-only problem is solved and the pose stays at the guess. */
 int lom_match_align(lom_map *m, const float *src_xyz, size_t n, size_t stride_bytes,
                     const float guess_t[3], const float guess_q_wxyz[4], float out_t[3],
                     float out_q_wxyz[4], lom_align_stats *stats_or_null);

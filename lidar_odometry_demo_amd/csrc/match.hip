@@ -7,13 +7,18 @@
 //   k_match   per source point: f64 transform -> f32 query -> 27-neighbour
 //             voxel lookup -> nearest stored point (strict-min, scan order
 //             ix,iy,iz then insertion order) -> winner's point+normal.
-//             HBM/L2-bound gather; no MFMA (nothing here is a contraction).
-//   k_eval    per valid correspondence: r = (q*p + t - o).n, 1x6 tangent
-//             Jacobian, Huber(0.15) IRLS weight; f64 wave reduction of
-//             sum w J J^T (21), sum w J r (6), sum 0.5 rho (1) -> one partial
-//             per workgroup.
-//             Single GPU: the <= 64 records land in pinned host memory and the host
-//             adds them in workgroup order (no second kernel, no copy, no sync).
+//             A gather that is VALU-issue- and latency-bound at scan sizes;
+//             no MFMA (nothing here is a contraction).
+//   k_lm      single GPU: one whole ceres::Solve per launch.  Per evaluation and valid
+//             correspondence: r = (q*p + t - o).n, 1x6 tangent Jacobian, Huber(0.15) IRLS
+//             weight; f64 reduction of sum w J J^T (21), sum w J r (6), sum 0.5 rho (1) per
+//             workgroup, exchange between the workgroups through HBM, then the
+//             Levenberg-Marquardt policy of lm_core.hpp on one wave.  The pose of the next
+//             k_match travels through AlignState in HBM: no host round trip inside an align.
+//   k_eval_server / k_eval
+//             the same evaluation for the host-driven loop (ranks that exchange sums,
+//             LOM_HOST_LM=1): the <= 64 records land in pinned host memory and the host adds
+//             them in workgroup order, or stay in HBM for the RCCL all-gather.
 //
 // Built with -ffp-contract=off (see voxel_map.hip).
 #include <algorithm>
@@ -408,7 +413,7 @@ __global__ __launch_bounds__(kMatchThreads, kMinWaves) void k_match(MapView map,
 //
 //   k_eval         one evaluation per launch; records stay in HBM (multi-GPU path:
 //                  k_sum_records folds them for the RCCL all-gather).
-//   k_eval_server  single-GPU path.  Launched once per outer iteration behind
+//   k_eval_server  host-driven path, one GPU per rank.  Launched once per outer iteration behind
 //                  k_match, it evaluates at the launch pose, then stays resident and
 //                  serves the LM iterations: the host writes {seq, op, pose} into
 //                  pinned host memory, every workgroup polls that word, evaluates,
