@@ -171,6 +171,7 @@ typedef struct {
     double algorithmic_bytes;  /* sum over queries of 444 + 12*cand + 12*valid     */
     double host_launch_ms;     /* host time spent inside kernel-launch calls                   */
     double host_wait_ms;       /* host time spent waiting for evaluation results               */
+    int64_t profiled_launches; /* correspondence launches that carried the HIP event pair      */
 } lom_align_stats;
 
 /* Replaces CloudMatcher::align (cloud_matcher.h:15-16): up to 35 outer iterations of
@@ -203,8 +204,11 @@ int lom_debug_match_stamps(lom_map *m, const float *d_src_xyz, size_t n, size_t 
                            const float q_wxyz[4], float max_dist, unsigned long long *stamps_out,
                            size_t cap_blocks, uint32_t *n_blocks_out);
 
-/* record HIP events around the correspondence launches of lom_match_align* (stats->match_kernel_ms) */
-int lom_map_set_profiling(lom_map *m, int enabled);
+/* Record a HIP event pair around the correspondence launches of lom_match_align*
+ * (stats->match_kernel_ms over stats->profiled_launches launches).  `period` = 0: off; 1: every
+ * align; N: every N-th align of this handle (an event pair costs the stream ~5 us per launch --
+ * sampling keeps a live in-loop measurement from distorting the loop it measures). */
+int lom_map_set_profiling(lom_map *m, int period);
 /* Roofline probe: `reps` back-to-back launches of the correspondence kernel on a device-resident
  * scan at pose (t,q), bracketed by ONE HIP event pair on the handle's stream, so the per-event
  * packet overhead is amortised.  Returns the average launch duration in microseconds and the

@@ -189,8 +189,9 @@ class VoxelGrid:
             C.byref(rq)), self._h)
         return us.value, by.value, rq.value
 
-    def setProfiling(self, on):
-        capi.check(capi.lib().lom_map_set_profiling(self._h, 1 if on else 0), self._h)
+    def setProfiling(self, period):
+        """HIP event pairs around the correspondence launches of every `period`-th align (True = 1, False = 0)."""
+        capi.check(capi.lib().lom_map_set_profiling(self._h, int(period)), self._h)
 
 
 def align_repeat(keyframe, d_src_ptr, n, position_guess, reps, stride_bytes=12):

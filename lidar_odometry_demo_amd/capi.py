@@ -49,6 +49,7 @@ class AlignStats(C.Structure):
         ("cand_total", C.c_int64), ("occ_total", C.c_int64), ("final_cost", C.c_double),
         ("last_step_norm", C.c_double), ("match_kernel_ms", C.c_double),
         ("algorithmic_bytes", C.c_double), ("host_launch_ms", C.c_double), ("host_wait_ms", C.c_double),
+        ("profiled_launches", C.c_int64),
     ]
 
     def asdict(self):

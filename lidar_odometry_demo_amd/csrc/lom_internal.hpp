@@ -182,7 +182,9 @@ struct lom_map {
     unsigned long long report_seq = 0, lm_seq = 0;
     double last_counters[4] = {0, 0, 0, 0};  // valid, cand, occ, queries of the last k_match
 
-    bool profiling = false;
+    bool profiling = false;       // this align carries event pairs
+    int profile_period = 0;       // 0 off, N: every N-th align
+    unsigned long long align_count = 0;
     std::vector<hipEvent_t> prof_events;  // pairs around each k_match launch of one align
 
     // RCCL

@@ -1726,6 +1726,7 @@ static int align_chained(lom_map *m, const char *d_src, size_t n, size_t stride,
             if (hipEventElapsedTime(&ms, m->prof_events[(size_t)i * 2], m->prof_events[(size_t)i * 2 + 1]) == hipSuccess)
                 st.match_kernel_ms += ms;
         }
+        st.profiled_launches = c.prof_used;
     }
     st.host_launch_ms = c.launch_s * 1e3;
     st.host_wait_ms = c.wait_s * 1e3;
@@ -1748,6 +1749,7 @@ static int align_device(lom_map *m, const char *d_src, size_t n, size_t stride, 
                         const float guess_q[4], float out_t[3], float out_q[4], lom_align_stats *stats)
 {
     if (n >= 0x7FFFFFFFull) return set_error(m, LOM_ERR_ARG, "too many source points");
+    m->profiling = m->profile_period > 0 && (m->align_count++ % (unsigned)m->profile_period) == 0;
     if (!m->comm && !m->host_comm && !getenv("LOM_HOST_LM")) {
         server_stop(m);
         return align_chained(m, d_src, n, stride, guess_t, guess_q, out_t, out_q, stats);
@@ -1774,6 +1776,7 @@ static int align_device(lom_map *m, const char *d_src, size_t n, size_t stride, 
             if (hipEventElapsedTime(&ms, m->prof_events[(size_t)i * 2], m->prof_events[(size_t)i * 2 + 1]) == hipSuccess)
                 st.match_kernel_ms += ms;
         }
+        st.profiled_launches = c.prof_used;
     }
     st.host_launch_ms = c.launch_s * 1e3;
     st.host_wait_ms = c.wait_s * 1e3;
@@ -1944,6 +1947,7 @@ int lom_match_align_repeat(lom_map *m, const float *d_src, size_t n, size_t stri
         acc.algorithmic_bytes += st.algorithmic_bytes;
         acc.host_launch_ms += st.host_launch_ms;
         acc.host_wait_ms += st.host_wait_ms;
+        acc.profiled_launches += st.profiled_launches;
     }
     if (total) *total = acc;
     return LOM_OK;

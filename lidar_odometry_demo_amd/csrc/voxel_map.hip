@@ -927,10 +927,12 @@ int lom_map_set_stream(lom_map *m, void *hip_stream)
     return LOM_OK;
 }
 
-int lom_map_set_profiling(lom_map *m, int enabled)
+int lom_map_set_profiling(lom_map *m, int period)
 {
-    if (!m) return LOM_ERR_ARG;
-    m->profiling = enabled != 0;
+    if (!m || period < 0) return LOM_ERR_ARG;
+    m->profile_period = period;
+    m->profiling = false;
+    m->align_count = 0;
     return LOM_OK;
 }
 

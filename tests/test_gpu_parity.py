@@ -479,6 +479,28 @@ def test_comm_path_single_rank(lom):
     assert again.translation.tobytes() == ref.translation.tobytes()
 
 
+def test_sampled_profiling_events(lom):
+    """lom_map_set_profiling(period): HIP event pairs around the correspondence launches of every
+    period-th align only; the other aligns run uninstrumented; results do not change."""
+    sm = scenes.small_synth_case()
+    g = lom.VoxelGrid(0.5, 20)
+    g.addCloud(sm["map_xyz"], sm["map_nrm"])
+    m = lom.CloudMatcher()
+    ref = m.align(g, sm["scan"], lom.Pose3D())
+    assert m.stats["profiled_launches"] == 0 and m.stats["match_kernel_ms"] == 0.0
+    g.setProfiling(2)
+    seen = []
+    for _ in range(4):
+        got = m.align(g, sm["scan"], lom.Pose3D())
+        assert got.translation.tobytes() == ref.translation.tobytes()
+        seen.append((m.stats["profiled_launches"], m.stats["match_launches"], m.stats["match_kernel_ms"]))
+    assert [p for p, _, _ in seen] == [seen[0][1], 0, seen[2][1], 0]
+    assert seen[0][2] > 0.0 and seen[1][2] == 0.0
+    g.setProfiling(0)
+    m.align(g, sm["scan"], lom.Pose3D())
+    assert m.stats["profiled_launches"] == 0
+
+
 def test_zero_matches_returns_guess(lom):
     g = lom.VoxelGrid(0.5, 20)
     g.addCloudWithoutNormals(np.array([[50, 50, 50]], np.float32))
