@@ -439,6 +439,7 @@ struct EvalCmd {  // pinned host memory, written by the host only
 };
 constexpr unsigned int kCmdEval = 1, kCmdStop = 2;
 constexpr int kPublishPlain = 0, kPublishHost = 1, kPublishDevice = 2;
+constexpr int kPairsAhead = 5;  // (k_match, k_lm) pairs enqueued before the host looks at a report
 constexpr uint32_t kMaxLmBlocks = 64;  // workgroups of k_lm (one lane of a wave watches each record)
 
 // cloud_matcher.cpp:48-102 for one correspondence, accumulated into the 28 sums
@@ -1284,6 +1285,10 @@ __global__ __launch_bounds__(kEvalThreads) void k_lm(const MatchRec *__restrict_
     st.final_cost = S.cost;
     st.last_step_norm = S.last_step_norm;
     *state = st;
+    // The host reads its first report after the fifth outer iteration (the stop rule cannot fire
+    // earlier, and it enqueued five pairs at once): the reports of iterations 1-4 would only cost
+    // this kernel a PCIe round trip each.
+    if (st.outer_done < kPairsAhead) return;
     // report: payload as system-scope stores, drained, then the sequence word
     unsigned long long *dst_w = reinterpret_cast<unsigned long long *>(report);
     auto put = [&](size_t byte_off, unsigned long long v) {
@@ -1665,7 +1670,7 @@ static int align_chained(lom_map *m, const char *d_src, size_t n, size_t stride,
         launched++;
         return LOM_OK;
     };
-    for (int i = 0; i < 5; i++)
+    for (int i = 0; i < kPairsAhead; i++)
         if ((rc = launch_pair()) != LOM_OK) return rc;
     for (;;) {
         const double t_w = now_s();
