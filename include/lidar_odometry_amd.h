@@ -299,6 +299,7 @@ typedef struct {
 typedef struct {
     int64_t planar_points, filtered_points, update_points, matching_points, keyframe_voxels, queries;
     int32_t outer_iterations, initialised_keyframe, unstable_rotation, pad;
+    int64_t queries_total; /* source points x outer iterations of all frames since creation */
 } lom_odometry_frame_stats;
 
 typedef struct lom_odometry lom_odometry;

@@ -73,7 +73,7 @@ class OdometryFrameStats(C.Structure):
     _fields_ = [("planar_points", C.c_int64), ("filtered_points", C.c_int64), ("update_points", C.c_int64),
                 ("matching_points", C.c_int64), ("keyframe_voxels", C.c_int64), ("queries", C.c_int64),
                 ("outer_iterations", C.c_int32), ("initialised_keyframe", C.c_int32),
-                ("unstable_rotation", C.c_int32), ("pad", C.c_int32)]
+                ("unstable_rotation", C.c_int32), ("pad", C.c_int32), ("queries_total", C.c_int64)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "pad"}

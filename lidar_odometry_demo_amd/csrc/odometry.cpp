@@ -379,6 +379,67 @@ void delta_euler_deg(const float qa[4], const float qb[4], float out[3])
 }  // namespace
 
 // ---- LidarOdometry (src/lidar_odometry.{h,cpp}) ---------------------------------------------
+// One helper thread per odometry: the keyframe update of frame k (radiusCleanup, rigid transform,
+// insert: lidar_odometry.cpp:67-70) does not influence frame k's pose, and frame k+1 touches the
+// GPU handles only after its host stages (time normalisation, deskew, classifier, range filter).
+// So processCloud returns the pose and lets the update run here; the next call (or any accessor)
+// joins it before it uses a handle.  Same operations in the same order on the same stream: results
+// do not change.
+class Deferred {
+public:
+    Deferred() : th_([this] { loop(); }) {}
+    ~Deferred()
+    {
+        {
+            std::lock_guard<std::mutex> g(m_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        th_.join();
+    }
+    void submit(std::function<int()> f)
+    {
+        {
+            std::lock_guard<std::mutex> g(m_);
+            job_ = std::move(f);
+            busy_ = true;
+        }
+        cv_.notify_all();
+    }
+    int join()  // status of the last job (LOM_OK if none is pending)
+    {
+        std::unique_lock<std::mutex> g(m_);
+        cv_.wait(g, [this] { return !busy_; });
+        const int rc = rc_;
+        rc_ = LOM_OK;
+        return rc;
+    }
+
+private:
+    void loop()
+    {
+        std::unique_lock<std::mutex> g(m_);
+        for (;;) {
+            cv_.wait(g, [this] { return stop_ || (busy_ && job_); });
+            if (stop_) return;
+            std::function<int()> f = std::move(job_);
+            job_ = nullptr;
+            g.unlock();
+            const int rc = f();
+            g.lock();
+            rc_ = rc;
+            busy_ = false;
+            cv_.notify_all();
+        }
+    }
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::function<int()> job_;
+    bool busy_ = false, stop_ = false;
+    int rc_ = LOM_OK;
+    std::thread th_;
+};
+
 struct lom_odometry {
     lom_odometry_params cfg;
     lom_map *keyframe = nullptr;       // keyframe_           lidar_odometry.h:82
@@ -391,6 +452,17 @@ struct lom_odometry {
     std::vector<float> planar, planar_n, filtered, filtered_n, down, down_n, match, upd, upd_n;
     std::string error;
     std::unique_ptr<Pool> pool;  // host workers for the per-point stages (std::execution::par in the reference)
+    int64_t queries_total = 0;
+    std::unique_ptr<Deferred> deferred;  // keyframe update of the previous frame
+    std::string deferred_error;
+    // finish the previous frame's keyframe update; its failure is this call's failure
+    int settle()
+    {
+        if (!deferred) return LOM_OK;
+        const int rc = deferred->join();
+        if (rc != LOM_OK) error = deferred_error;
+        return rc;
+    }
 };
 
 extern "C" {
@@ -441,6 +513,7 @@ int lom_odometry_create(const lom_odometry_params *params, int device, lom_odome
         if (const char *e = getenv("LOM_HOST_THREADS")) hw = (unsigned)std::max(1, atoi(e));
         o->pool.reset(new Pool(std::max(1u, std::min(hw, 16u))));
     }
+    if (!getenv("LOM_SYNC_KEYFRAME_UPDATE")) o->deferred.reset(new Deferred());
     lom_pose_identity(&o->current);  // lidar_odometry.cpp:15-17
     o->previous = o->current;
     int rc = lom_map_create(params->keyframe_voxel_size, params->keyframe_max_points_cnt, 1 << 16, device,
@@ -462,6 +535,8 @@ int lom_odometry_create(const lom_odometry_params *params, int device, lom_odome
 void lom_odometry_destroy(lom_odometry *o)
 {
     if (!o) return;
+    (void)o->settle();
+    o->deferred.reset();
     lom_map_destroy(o->update_ds);  // the down-samplers run on the keyframe handle's stream: they go first
     lom_map_destroy(o->matching_ds);
     lom_map_destroy(o->keyframe);
@@ -469,7 +544,12 @@ void lom_odometry_destroy(lom_odometry *o)
 }
 
 const char *lom_odometry_last_error(const lom_odometry *o) { return o ? o->error.c_str() : ""; }
-lom_map *lom_odometry_keyframe(lom_odometry *o) { return o ? o->keyframe : nullptr; }
+lom_map *lom_odometry_keyframe(lom_odometry *o)
+{
+    if (!o) return nullptr;
+    (void)o->settle();
+    return o->keyframe;
+}
 
 int lom_odometry_get_pose(const lom_odometry *o, lom_pose *out)
 {
@@ -481,8 +561,9 @@ int lom_odometry_get_pose(const lom_odometry *o, lom_pose *out)
 int lom_odometry_get_stats(const lom_odometry *o, lom_odometry_frame_stats *out)
 {
     if (!o || !out) return LOM_ERR_ARG;
+    const int rc = const_cast<lom_odometry *>(o)->settle();  // keyframe_voxels comes from the keyframe update
     *out = o->last;
-    return LOM_OK;
+    return rc;
 }
 
 // LidarOdometry::processCloud, lidar_odometry.cpp:22-77
@@ -494,7 +575,7 @@ int lom_odometry_process_cloud(lom_odometry *o, const lom_point_xyzirt *pts, siz
         return rc;
     };
     try {
-        o->last = lom_odometry_frame_stats{};
+        lom_odometry_frame_stats cur{};  // becomes o->last when the frame is through
         StageTimer tm;
         const size_t cap = n ? n : 1;
         o->normalized.resize(cap);
@@ -513,10 +594,14 @@ int lom_odometry_process_cloud(lom_odometry *o, const lom_point_xyzirt *pts, siz
                                    o->classify_scratch, o->pool.get());  // :33
         const size_t nf = range_filter(o->planar.data(), o->planar_n.data(), np, o->cfg.lidar_min_range,
                                        o->cfg.lidar_max_range, o->filtered.data(), o->filtered_n.data());  // :35
-        o->last.planar_points = (int64_t)np;
-        o->last.filtered_points = (int64_t)nf;
+        cur.planar_points = (int64_t)np;
+        cur.filtered_points = (int64_t)nf;
         tm.lap("classify+filter");
         int rc;
+        // the previous frame's keyframe update ran beside the host stages above; it must be through
+        // before this frame touches a handle
+        if ((rc = o->settle()) != LOM_OK) return rc;
+        tm.lap("settle");
         // From here on the frame lives in HBM: one upload of the filtered cloud, both down-samplers,
         // the align, the rigid transform and the keyframe update consume device buffers in stream order.
         const float *d_fx = nullptr, *d_fn = nullptr;
@@ -528,13 +613,14 @@ int lom_odometry_process_cloud(lom_odometry *o, const lom_point_xyzirt *pts, siz
         const int64_t nd = lom_voxel_downsample_device(o->update_ds, o->cfg.keyframe_update_voxel_size, d_fx, d_fn, nf,
                                                        12, &d_down, &d_down_n);
         if (nd < 0) return fail((int)nd, o->update_ds);
-        o->last.update_points = nd;
+        cur.update_points = nd;
         tm.lap("update_ds");
         if (lom_map_size(o->keyframe) == 0) {  // :40-44 init keyframe
             if ((rc = lom_map_add_points_device(o->keyframe, d_down, d_down_n, (size_t)nd, 12)) != LOM_OK)
                 return fail(rc, o->keyframe);
-            o->last.initialised_keyframe = 1;
-            o->last.keyframe_voxels = lom_map_size(o->keyframe);
+            cur.initialised_keyframe = 1;
+            cur.keyframe_voxels = lom_map_size(o->keyframe);
+            o->last = cur;
             return LOM_OK;
         }
         // VoxelGrid matching_downsampler(matching_voxel_size, 1); addCloud(filtered); getCloudWithoutNormals()   :46-47,50
@@ -542,15 +628,17 @@ int lom_odometry_process_cloud(lom_odometry *o, const lom_point_xyzirt *pts, siz
         const int64_t nm = lom_voxel_downsample_device(o->matching_ds, o->cfg.keyframe_matching_voxel_size, d_fx,
                                                        nullptr, nf, 12, &d_match, nullptr);
         if (nm < 0) return fail((int)nm, o->matching_ds);
-        o->last.matching_points = nm;
+        cur.matching_points = nm;
         tm.lap("matching_ds");
         lom_pose_compose(&o->current, &relative, &guess);  // :51
         lom_align_stats ast;
         if ((rc = lom_match_align_device(o->keyframe, d_match, (size_t)nm, 12, guess.t, guess.q, result.t, result.q,
                                          &ast)) != LOM_OK)  // :49-51
             return fail(rc, o->keyframe);
-        o->last.outer_iterations = ast.outer_iterations;
-        o->last.queries = ast.queries;
+        cur.outer_iterations = ast.outer_iterations;
+        cur.queries = ast.queries;
+        o->queries_total += ast.queries;
+        cur.queries_total = o->queries_total;
         tm.lap("align");
         {  // :53-63 divergence guard
             float ang[3];
@@ -560,21 +648,38 @@ int lom_odometry_process_cloud(lom_odometry *o, const lom_point_xyzirt *pts, siz
             for (int a = 0; a < 3; a++) ok = ok && (std::fabs(ang[a]) < thr || std::fabs(ang[a]) > 180 - thr);
             if (!ok) {
                 result = guess;  // :61
-                o->last.unstable_rotation = 1;
+                cur.unstable_rotation = 1;
             }
         }
         o->current = result;                                                                          // :65
-        if ((rc = lom_map_radius_cleanup(o->keyframe, o->current.t, o->cfg.keyframe_cleanup_range)) != LOM_OK)  // :67
-            return fail(rc, o->keyframe);
-        tm.lap("cleanup");
-        const float *d_upd = nullptr, *d_upd_n = nullptr;
-        if ((rc = lom_transform_points_device(o->keyframe, &o->current, d_down, d_down_n, (size_t)nd, 12, &d_upd,
-                                              &d_upd_n)) != LOM_OK)  // :69
-            return fail(rc, o->keyframe);
-        if ((rc = lom_map_add_points_device(o->keyframe, d_upd, d_upd_n, (size_t)nd, 12)) != LOM_OK)  // :70
-            return fail(rc, o->keyframe);
-        o->last.keyframe_voxels = lom_map_size(o->keyframe);
-        tm.lap("keyframe add");
+        o->last = cur;
+        // keyframe update (:67-70): same calls in the same order, on the helper thread when there is one
+        const lom_pose pose_now = o->current;
+        const size_t n_down = (size_t)nd;
+        auto update = [o, pose_now, d_down, d_down_n, n_down]() -> int {
+            auto bad = [o](int rc, lom_map *m) {
+                o->deferred_error = lom_last_error(m);
+                return rc;
+            };
+            int rc;
+            if ((rc = lom_map_radius_cleanup(o->keyframe, pose_now.t, o->cfg.keyframe_cleanup_range)) != LOM_OK)  // :67
+                return bad(rc, o->keyframe);
+            const float *d_upd = nullptr, *d_upd_n = nullptr;
+            if ((rc = lom_transform_points_device(o->keyframe, &pose_now, d_down, d_down_n, n_down, 12, &d_upd,
+                                                  &d_upd_n)) != LOM_OK)  // :69
+                return bad(rc, o->keyframe);
+            if ((rc = lom_map_add_points_device(o->keyframe, d_upd, d_upd_n, n_down, 12)) != LOM_OK)  // :70
+                return bad(rc, o->keyframe);
+            o->last.keyframe_voxels = lom_map_size(o->keyframe);
+            return LOM_OK;
+        };
+        if (o->deferred) {
+            o->deferred->submit(update);
+        } else if ((rc = update()) != LOM_OK) {
+            o->error = o->deferred_error;
+            return rc;
+        }
+        tm.lap("keyframe update");
         tm.total();
         return LOM_OK;
     } catch (const std::bad_alloc &) {
