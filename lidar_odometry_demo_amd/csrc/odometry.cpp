@@ -141,10 +141,22 @@ void run_parts(Pool *pool, size_t n, F &&fn, size_t serial_below = 2048)
 // ---- utils::pointTimeNormalize ---------------------------------------------------
 void time_normalize(const lom_point_xyzirt *in, size_t n, lom_point_xyzirt *out, Pool *pool = nullptr)
 {
+    // min / max of the stamps (:21, sequential in the reference; exact, so parts may be combined)
+    float part_lo[64], part_hi[64];
+    for (int p = 0; p < 64; p++) part_lo[p] = 3.402823466e+38f, part_hi[p] = -3.402823466e+38f;
+    run_parts(pool, n, [&](size_t b, size_t e, unsigned part) {
+        float l = 3.402823466e+38f, h = -3.402823466e+38f;
+        for (size_t i = b; i < e; i++) {
+            l = in[i].time < l ? in[i].time : l;
+            h = in[i].time > h ? in[i].time : h;
+        }
+        part_lo[part & 63] = l;
+        part_hi[part & 63] = h;
+    });
     float lo = 3.402823466e+38f, hi = -3.402823466e+38f;
-    for (size_t i = 0; i < n; i++) {  // sequential in the reference too (:21 execution::seq)
-        lo = in[i].time < lo ? in[i].time : lo;
-        hi = in[i].time > hi ? in[i].time : hi;
+    for (int p = 0; p < 64; p++) {
+        lo = part_lo[p] < lo ? part_lo[p] : lo;
+        hi = part_hi[p] > hi ? part_hi[p] : hi;
     }
     const float range = hi - lo;  // point_time_normalize.h:27 (0/0 when all stamps are equal, as there)
     run_parts(pool, n, [&](size_t b, size_t e, unsigned) {
@@ -198,20 +210,34 @@ void transform_non_rigid(const lom_point_xyzirt *in, size_t n, const lom_pose &s
 
 // ---- utils::rangeFilter ------------------------------------------------------------
 size_t range_filter(const float *xyz, const float *nrm, size_t n, float min_range, float max_range, float *xyz_out,
-                    float *nrm_out)
+                    float *nrm_out, Pool *pool = nullptr)
 {
     const float lo = min_range * min_range, hi = max_range * max_range;
-    size_t w = 0;
-    for (size_t i = 0; i < n; i++) {
+    auto keep = [&](size_t i) {
         const float *p = xyz + 3 * i;
         const float r2 = p[0] * p[0] + p[1] * p[1] + p[2] * p[2];
-        if (r2 >= lo && r2 <= hi) {
-            std::memcpy(xyz_out + 3 * w, p, 12);
+        return r2 >= lo && r2 <= hi;
+    };
+    // contiguous parts: count, then copy each part to its offset -- the output keeps the input order
+    size_t count[65] = {};
+    run_parts(pool, n, [&](size_t b, size_t e, unsigned part) {
+        size_t c = 0;
+        for (size_t i = b; i < e; i++) c += keep(i) ? 1 : 0;
+        count[part & 63] = c;
+    });
+    size_t offset[65];
+    offset[0] = 0;
+    for (int p = 0; p < 64; p++) offset[p + 1] = offset[p] + count[p];
+    run_parts(pool, n, [&](size_t b, size_t e, unsigned part) {
+        size_t w = offset[part & 63];
+        for (size_t i = b; i < e; i++) {
+            if (!keep(i)) continue;
+            std::memcpy(xyz_out + 3 * w, xyz + 3 * i, 12);
             if (nrm && nrm_out) std::memcpy(nrm_out + 3 * w, nrm + 3 * i, 12);
             w++;
         }
-    }
-    return w;
+    });
+    return offset[64];
 }
 
 // ---- CloudClassifier::classify ---------------------------------------------------------
@@ -219,9 +245,9 @@ size_t range_filter(const float *xyz, const float *nrm, size_t n, float min_rang
 // lidar_odometry.cpp:33, so only its size is reported)
 struct ClassifyScratch {  // reused across frames: no allocation or zero-fill beyond what the algorithm needs
     std::vector<lom_point_xyzirt> cloud;
-    std::vector<uint32_t> cell;
+    std::vector<uint32_t> cell, hist;
     std::vector<float> tmp_xyz, tmp_nrm;
-    std::vector<size_t> cnt_p, cnt_u;
+    std::vector<size_t> cnt_p, cnt_u, off_p;
 };
 
 size_t classify(const lom_point_xyzirt *in, size_t n, float *xyz_out, float *nrm_out, size_t *unclassified,
@@ -230,7 +256,17 @@ size_t classify(const lom_point_xyzirt *in, size_t n, float *xyz_out, float *nrm
     std::vector<lom_point_xyzirt> &cloud = sc.cloud;
     // organise by ring (map key is uint8_t in the reference, :23) and azimuth bin
     size_t ring_count[256] = {};
-    for (size_t i = 0; i < n; i++) ring_count[(uint8_t)in[i].ring]++;
+    {
+        std::vector<uint32_t> &hist = sc.hist;
+        const unsigned parts = pool ? pool->size() : 1u;
+        hist.assign((size_t)parts * 256, 0u);
+        run_parts(pool, n, [&](size_t b, size_t e, unsigned part) {
+            uint32_t *h = hist.data() + (size_t)part * 256;
+            for (size_t i = b; i < e; i++) h[(uint8_t)in[i].ring]++;
+        });
+        for (unsigned p = 0; p < parts; p++)
+            for (int r = 0; r < 256; r++) ring_count[r] += hist[(size_t)p * 256 + r];
+    }
     int row_of[256];
     size_t H = 0, W = 0;
     for (int r = 0; r < 256; r++) {
@@ -244,9 +280,10 @@ size_t classify(const lom_point_xyzirt *in, size_t n, float *xyz_out, float *nrm
     if (unclassified) *unclassified = 0;
     const size_t total = H * W;
     if (!total) return 0;
-    lom_point_xyzirt zero;
-    std::memset(&zero, 0, sizeof zero);
-    cloud.assign(total, zero);
+    if (cloud.size() < total) cloud.resize(total);
+    run_parts(pool, total, [&](size_t b, size_t e, unsigned) {  // empty cells are zero points (:41-46)
+        std::memset(static_cast<void *>(cloud.data() + b), 0, (e - b) * sizeof(lom_point_xyzirt));
+    });
     // cell of every point in parallel, then the scatter in input order (last writer wins, :52-54)
     std::vector<uint32_t> &cell = sc.cell;
     if (cell.size() < n) cell.resize(n);
@@ -258,8 +295,14 @@ size_t classify(const lom_point_xyzirt *in, size_t n, float *xyz_out, float *nrm
             cell[i] = idx < W ? (uint32_t)((size_t)row_of[(uint8_t)p.ring] * W + idx) : 0xFFFFFFFFu;
         }
     });
-    for (size_t i = 0; i < n; i++)
-        if (cell[i] != 0xFFFFFFFFu) cloud[cell[i]] = in[i];
+    // every part owns a contiguous range of cells and walks the points in input order, so the last
+    // writer of a cell is the same as in the sequential loop
+    run_parts(pool, total, [&](size_t cb, size_t ce, unsigned) {
+        for (size_t i = 0; i < n; i++) {
+            const uint32_t c = cell[i];
+            if (c >= cb && c < ce) cloud[c] = in[i];
+        }
+    });
     // curvature over the flattened array (+-4 window crosses ring boundaries), :76-103
     const int cw = 4;
     const float intensity_max = 1000.0f;
@@ -341,12 +384,19 @@ size_t classify(const lom_point_xyzirt *in, size_t n, float *xyz_out, float *nrm
     }
     }, 2);
     size_t np = 0, nu = 0;
+    std::vector<size_t> &off_p = sc.off_p;
+    off_p.assign(H + 1, 0);
     for (size_t ray = 1; ray < H; ray++) {
-        std::memcpy(xyz_out + 3 * np, tmp_xyz.data() + ray * W * 3, cnt_p[ray] * 12);
-        std::memcpy(nrm_out + 3 * np, tmp_nrm.data() + ray * W * 3, cnt_p[ray] * 12);
+        off_p[ray] = np;
         np += cnt_p[ray];
         nu += cnt_u[ray];
     }
+    run_parts(pool, H - 1, [&](size_t rb, size_t re, unsigned) {
+        for (size_t ray = rb + 1; ray < re + 1; ray++) {
+            std::memcpy(xyz_out + 3 * off_p[ray], tmp_xyz.data() + ray * W * 3, cnt_p[ray] * 12);
+            std::memcpy(nrm_out + 3 * off_p[ray], tmp_nrm.data() + ray * W * 3, cnt_p[ray] * 12);
+        }
+    }, 2);
     if (unclassified) *unclassified = nu;
     return np;
 }
@@ -593,7 +643,8 @@ int lom_odometry_process_cloud(lom_odometry *o, const lom_point_xyzirt *pts, siz
         const size_t np = classify(o->deskewed.data(), n, o->planar.data(), o->planar_n.data(), &nu, nullptr,
                                    o->classify_scratch, o->pool.get());  // :33
         const size_t nf = range_filter(o->planar.data(), o->planar_n.data(), np, o->cfg.lidar_min_range,
-                                       o->cfg.lidar_max_range, o->filtered.data(), o->filtered_n.data());  // :35
+                                       o->cfg.lidar_max_range, o->filtered.data(), o->filtered_n.data(),
+                                       o->pool.get());  // :35
         cur.planar_points = (int64_t)np;
         cur.filtered_points = (int64_t)nf;
         tm.lap("classify+filter");
