@@ -204,12 +204,20 @@ def main():
     if use_dist and "MASTER_ADDR" not in os.environ:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # LOM_BENCH_ONE_DEVICE=1: all ranks on GPU 0 with a gloo process group -- a rehearsal of the
+    # N > 1 flow on a one-GPU box (the numbers mean nothing: the ranks share the GPU)
+    one_device = bool(os.environ.get("LOM_BENCH_ONE_DEVICE"))
+    if one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # the align is a chain of host<->device round trips: run on the socket the GPU hangs off
     pinned = lom.capi.pin_to_device_numa_node(local_rank) if not os.environ.get("LOM_NO_PIN") else None
     if use_dist:
-        dist.init_process_group("nccl", device_id=dev)
+        if one_device:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     if args.config != "C2" and n != 1:
         raise SystemExit(f"--config {args.config} is a single-GPU configuration")
@@ -226,16 +234,18 @@ def main():
     torch.cuda.synchronize()
 
     # Exchange of the 32 reduced sums per residual evaluation (the path's one real exchange step).
-    # "host" (default): the ranks' hosts exchange through shared memory -- the consumer is the
-    # host-side solver and each host already holds its own sums; "rccl": all-gather over xGMI.
-    exchange = os.environ.get("LOM_EXCHANGE", "host")
+    # "p2p" (default): the device-resident solve on every rank, the GPUs store their totals into each
+    # other's HBM (IPC mappings, xGMI); attach runs a self-test on all ranks and the bench falls back
+    # to "host" if it fails anywhere.  "host": host-driven solve, the ranks' hosts exchange through
+    # shared memory.  "rccl": host-driven solve, all-gather over xGMI.
+    exchange = os.environ.get("LOM_EXCHANGE", "p2p")
     host_comm = None
     L = lom.capi.lib()
 
     def broadcast_id(make):
         import ctypes as C
 
-        ident = torch.zeros(lom.capi.COMM_ID_BYTES, dtype=torch.uint8, device=dev)
+        ident = torch.zeros(lom.capi.COMM_ID_BYTES, dtype=torch.uint8, device="cpu" if one_device else dev)
         if rank == 0:
             buf = C.create_string_buffer(lom.capi.COMM_ID_BYTES)
             lom.capi.check(make(buf))
@@ -244,7 +254,7 @@ def main():
         return bytes(ident.cpu().numpy().tobytes())
 
     def attach(kind):
-        nonlocal host_comm
+        nonlocal host_comm, exchange
         import ctypes as C
 
         if kind == "rccl":
@@ -252,8 +262,15 @@ def main():
         else:
             h = C.c_void_p()
             lom.capi.check(L.lom_host_comm_create(rank, world, broadcast_id(L.lom_comm_host_id), C.byref(h)))
-            lom.capi.check(L.lom_comm_attach_host(grid.handle, h), grid.handle)
             host_comm = h
+            if kind == "p2p":
+                if L.lom_comm_attach_p2p(grid.handle, h) == 0:
+                    return
+                # the verdict is collective: every rank lands here together
+                print(f"[bench] rank {rank}: device-to-device exchange not available "
+                      f"({L.lom_last_error(grid.handle).decode()}); using the host exchange", file=sys.stderr)
+                exchange = "host"
+            lom.capi.check(L.lom_comm_attach_host(grid.handle, h), grid.handle)
 
     def detach():
         nonlocal host_comm
@@ -298,7 +315,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if one_device else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -320,7 +337,7 @@ def main():
                 q_alt += step()[1]["queries"]
             fence()
             el = time.perf_counter() - t_alt
-            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            t = torch.tensor([el], dtype=torch.float64, device="cpu" if one_device else dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             other = {"exchange": alt, "value": q_alt / float(t.item()) / 1e6, "unit": "Mcorr/s",
                      "ms_per_step": float(t.item()) / args.steps * 1e3}
@@ -376,8 +393,10 @@ def main():
                 "parallelism": f"source-range x{n}, map replicated" if n > 1 else "single GPU",
                 "host_cpus": (f"{len(pinned)} CPUs of the GPU's NUMA node" if pinned else "not pinned"),
                 "exchange": (exchange if use_dist else None),
-                "exchange_note": ("32 f64 per rank per residual evaluation; host = shared-memory exchange "
-                                  "between the ranks' hosts, rccl = all-gather over xGMI" if use_dist else None),
+                "exchange_note": ("32 f64 per rank per residual evaluation; p2p = device-resident solve, the GPUs "
+                                  "store their totals into each other's HBM; host = host-driven solve, "
+                                  "shared-memory exchange between the ranks' hosts; rccl = host-driven solve, "
+                                  "all-gather over xGMI" if use_dist else None),
                 "other_exchange": other,
             },
             "host_breakdown_ms_per_step": {"in_launch_calls": launch_ms / args.steps,

@@ -240,8 +240,18 @@ typedef struct lom_host_comm lom_host_comm;
 int lom_comm_host_id(char id_out[LOM_COMM_ID_BYTES]);
 int lom_host_comm_create(int rank, int nranks, const char id[LOM_COMM_ID_BYTES], lom_host_comm **out);
 int lom_host_comm_allreduce(lom_host_comm *c, double *buf, int count); /* in place, count <= LOM_NSUMS */
+/* every rank contributes `bytes` (<= 256) raw bytes; all_out receives nranks * bytes in rank order */
+int lom_host_comm_allgather(lom_host_comm *c, const void *mine, size_t bytes, void *all_out);
 void lom_host_comm_destroy(lom_host_comm *c);
 int lom_comm_attach_host(lom_map *m, lom_host_comm *c_or_null);
+/* Third transport (ranks of one node, <= 8): the device-resident solve of the single-GPU path on
+ * every rank, with the ranks' reduced sums exchanged by the GPUs themselves -- every rank's k_lm
+ * stores its 32 words into a small buffer in each peer's HBM (IPC-mapped, over xGMI) and adds the
+ * ranks' words in rank order: no host round trip per evaluation.  `c` carries rank / nranks and the
+ * exchange of the IPC handles.  The call runs a self-test of the device-to-device exchange on all
+ * ranks and returns LOM_ERR_COMM on EVERY rank if it fails on any (fall back to
+ * lom_comm_attach_host).  Ranks must issue the same sequence of aligns. */
+int lom_comm_attach_p2p(lom_map *m, lom_host_comm *c);
 
 /* ---- host-side align driver over user evaluators ------------------------ */
 /* lom_match_align* = this driver over the HIP kernels.  Exposed so that the

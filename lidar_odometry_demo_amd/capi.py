@@ -101,7 +101,7 @@ EXPORTED = [
     "lom_transform_points_device", "lom_map_get_stream", "lom_match_find_pairs", "lom_match_align", "lom_match_align_device", "lom_match_align_repeat", "lom_debug_match_stamps",
     "lom_map_set_profiling", "lom_profile_match", "lom_map_set_stream", "lom_comm_unique_id", "lom_comm_init",
     "lom_comm_finalize", "lom_comm_host_id", "lom_host_comm_create", "lom_host_comm_allreduce",
-    "lom_host_comm_destroy", "lom_comm_attach_host", "lom_align_with_hooks", "lom_point_time_normalize", "lom_transform_non_rigid",
+    "lom_host_comm_destroy", "lom_host_comm_allgather", "lom_comm_attach_host", "lom_comm_attach_p2p", "lom_align_with_hooks", "lom_point_time_normalize", "lom_transform_non_rigid",
     "lom_range_filter", "lom_cloud_classify", "lom_odometry_default_params", "lom_odometry_create",
     "lom_odometry_destroy", "lom_odometry_process_cloud", "lom_odometry_get_pose", "lom_odometry_get_stats",
     "lom_odometry_keyframe", "lom_odometry_last_error",
@@ -198,6 +198,10 @@ def lib():
     L.lom_host_comm_destroy.argtypes = [vp]
     L.lom_host_comm_destroy.restype = None
     L.lom_comm_attach_host.argtypes = [vp, vp]
+    L.lom_comm_attach_p2p.argtypes = [vp, vp]
+    L.lom_comm_attach_p2p.restype = C.c_int
+    L.lom_host_comm_allgather.argtypes = [vp, vp, C.c_size_t, vp]
+    L.lom_host_comm_allgather.restype = C.c_int
     L.lom_align_with_hooks.argtypes = [C.POINTER(AlignHooks), fp, fp, fp, fp, C.POINTER(AlignStats)]
     L.lom_point_time_normalize.argtypes = [vp, C.c_size_t, vp]
     L.lom_point_time_normalize.restype = None

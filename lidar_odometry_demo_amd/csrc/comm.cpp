@@ -114,6 +114,16 @@ double mono_s()
 
 namespace lom {
 
+int host_comm_rank(void *hc, int *rank, int *nranks, unsigned long long *seq)
+{
+    lom_host_comm *c = reinterpret_cast<lom_host_comm *>(hc);
+    if (!c) return LOM_ERR_ARG;
+    *rank = c->rank;
+    *nranks = c->nranks;
+    if (seq) *seq = c->seq;  // operations so far: the same number on every rank
+    return LOM_OK;
+}
+
 int host_exchange_sums(lom_map *m, const double *mine, double *out)
 {
     lom_host_comm *hc = reinterpret_cast<lom_host_comm *>(m->host_comm);
@@ -188,6 +198,30 @@ int lom_host_comm_allreduce(lom_host_comm *hc, double *buf, int count)
     return LOM_OK;
 }
 
+// Raw bytes through the same double-buffered slots (a slot's data area is 256 bytes).
+int lom_host_comm_allgather(lom_host_comm *hc, const void *mine, size_t bytes, void *all_out)
+{
+    if (!hc || !mine || !all_out || bytes == 0 || bytes > sizeof(double) * LOM_NSUMS) return LOM_ERR_ARG;
+    const unsigned long long seq = ++hc->seq;
+    HostSlot *slots = hc->slots + (size_t)(seq & 1) * hc->nranks;
+    HostSlot &me = slots[hc->rank];
+    std::memcpy(me.data, mine, bytes);
+    __atomic_store_n(&me.seq, seq, __ATOMIC_RELEASE);
+    const double t0 = mono_s();
+    for (int r = 0; r < hc->nranks; r++) {
+        unsigned long long spins = 0;
+        while (__atomic_load_n(&slots[r].seq, __ATOMIC_ACQUIRE) != seq) {
+            __builtin_ia32_pause();
+            if ((++spins & 0xFFFFF) == 0 && mono_s() - t0 > 60.0) {
+                hc->error = "host exchange timed out waiting for rank " + std::to_string(r);
+                return LOM_ERR_COMM;
+            }
+        }
+        std::memcpy(static_cast<char *>(all_out) + (size_t)r * bytes, slots[r].data, bytes);
+    }
+    return LOM_OK;
+}
+
 void lom_host_comm_destroy(lom_host_comm *hc)
 {
     if (!hc) return;
@@ -200,6 +234,7 @@ int lom_comm_attach_host(lom_map *m, lom_host_comm *hc)
 {
     if (!m) return LOM_ERR_ARG;
     if (m->comm) return lom::set_error(m, LOM_ERR_STATE, "an RCCL communicator is already attached");
+    if (m->p2p) lom::p2p_detach(m);
     m->host_comm = hc;  // NULL detaches; the caller keeps ownership
     m->rank = hc ? hc->rank : 0;
     m->nranks = hc ? hc->nranks : 1;
@@ -253,6 +288,7 @@ int lom_comm_init(lom_map *m, int rank, int nranks, const char id_in[LOM_COMM_ID
 int lom_comm_finalize(lom_map *m)
 {
     if (!m) return LOM_ERR_ARG;
+    if (m->p2p) lom::p2p_detach(m);
     if (m->host_comm) {  // attached host exchange: detach (its owner destroys it)
         m->host_comm = nullptr;
         m->rank = 0;

@@ -187,6 +187,10 @@ struct lom_map {
     unsigned long long align_count = 0;
     std::vector<hipEvent_t> prof_events;  // pairs around each k_match launch of one align
 
+    // device-to-device exchange (lom_comm_attach_p2p): this rank's buffer and the peers' IPC mappings
+    bool p2p = false;
+    void *p2p_local = nullptr;          // [2 sets][kP2pMaxRanks][32] exchange words in this GPU's HBM
+    void *p2p_peer[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     // RCCL
     void *comm = nullptr;       // RCCL communicator (device-side all-gather)
     void *host_comm = nullptr;  // host shared-memory exchange between the ranks of one node
@@ -212,5 +216,9 @@ MapView view_of(const lom_map *m);
 int comm_allgather_sums(lom_map *m, const double *d_send, double *d_recv, int count);
 // host shared-memory exchange: out = sum over ranks (rank order) of `mine`
 int host_exchange_sums(lom_map *m, const double *mine, double *out);
+int host_comm_rank(void *host_comm, int *rank, int *nranks, unsigned long long *seq = nullptr);
+// device-to-device exchange (match.hip)
+constexpr int kP2pMaxRanks = 8;
+void p2p_detach(lom_map *m);
 
 }  // namespace lom

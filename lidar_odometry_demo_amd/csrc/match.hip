@@ -1144,6 +1144,104 @@ __device__ __forceinline__ int lmw_propose(LmState &S, int lane)
     return result;
 }
 
+// ---- ranks of one node: the ranks' totals exchanged by the GPUs themselves -------------------
+// Every rank owns a small buffer in its HBM: [2 sets][kP2pMaxRanks][32] exchange words.  Rank r's
+// workgroup 0 stores its 32 rank totals into slot r of EVERY rank's buffer (its own directly, the
+// peers' through their IPC mappings: xGMI), system-coherent stores, same {bits, seq ^ bits} words as
+// inside a GPU.  Every workgroup of every rank then reads its own GPU's buffer and adds the ranks'
+// words in rank order: identical bits on all workgroups of all ranks, no host in the loop.
+struct P2pArgs {
+    XWord *peer[kP2pMaxRanks];  // peer[r]: rank r's buffer as seen from this GPU (peer[rank] = local)
+    int rank, nranks;
+};
+
+__device__ __forceinline__ void global_exchange(const P2pArgs &A, double *s_tot, unsigned long long seq,
+                                                unsigned long long timeout_ticks, int *s_failed, bool publisher,
+                                                int lane)
+{
+    const size_t set_off = (size_t)(seq & 1) * kP2pMaxRanks * kRecWords;
+    if (publisher && lane < kRecWords) {
+        const unsigned long long b = (unsigned long long)__double_as_longlong(s_tot[lane]);
+        for (int r = 0; r < A.nranks; r++) {
+            XWord *dst = A.peer[r] + set_off + (size_t)A.rank * kRecWords + lane;
+            __hip_atomic_store(&dst->bits, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&dst->check, seq ^ b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    // lane (h = lane / 32, k = lane % 32) reads word k of ranks h, h + 2, h + 4, h + 6
+    const XWord *local = A.peer[A.rank] + set_off;
+    const int k = lane & 31, h = lane >> 5;
+    unsigned long long vb[4] = {0, 0, 0, 0};
+    const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+    bool failed = false;
+    for (;;) {
+        bool all = true;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int r = h + 2 * u;
+            if (r < A.nranks) {
+                const XWord *w = local + (size_t)r * kRecWords + k;
+                const unsigned long long bits = __hip_atomic_load(&w->bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                const unsigned long long chk = __hip_atomic_load(&w->check, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                vb[u] = bits;
+                all = all && ((chk ^ bits) == seq);
+            }
+        }
+        if (__ballot(!all) == 0ull) break;
+        if (__builtin_amdgcn_s_memrealtime() - t_start > timeout_ticks) {
+            failed = true;  // a rank never published: give up (every grid drains)
+            break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    // rank order: lanes < 32 hold the even ranks, their partners (lane + 32) the odd ones
+    double total = 0.0;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const double mine = __longlong_as_double((long long)vb[u]);
+        const double other = __shfl_xor(mine, 32, 64);
+        total += (h == 0) ? mine : other;   // rank 2u     (absent ranks add +0.0)
+        total += (h == 0) ? other : mine;   // rank 2u + 1
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (lane < kRecWords) s_tot[lane] = total;
+    if (failed && lane == 0) *s_failed = 1;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// lom_comm_attach_p2p's self-test: `rounds` exchanges of known values between all ranks
+__global__ __launch_bounds__(64) void k_p2p_selftest(P2pArgs A, unsigned long long seq_base, int rounds,
+                                                     unsigned long long timeout_ticks, uint32_t *result)
+{
+    __shared__ double s_tot[kRecWords];
+    __shared__ int s_failed;
+    const int lane = threadIdx.x;
+    if (lane == 0) s_failed = 0;
+    __syncthreads();
+    uint32_t bad = 0;
+    for (int i = 0; i < rounds && !s_failed; i++) {
+        if (lane < kRecWords) s_tot[lane] = (double)(A.rank + 1) * 1000.0 + (double)i + 0.5 * (double)lane;
+        __syncthreads();
+        // the first round also absorbs the start-up skew between the ranks' processes
+        global_exchange(A, s_tot, seq_base + 1 + (unsigned long long)i, i == 0 ? timeout_ticks * 100 : timeout_ticks,
+                        &s_failed, true, lane);
+        if (lane < kRecWords && !s_failed) {
+            double want = 0.0;
+            for (int r = 0; r < A.nranks; r++) want += (double)(r + 1) * 1000.0 + (double)i + 0.5 * (double)lane;
+            if (s_tot[lane] != want) bad++;
+        }
+        __syncthreads();
+    }
+    for (int d = 32; d >= 1; d >>= 1) bad += __shfl_xor(bad, d, 64);
+    if (lane == 0) {
+        result[0] = bad;
+        result[1] = (uint32_t)s_failed;
+    }
+}
+
 struct LmInit {
     float t[3], q[4];   // initial guess (cloud_matcher.cpp:107), used when `first`
     double prior_b[3];  // NormalPrior anchor = the guess's translation (:153)
@@ -1172,7 +1270,7 @@ __global__ __launch_bounds__(kEvalThreads) void k_lm(const MatchRec *__restrict_
                                                      unsigned long long seq_base, AlignReport *report,
                                                      unsigned long long report_seq,
                                                      unsigned long long timeout_ticks,
-                                                     unsigned long long *dbg_stamps)
+                                                     unsigned long long *dbg_stamps, P2pArgs px)
 {
     extern __shared__ __attribute__((aligned(16))) double s_acc[];
     __shared__ double s_tot[kRecWords];
@@ -1205,7 +1303,7 @@ __global__ __launch_bounds__(kEvalThreads) void k_lm(const MatchRec *__restrict_
     __syncthreads();
     unsigned long long seq = seq_base;
     uint32_t counters_from = n_match_blocks;  // k_match's counters are folded by the first evaluation only
-    double counters[3] = {0.0, 0.0, 0.0};
+    double counters[4] = {0.0, 0.0, 0.0, 0.0};  // valid, cand, occ of the last k_match; queries (all ranks)
     int action = LM_EVAL;
     // LOM_DEBUG_LM: shader-clock stamps of workgroup 0's first lane (0 start, 1 accumulated,
     // 3 totals known, 4 policy done); entries of different launches of one align overwrite each other
@@ -1224,6 +1322,14 @@ __global__ __launch_bounds__(kEvalThreads) void k_lm(const MatchRec *__restrict_
         reduce_and_exchange(acc, s_acc, s_part, block_counters, counters_from, set, nb, seq, timeout_ticks,
                             s_tot, &s_failed, (dbg_stamps && ev == 1) ? dbg_stamps + 32 : nullptr);
         counters_from = 0;
+        if (px.nranks > 1 && wave == 0 && !s_failed) {
+            // ranks of one node: this GPU's totals become the totals over all ranks
+            if (lane == 31) s_tot[31] = (double)n;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            global_exchange(px, s_tot, seq, timeout_ticks, &s_failed, blockIdx.x == 0, lane);
+        }
         LM_STAMP(3);
         if (wave == 0 && !s_failed) {
             // the first wave holds the totals (s_tot) and runs the policy (lm_core.hpp's,
@@ -1234,6 +1340,7 @@ __global__ __launch_bounds__(kEvalThreads) void k_lm(const MatchRec *__restrict_
                     counters[0] = s_tot[28];
                     counters[1] = s_tot[29];
                     counters[2] = s_tot[30];
+                    counters[3] = px.nranks > 1 ? s_tot[31] : (double)n;
                 }
                 a = lmw_begin(s_lm, s_tot, s_x, init.prior_b, lane);
             } else {
@@ -1281,7 +1388,7 @@ __global__ __launch_bounds__(kEvalThreads) void k_lm(const MatchRec *__restrict_
     st.valid_total = (first_outer ? 0.0 : state->valid_total) + counters[0];
     st.cand_total = (first_outer ? 0.0 : state->cand_total) + counters[1];
     st.occ_total = (first_outer ? 0.0 : state->occ_total) + counters[2];
-    st.queries_total = (first_outer ? 0.0 : state->queries_total) + (double)n;
+    st.queries_total = (first_outer ? 0.0 : state->queries_total) + counters[3];
     st.final_cost = S.cost;
     st.last_step_norm = S.last_step_norm;
     *state = st;
@@ -1616,6 +1723,29 @@ static int hook_eval_fixed(void *user, const double q[4], const double t[3], dou
     return launch_eval(c, q, t, false, out);
 }
 
+static P2pArgs p2p_args(const lom_map *m)
+{
+    P2pArgs A;
+    for (int r = 0; r < kP2pMaxRanks; r++) A.peer[r] = m->p2p ? (XWord *)m->p2p_peer[r] : nullptr;
+    A.rank = m->p2p ? m->rank : 0;
+    A.nranks = m->p2p ? m->nranks : 1;
+    return A;
+}
+
+void p2p_detach(lom_map *m)
+{
+    if (!m->p2p_local) return;
+    (void)hipSetDevice(m->device);
+    (void)hipStreamSynchronize(m->stream);
+    for (int r = 0; r < kP2pMaxRanks; r++) {
+        if (m->p2p_peer[r] && m->p2p_peer[r] != m->p2p_local) (void)hipIpcCloseMemHandle(m->p2p_peer[r]);
+        m->p2p_peer[r] = nullptr;
+    }
+    (void)hipFree(m->p2p_local);
+    m->p2p_local = nullptr;
+    m->p2p = false;
+}
+
 // Single GPU, no exchange: the outer loop runs on the device.  One (k_match, k_lm) pair per outer
 // iteration; the pose travels from pair to pair through AlignState in HBM, so the host enqueues
 // pairs without waiting for results.  cloud_matcher.cpp:169-172 cannot stop before the fifth outer
@@ -1647,6 +1777,7 @@ static int align_chained(lom_map *m, const char *d_src, size_t n, size_t stride,
     rp->error = 0;
     const unsigned long long seq0 = m->report_seq;
     int launched = 0;
+    const P2pArgs px = p2p_args(m);
     unsigned long long *dbg = nullptr;  // LOM_DEBUG_LM: phase stamps of the last k_lm of the align
     if (getenv("LOM_DEBUG_LM")) {
         if ((rc = ensure(m, m->scr[0], 4096)) != LOM_OK) return rc;
@@ -1663,8 +1794,7 @@ static int align_chained(lom_map *m, const char *d_src, size_t n, size_t stride,
                            (const MatchRec *)m->scan_on.p, c.n, (AlignState *)m->align_state.p, init, i == 0 ? 1 : 0,
                            (const uint32_t *)d_block_counters(m), c.match_blocks, (XWord *)m->xrec.p, m->lm_seq,
                            reinterpret_cast<AlignReport *>(m->d_report), seq0 + (unsigned long long)i + 1,
-                           server_timeout_ticks(), dbg);
-        (void)0;
+                           server_timeout_ticks(), dbg, px);
         LOM_HIP(m, hipGetLastError());
         c.launch_s += now_s() - t_l;
         launched++;
@@ -1755,7 +1885,7 @@ static int align_device(lom_map *m, const char *d_src, size_t n, size_t stride, 
 {
     if (n >= 0x7FFFFFFFull) return set_error(m, LOM_ERR_ARG, "too many source points");
     m->profiling = m->profile_period > 0 && (m->align_count++ % (unsigned)m->profile_period) == 0;
-    if (!m->comm && !m->host_comm && !getenv("LOM_HOST_LM")) {
+    if (!m->comm && (!m->host_comm || m->p2p) && !getenv("LOM_HOST_LM")) {
         server_stop(m);
         return align_chained(m, d_src, n, stride, guess_t, guess_q, out_t, out_q, stats);
     }
@@ -1841,6 +1971,90 @@ int64_t lom_match_find_pairs(lom_map *m, const float *src, size_t n, size_t stri
         valid += idx[i] >= 0;
     }
     return valid;
+}
+
+int lom_comm_attach_p2p(lom_map *m, lom_host_comm *hc)
+{
+    if (!m || !hc) return LOM_ERR_ARG;
+    if (m->comm) return set_error(m, LOM_ERR_STATE, "an RCCL communicator is already attached");
+    LOM_HIP(m, hipSetDevice(m->device));
+    int rank = 0, nranks = 1;
+    if (host_comm_rank(hc, &rank, &nranks) != LOM_OK) return LOM_ERR_ARG;
+    if (nranks > kP2pMaxRanks) return set_error(m, LOM_ERR_ARG, "device-to-device exchange: at most 8 ranks");
+    p2p_detach(m);
+    server_stop(m);
+    // From here on every step is collective: a rank that fails locally still takes part in the
+    // exchanges below, so that all ranks reach the same verdict.
+    const size_t bytes = (size_t)2 * kP2pMaxRanks * kRecWords * sizeof(XWord);
+    int ok = 1;
+    struct Blob {
+        hipIpcMemHandle_t handle;
+        int ok;
+    } mine, all[kP2pMaxRanks];
+    std::memset(&mine, 0, sizeof mine);
+    static_assert(sizeof(Blob) <= 256, "fits one host-exchange slot");
+    if (hipMalloc(&m->p2p_local, bytes) != hipSuccess) {
+        m->p2p_local = nullptr;
+        ok = 0;
+    }
+    if (ok && (hipMemsetAsync(m->p2p_local, 0, bytes, m->stream) != hipSuccess ||
+               hipStreamSynchronize(m->stream) != hipSuccess))
+        ok = 0;
+    if (ok && nranks > 1 && hipIpcGetMemHandle(&mine.handle, m->p2p_local) != hipSuccess) ok = 0;
+    mine.ok = ok;
+    if (lom_host_comm_allgather(hc, &mine, sizeof mine, all) != LOM_OK) {
+        p2p_detach(m);
+        return set_error(m, LOM_ERR_COMM, "device-to-device exchange: handle exchange failed");
+    }
+    for (int r = 0; r < nranks; r++) ok = ok && all[r].ok;
+    if (ok) {
+        for (int r = 0; r < nranks && ok; r++) {
+            if (r == rank) {
+                m->p2p_peer[r] = m->p2p_local;
+            } else if (hipIpcOpenMemHandle(&m->p2p_peer[r], all[r].handle, hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
+                m->p2p_peer[r] = nullptr;
+                ok = 0;
+            }
+        }
+    }
+    // barrier: every rank has its mappings before anybody stores through them
+    double sync[1] = {0.0};
+    if (lom_host_comm_allreduce(hc, sync, 1) != LOM_OK) ok = 0;
+    // sequence numbers: one epoch per attach, identical on all ranks (the host exchange has done the
+    // same number of operations on every rank) and above every number this handle has used
+    unsigned long long hseq = 0;
+    (void)host_comm_rank(hc, &rank, &nranks, &hseq);
+    m->lm_seq = std::max(m->lm_seq, hseq << 32);
+    m->rank = rank;
+    m->nranks = nranks;
+    // self-test: 200 exchanges of known values through the mappings
+    uint32_t res[2] = {1u, 1u};
+    if (ok && scan_buffers(m, 1, false) != LOM_OK) ok = 0;
+    if (ok) {
+        m->p2p = true;
+        const P2pArgs A = p2p_args(m);
+        m->p2p = false;
+        hipLaunchKernelGGL(k_p2p_selftest, dim3(1), dim3(64), 0, m->stream, A, m->lm_seq, 200,
+                           server_timeout_ticks(), (uint32_t *)m->results.p);
+        if (hipGetLastError() != hipSuccess ||
+            hipMemcpyAsync(res, (uint32_t *)m->results.p, 8, hipMemcpyDeviceToHost, m->stream) != hipSuccess ||
+            hipStreamSynchronize(m->stream) != hipSuccess)
+            ok = 0;
+        else if (res[0] != 0 || res[1] != 0)
+            ok = 0;
+    }
+    m->lm_seq += 256;
+    double verdict[1] = {ok ? 0.0 : 1.0};
+    if (lom_host_comm_allreduce(hc, verdict, 1) != LOM_OK) verdict[0] = 1.0;
+    if (verdict[0] != 0.0) {
+        p2p_detach(m);
+        m->rank = 0;
+        m->nranks = 1;
+        return set_error(m, LOM_ERR_COMM, "device-to-device exchange failed its self-test on some rank");
+    }
+    m->host_comm = hc;  // rank / nranks bookkeeping as with the host exchange; the caller keeps ownership
+    m->p2p = true;
+    return LOM_OK;
 }
 
 int lom_profile_match(lom_map *m, const float *d_src, size_t n, size_t stride, const float t[3], const float q[4],

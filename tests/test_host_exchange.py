@@ -47,6 +47,30 @@ def _stress_worker(rank, world, ident, n_iter, q):
     q.put((rank, ok, digest))
 
 
+def _gather_worker(rank, world, ident, n_iter, q):
+    sys.path.insert(0, ROOT)
+    import lidar_odometry_demo_amd as lom
+
+    L = lom.capi.lib()
+    h = C.c_void_p()
+    assert L.lom_host_comm_create(rank, world, ident, C.byref(h)) == 0
+    ok = True
+    for it in range(n_iter):
+        nbytes = 1 + (it * 37) % 256                               # every size up to a full slot
+        mine = bytes((rank * 31 + it + k) & 0xFF for k in range(nbytes))
+        out = C.create_string_buffer(world * nbytes)
+        assert L.lom_host_comm_allgather(h, mine, nbytes, out) == 0
+        for r in range(world):
+            want = bytes((r * 31 + it + k) & 0xFF for k in range(nbytes))
+            ok = ok and out.raw[r * nbytes:(r + 1) * nbytes] == want
+        if it % 5 == 0:                                            # interleaved with all-reduces: one sequence
+            buf = (C.c_double * 1)(float(rank))
+            assert L.lom_host_comm_allreduce(h, buf, 1) == 0
+            ok = ok and buf[0] == float(sum(range(world)))
+    L.lom_host_comm_destroy(h)
+    q.put((rank, ok))
+
+
 def _align_worker(rank, world, ident, q):
     sys.path.insert(0, ROOT)
     import lidar_odometry_demo_amd as lom
@@ -93,6 +117,13 @@ def test_host_exchange_stress_three_ranks():
     res = _run(_stress_worker, 3, 3000)
     assert all(ok for _, ok, _ in res)
     assert len({d for _, _, d in res}) == 1          # bitwise the same history on every rank
+
+
+def test_host_allgather_bytes_three_ranks():
+    """Raw-byte all-gather (carries the IPC handles of the device-to-device exchange), mixed with
+    all-reduces on the same object."""
+    res = _run(_gather_worker, 3, 400)
+    assert all(ok for _, ok in res)
 
 
 @pytest.mark.parametrize("world", [2, 4])
