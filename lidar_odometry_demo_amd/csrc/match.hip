@@ -1328,7 +1328,8 @@ __global__ __launch_bounds__(kEvalThreads) void k_lm(const MatchRec *__restrict_
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            global_exchange(px, s_tot, seq, timeout_ticks, &s_failed, blockIdx.x == 0, lane);
+            // ten times the patience of the in-GPU waits: the peers are other processes
+            global_exchange(px, s_tot, seq, timeout_ticks * 10, &s_failed, blockIdx.x == 0, lane);
         }
         LM_STAMP(3);
         if (wave == 0 && !s_failed) {
@@ -1887,7 +1888,15 @@ static int align_device(lom_map *m, const char *d_src, size_t n, size_t stride, 
     m->profiling = m->profile_period > 0 && (m->align_count++ % (unsigned)m->profile_period) == 0;
     if (!m->comm && (!m->host_comm || m->p2p) && !getenv("LOM_HOST_LM")) {
         server_stop(m);
-        return align_chained(m, d_src, n, stride, guess_t, guess_q, out_t, out_q, stats);
+        const int rc = align_chained(m, d_src, n, stride, guess_t, guess_q, out_t, out_q, stats);
+        if (rc == LOM_OK || !m->p2p) return rc;
+        // A rank that gives up stops publishing, so every rank gives up on the same align: all of
+        // them fall back to the host-driven loop over the host exchange (still attached) and redo it.
+        fprintf(stderr, "lidar_odometry_amd: device-to-device exchange failed (%s); rank %d continues with the host exchange\n",
+                m->last_error.c_str(), m->rank);
+        (void)hipStreamSynchronize(m->stream);
+        m->p2p = false;
+        m->last_error.clear();
     }
     int rc = scan_buffers(m, (uint32_t)n, false);
     if (rc != LOM_OK) return rc;
@@ -1993,9 +2002,14 @@ int lom_comm_attach_p2p(lom_map *m, lom_host_comm *hc)
     } mine, all[kP2pMaxRanks];
     std::memset(&mine, 0, sizeof mine);
     static_assert(sizeof(Blob) <= 256, "fits one host-exchange slot");
-    if (hipMalloc(&m->p2p_local, bytes) != hipSuccess) {
-        m->p2p_local = nullptr;
-        ok = 0;
+    // fine-grained (coherent across agents) device memory; plain device memory if that is refused --
+    // the self-test below decides whether the exchange works on this machine
+    if (hipExtMallocWithFlags(&m->p2p_local, bytes, hipDeviceMallocFinegrained) != hipSuccess) {
+        (void)hipGetLastError();
+        if (hipMalloc(&m->p2p_local, bytes) != hipSuccess) {
+            m->p2p_local = nullptr;
+            ok = 0;
+        }
     }
     if (ok && (hipMemsetAsync(m->p2p_local, 0, bytes, m->stream) != hipSuccess ||
                hipStreamSynchronize(m->stream) != hipSuccess))

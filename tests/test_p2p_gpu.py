@@ -41,6 +41,18 @@ def _rank_main(rank, world, ident, q):
         L.lom_host_comm_allreduce(hc, buf, 1)                       # start the aligns together
         p = m.align(g, np.ascontiguousarray(scan[lo:hi]), guess)
         out.append((p.translation.tobytes(), p.rotation.tobytes(), dict(m.stats)))
+    # a rank that gives up waiting stops publishing, so all ranks give up on the same align: they
+    # fall back to the host-driven loop over the host exchange and redo it (1-tick patience forces that)
+    os.environ["LOM_TEST_SERVER_TIMEOUT_TICKS"] = "1"
+    guess = lom.Pose3D((0.0, 0.0, 0.0), scenes.angle_axis_q(0.01, (0, 0, 1)))
+    buf = (C.c_double * 1)(0.0)
+    L.lom_host_comm_allreduce(hc, buf, 1)
+    p = m.align(g, np.ascontiguousarray(scan[lo:hi]), guess)
+    out.append((p.translation.tobytes(), p.rotation.tobytes(), dict(m.stats)))
+    os.environ["LOM_TEST_SERVER_TIMEOUT_TICKS"] = "300000000"
+    L.lom_host_comm_allreduce(hc, buf, 1)
+    p = m.align(g, np.ascontiguousarray(scan[lo:hi]), guess)          # stays on the host exchange
+    out.append((p.translation.tobytes(), p.rotation.tobytes(), dict(m.stats)))
     L.lom_comm_finalize(g.handle)
     L.lom_host_comm_destroy(hc)
     q.put((rank, "ok", out))
@@ -74,3 +86,12 @@ def test_two_ranks_exchange_on_the_device(lom):
         assert dt < 1e-6 and dr < 1e-6, (dt, dr)         # and with the single-rank pose (summation order differs)
         for k in ("outer_iterations", "queries", "cand_total", "occ_total", "valid_last"):
             assert s0[k] == s1[k] == m.stats[k], k       # totals over all ranks
+    # after the forced failure (entries 2 and 3): host exchange, same answer as the first align
+    ref = m.align(g, sm["scan"], lom.Pose3D((0.0, 0.0, 0.0), scenes.angle_axis_q(0.01, (0, 0, 1))))
+    for i in (2, 3):
+        (t0, q0, s0), (t1, q1, s1) = res[0][2][i], res[1][2][i]
+        assert t0 == t1 and q0 == q1
+        dt, dr = scenes.pose_delta(np.frombuffer(t0, np.float32), np.frombuffer(q0, np.float32),
+                                   ref.translation, ref.rotation)
+        assert dt < 1e-6 and dr < 1e-6, (dt, dr)
+        assert s0["outer_iterations"] == m.stats["outer_iterations"] and s0["queries"] == m.stats["queries"]
