@@ -769,6 +769,11 @@ __device__ __forceinline__ void reduce_and_exchange(const double acc[28], double
         bool ok[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) ok[u] = (k >= 31) || ((uint32_t)(g * 4 + u) >= nb);
+        // Let the words land before the first poll: a poll that comes too early is a wasted memory
+        // round trip (and 52 workgroups x 512 lanes of them load the memory side).  Measured on C2:
+        // no head start 0.1724 ms per align, s_sleep 8 / 12 / 16 / 20 / 24 -> 0.1668 / 0.1657 / 0.1645 /
+        // 0.1650 / 0.1650.
+        __builtin_amdgcn_s_sleep(16);
         const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
         for (;;) {
             unsigned long long cb[4];
