@@ -840,8 +840,8 @@ __device__ __forceinline__ void reduce_and_exchange(const double acc[28], double
 // lane issuing ~1500 f64 instructions costs ~4 us per step on a 64-wide SIMD.  Here lane r < 6
 // owns row r of the 6x6 system; values another row needs travel by v_readlane (uniform
 // broadcasts), so a step is ~400 instructions.  Differences from the serial code are at rounding
-// level only: sqrt / reciprocal of the Cholesky pivots come from v_rsq_f64 + two Goldschmidt steps
-// instead of the correctly rounded library calls.  All 64 lanes run the code (uniform control
+// level only: the 6x6 system is factored as L D L^T with reciprocals from v_rcp_f64 + two Newton
+// steps (lm_core.hpp: Cholesky with the correctly rounded library sqrt and division).  All 64 lanes run the code (uniform control
 // flow); lanes >= 6 compute unused values and never store.
 __device__ __forceinline__ double lane_bcast(double v, int k)
 {
@@ -863,6 +863,37 @@ __device__ __forceinline__ void sqrt_and_inverse(double d, double &root, double 
     const double dd = __builtin_fma(-g, g, d);
     root = __builtin_fma(dd, h, g);
     inv = h + h;
+}
+
+__device__ __forceinline__ double fast_rcp(double d)  // v_rcp_f64 + two Newton steps
+{
+    double y = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-d, y, 1.0);
+    return __builtin_fma(y, e, y);
+}
+
+// manifold_plus (pose_math.hpp) with the square root from v_rsq_f64: one dependent chain shorter
+__device__ __forceinline__ void manifold_plus_fast(const double x[7], const double d[6], double out[7])
+{
+    const double n2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+    if (n2 == 0.0) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) out[i] = x[i];
+    } else {
+        double nd, unused;
+        sqrt_and_inverse(n2, nd, unused);
+        double s, c;
+        sinc_cos(nd, s, c);
+        const double z[4] = {c, s * d[0], s * d[1], s * d[2]};
+        out[0] = z[0] * x[0] - z[1] * x[1] - z[2] * x[2] - z[3] * x[3];
+        out[1] = z[0] * x[1] + z[1] * x[0] + z[2] * x[3] - z[3] * x[2];
+        out[2] = z[0] * x[2] - z[1] * x[3] + z[2] * x[0] + z[3] * x[1];
+        out[3] = z[0] * x[3] + z[1] * x[2] - z[2] * x[1] + z[3] * x[0];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; i++) out[4 + i] = x[4 + i] + d[3 + i];
 }
 
 // lm_assemble for lane r: its row of A, its g, and the (uniform) cost
@@ -1048,42 +1079,43 @@ __device__ __forceinline__ int lmw_propose(LmState &S, int lane)
     double cand[7] = {0, 0, 0, 0, 0, 0, 0}, model_change = 0.0;
     while (iter <= kLmMaxIter) {
         if (!reuse_diag) diag_r = fmin(fmax(lmw_pick(As, r), kLmMinDiag), kLmMaxDiag);
-        const double inv_radius = 1.0 / radius;
+        const double inv_radius = fast_rcp(radius);
         double M[6];
 #pragma unroll
         for (int j = 0; j < 6; j++) M[j] = (r == j) ? As[j] + diag_r * inv_radius : As[j];
-        // Cholesky, column by column: lane r ends with row r of L in M[0..r]; Lt[j] of lane k = L[j][k]
-        double inv[6], Lt[6] = {0, 0, 0, 0, 0, 0};
+        // M = L D L^T, column by column (positive pivots <=> the Cholesky factor of lm_core.hpp
+        // exists): lane r ends with l_rk in M[k] for k < r and d_r in M[r]; Lt[j] of lane k = l_jk.
+        // Unit triangles: the substitutions below carry no scaling in their dependent chains.
+        double invd[6], Lt[6] = {0, 0, 0, 0, 0, 0};
         bool ok = true;
 #pragma unroll
         for (int k = 0; k < 6; k++) {
             const double d = lane_bcast(M[k], k);
             if (!(d > 0.0)) ok = false;
-            double root, invk;
-            sqrt_and_inverse(d, root, invk);
-            inv[k] = invk;
-            const double Lrk = M[k] * invk;  // L[r][k] for r > k
+            const double id = fast_rcp(d);
+            invd[k] = id;
+            const double Lrk = M[k] * id;  // l_rk for r > k
 #pragma unroll
             for (int j = k + 1; j < 6; j++) {
-                const double Ljk = lane_bcast(Lrk, j);
-                M[j] -= Lrk * Ljk;
-                Lt[j] = (r == k) ? Ljk : Lt[j];
+                const double Cjk = lane_bcast(M[k], j);  // M[j][k], not yet scaled
+                M[j] -= Lrk * Cjk;
+                Lt[j] = (r == k) ? Cjk * id : Lt[j];
             }
-            M[k] = (r == k) ? root : Lrk;
+            M[k] = (r == k) ? d : Lrk;
         }
         double y[6];
         if (ok) {
             double s_r = gs_r, zv = 0.0;
 #pragma unroll
             for (int m = 0; m < 6; m++) {  // L z = gs
-                const double zm = lane_bcast(s_r, m) * inv[m];
+                const double zm = lane_bcast(s_r, m);
                 s_r -= M[m] * zm;
                 zv = (r == m) ? zm : zv;
             }
-            double t_r = zv;
+            double t_r = zv * lmw_pick(invd, r);  // D w = z
 #pragma unroll
-            for (int m = 5; m >= 0; m--) {  // L^T y = z
-                const double ym = lane_bcast(t_r, m) * inv[m];
+            for (int m = 5; m >= 0; m--) {  // L^T y = w
+                const double ym = lane_bcast(t_r, m);
                 t_r -= Lt[m] * ym;
                 y[m] = ym;
             }
@@ -1120,7 +1152,7 @@ __device__ __forceinline__ int lmw_propose(LmState &S, int lane)
         double delta[6];
 #pragma unroll
         for (int c = 0; c < 6; c++) delta[c] = step[c] * scale_c[c];
-        manifold_plus(xs, delta, cand);
+        manifold_plus_fast(xs, delta, cand);
         result = LM_EVAL;
         break;
     }
@@ -1135,13 +1167,16 @@ __device__ __forceinline__ int lmw_propose(LmState &S, int lane)
         S.iter = iter;
         S.recorded = recorded;
         S.last_step_norm = last_step_norm;
-        if (result == LM_EVAL) {
-#pragma unroll
-            for (int i = 0; i < 7; i++) S.cand[i] = cand[i];
+        if (result == LM_EVAL)
             S.model_change = model_change;
-        } else {
+        else
             S.cost = S.N.cost;
-        }
+    }
+    if (result == LM_EVAL && lane < 7) {  // one store: lane i writes cand[i]
+        double v = cand[0];
+#pragma unroll
+        for (int i = 1; i < 7; i++) v = (lane == i) ? cand[i] : v;
+        S.cand[lane] = v;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -1310,10 +1345,10 @@ __global__ __launch_bounds__(kEvalThreads) void k_lm(const MatchRec *__restrict_
     uint32_t counters_from = n_match_blocks;  // k_match's counters are folded by the first evaluation only
     double counters[4] = {0.0, 0.0, 0.0, 0.0};  // valid, cand, occ of the last k_match; queries (all ranks)
     int action = LM_EVAL;
-    // LOM_DEBUG_LM: shader-clock stamps of workgroup 0's first lane (0 start, 1 accumulated,
-    // 3 totals known, 4 policy done); entries of different launches of one align overwrite each other
+    // LOM_DEBUG_LM: shader-clock stamps of workgroup 0's first lane in the first k_lm of the align
+    // (0 start, 1 accumulated, 3 totals known, 4 policy done)
 #define LM_STAMP(k)                                                                            \
-    if (dbg_stamps && blockIdx.x == 0 && tid == 0 && ev < 5) {                                 \
+    if (dbg_stamps && first_outer && blockIdx.x == 0 && tid == 0 && ev < 5) {                  \
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                            \
         dbg_stamps[ev * 5 + (k)] = __builtin_amdgcn_s_memtime();                               \
     }
@@ -1325,7 +1360,7 @@ __global__ __launch_bounds__(kEvalThreads) void k_lm(const MatchRec *__restrict_
         seq++;
         XWord *set = xrec + (size_t)(seq & 1) * kMaxLmBlocks * kRecWords;
         reduce_and_exchange(acc, s_acc, s_part, block_counters, counters_from, set, nb, seq, timeout_ticks,
-                            s_tot, &s_failed, (dbg_stamps && ev == 1) ? dbg_stamps + 32 : nullptr);
+                            s_tot, &s_failed, (dbg_stamps && first_outer && ev == 1) ? dbg_stamps + 32 : nullptr);
         counters_from = 0;
         if (px.nranks > 1 && wave == 0 && !s_failed) {
             // ranks of one node: this GPU's totals become the totals over all ranks
