@@ -306,4 +306,81 @@ struct CloudTransformer {
     }
 };
 
+// ---- LidarOdometry (src/lidar_odometry.h:20-85) --------------------------------------
+// For callers that do not keep the reference's own orchestration: processCloud, getCurrentPose and the
+// two key-frame exporters over lom_odometry_*.  lidar_point::PointXYZIRT (src/lidar_point_type.h:13-31)
+// has the layout of lom_point_xyzirt, so a PCL cloud's points can be passed as they are.
+class LidarOdometry {
+public:
+    struct Params {  // lidar_odometry.h:23-48, defaults of GetROSDeclaration()
+        float lidar_min_range = 4.0f;
+        float lidar_max_range = 80.0f;
+        float keyframe_voxel_size = 0.2f;
+        size_t keyframe_max_points_cnt = 20;
+        float keyframe_matching_voxel_size = 0.3f;
+        float keyframe_update_voxel_size = 0.1f;
+        float keyframe_cleanup_range = 80.0f;
+        float angular_divergence_threshold = 5.0f;
+    };
+    using CloudType = PointCloud<lom_point_xyzirt>;
+
+    explicit LidarOdometry(const Params &config, int device = 0)
+    {
+        lom_odometry_params p;
+        p.lidar_min_range = config.lidar_min_range;
+        p.lidar_max_range = config.lidar_max_range;
+        p.keyframe_voxel_size = config.keyframe_voxel_size;
+        p.keyframe_max_points_cnt = (uint32_t)config.keyframe_max_points_cnt;
+        p.keyframe_matching_voxel_size = config.keyframe_matching_voxel_size;
+        p.keyframe_update_voxel_size = config.keyframe_update_voxel_size;
+        p.keyframe_cleanup_range = config.keyframe_cleanup_range;
+        p.angular_divergence_threshold = config.angular_divergence_threshold;
+        const int rc = lom_odometry_create(&p, device, &h_);
+        if (rc != LOM_OK) throw Error(rc, lom_last_error(nullptr));
+    }
+    ~LidarOdometry() { lom_odometry_destroy(h_); }
+    LidarOdometry(const LidarOdometry &) = delete;
+    LidarOdometry &operator=(const LidarOdometry &) = delete;
+
+    void processCloud(const CloudType &input_cloud)  // lidar_odometry.cpp:22-77
+    {
+        const int rc = lom_odometry_process_cloud(h_, input_cloud.points.data(), input_cloud.points.size());
+        if (rc != LOM_OK) throw Error(rc, lom_odometry_last_error(h_));
+    }
+    Pose3D getCurrentPose() const  // :87-89
+    {
+        lom_pose p;
+        lom_odometry_get_pose(h_, &p);
+        return Pose3D::from(p);
+    }
+    PointCloud<PointXYZ>::Ptr getKeyFrameCloud() const { return export_(LOM_EXPORT_FIRST_PER_VOXEL); }      // :79-81
+    PointCloud<PointXYZ>::Ptr getFullKeyFrameCloud() const { return export_(LOM_EXPORT_FULL_NO_NORMALS); }  // :83-85
+    lom_odometry_frame_stats lastFrameStats() const
+    {
+        lom_odometry_frame_stats s;
+        lom_odometry_get_stats(h_, &s);
+        return s;
+    }
+
+private:
+    PointCloud<PointXYZ>::Ptr export_(int mode) const
+    {
+        lom_map *kf = lom_odometry_keyframe(h_);
+        auto out = std::make_shared<PointCloud<PointXYZ>>();
+        const int64_t n = lom_map_export(kf, mode, nullptr, nullptr, 0);
+        if (n < 0) throw Error((int)n, lom_last_error(kf));
+        std::vector<float> xyz((size_t)n * 3 + 3);
+        const int64_t m = lom_map_export(kf, mode, xyz.data(), nullptr, (size_t)n);
+        if (m < 0) throw Error((int)m, lom_last_error(kf));
+        out->points.resize((size_t)n);
+        for (size_t i = 0; i < (size_t)n; i++) {
+            out->points[i].x = xyz[3 * i];
+            out->points[i].y = xyz[3 * i + 1];
+            out->points[i].z = xyz[3 * i + 2];
+        }
+        return out;
+    }
+    lom_odometry *h_ = nullptr;
+};
+
 }  // namespace lom

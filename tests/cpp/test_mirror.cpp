@@ -158,6 +158,55 @@ static void CloudMatcher_MatchingTest()  // protocol of test.cpp:226-262 on a sy
     EXPECT(keyframe.size() < before && keyframe.size() > 0);
 }
 
+// LidarOdometry (lidar_odometry.h:65-76) over a synthetic room: 16 beams x 900 azimuth steps ray-cast
+// against an axis-aligned box, the sensor moving 0.1 m per frame along +x
+static void LidarOdometry_RoomSequence()
+{
+    LidarOdometry::Params params;
+    LidarOdometry odometry(params);
+    const float half[3] = {24.f, 17.f, 0.f};  // walls at x = +-24, y = +-17; floor z = -2, ceiling z = 7
+    const float zlo = -2.f, zhi = 7.f;
+    const int n_frames = 8;
+    for (int f = 0; f < n_frames; f++) {
+        const float sx = 0.1f * (float)f;
+        LidarOdometry::CloudType cloud;
+        for (int ring = 0; ring < 16; ring++) {
+            const float el = (-15.f + 2.f * (float)ring) * 3.14159265358979f / 180.f;
+            for (int a = 0; a < 900; a++) {
+                const float az = (float)a * (2.f * 3.14159265358979f / 900.f);
+                const float d[3] = {std::cos(el) * std::cos(az), -std::cos(el) * std::sin(az), std::sin(el)};
+                float t = 1e9f;
+                if (d[0] > 1e-6f) t = std::fmin(t, (half[0] - sx) / d[0]);
+                if (d[0] < -1e-6f) t = std::fmin(t, (-half[0] - sx) / d[0]);
+                if (d[1] > 1e-6f) t = std::fmin(t, half[1] / d[1]);
+                if (d[1] < -1e-6f) t = std::fmin(t, -half[1] / d[1]);
+                if (d[2] > 1e-6f) t = std::fmin(t, zhi / d[2]);
+                if (d[2] < -1e-6f) t = std::fmin(t, zlo / d[2]);
+                lom_point_xyzirt p{};
+                p.x = t * d[0];
+                p.y = t * d[1];
+                p.z = t * d[2];
+                p.intensity = 1.f;
+                p.ring = (uint16_t)ring;
+                p.time = (float)a / 900.f * 0.1f;
+                cloud.points.push_back(p);
+            }
+        }
+        odometry.processCloud(cloud);
+        const auto st = odometry.lastFrameStats();
+        EXPECT(st.planar_points > 2000 && st.filtered_points > 1000);
+        if (f == 0) EXPECT(st.initialised_keyframe == 1);
+        if (f > 0) EXPECT(st.outer_iterations >= 5 && st.matching_points > 200);
+    }
+    const Pose3D pose = odometry.getCurrentPose();
+    EXPECT(std::fabs(pose.translation.x() - 0.1f * (float)(n_frames - 1)) < 0.1f);
+    EXPECT(std::fabs(pose.translation.y()) < 0.05f && std::fabs(pose.translation.z()) < 0.05f);
+    EXPECT(std::fabs(pose.rotation.w()) > 0.9999f);
+    auto sparse = odometry.getKeyFrameCloud();
+    auto full = odometry.getFullKeyFrameCloud();
+    EXPECT(sparse->size() > 1000 && full->size() >= sparse->size());
+}
+
 int main()
 {
     try {
@@ -166,6 +215,7 @@ int main()
         Pose3D_ComposeRelativeInverse();
         CloudTransformer_RigidTransform();
         CloudMatcher_MatchingTest();
+        LidarOdometry_RoomSequence();
     } catch (const lom::Error &e) {
         std::printf("lom::Error %d: %s\n", e.code, e.what());
         return 2;
