@@ -109,9 +109,22 @@ def cpu_baseline(work, budget_s=10.0):
         el = time.perf_counter() - t0
         if el > budget_s or frames >= 2000:
             break
+    # also a 1-thread total (a few frames)
+    m1 = O.CloudMatcher(nthreads=1)
+    f1, q1 = 0, 0
+    t1 = time.perf_counter()
+    while True:
+        m1.align(g, work["scan"], O.Pose3D())
+        f1 += 1
+        q1 += m1.stats["queries"]
+        el1 = time.perf_counter() - t1
+        if el1 > budget_s / 4 or f1 >= 500:
+            break
     return {"value": queries / el / 1e6, "unit": "Mcorr/s", "cores": cores, "kind": "port",
             "frames_per_s": frames / el,
-            "sample": f"{frames} full frames of the same workload ({queries} queries, {el:.1f} s); "
+            "single_thread_value": q1 / el1 / 1e6, "single_thread_frames_per_s": f1 / el1,
+            "sample": f"{frames} full frames of the same workload ({queries} queries, {el:.1f} s) with the search on "
+                      f"{cores} threads and the solve on one, then {f1} frames on one thread ({el1:.1f} s); "
                       "CPU restatement of the reference algorithm (oracle/), not the reference binary"}
 
 
@@ -388,6 +401,7 @@ def main():
                 "map_points_stored": grid.pointCount(),
                 "map_voxels": grid.size(),
                 "pcie_inclusive_ms_per_step": pcie_ms,
+                "valid_match_rate": tot["valid_last"] / max(1, int(len(work["scan"]))),
                 "outer_iterations_per_frame": outer / args.steps,
                 "evaluations_per_frame": evals / args.steps,
                 "parallelism": f"source-range x{n}, map replicated" if n > 1 else "single GPU",
