@@ -186,7 +186,7 @@ class VoxelGrid:
         self.max_points = int(max_points)
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and lib is not None:   # module globals may be gone at interpreter exit
             lib().orc_map_destroy(self._h)
             self._h = None
 
@@ -277,7 +277,7 @@ class Shard:
         self._h = lib().orc_shard_create(keyframe._h, self._xyz.ctypes.data, len(self._xyz), 12)
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and lib is not None:
             lib().orc_shard_destroy(self._h)
             self._h = None
 
@@ -395,7 +395,7 @@ class LidarOdometry:
         self.nthreads = nthreads
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and _pipeline_lib is not None:
             _pipeline_lib().orc_odom_destroy(self._h)
             self._h = None
 

@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""One-off stress against the CPU oracle: random maps (clusters, duplicates, the double-width voxel 0),
+voxel sizes, caps, cleanups; correspondence search bit-exact, align within 1e-4 m / 1e-4 rad with
+equal iteration counts.  (tests/test_gpu_parity.py holds the committed subset of this.)"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: F401,E402
+import lidar_odometry_demo_amd as lom  # noqa: E402
+from oracle import oracle  # noqa: E402
+from tests import scenes  # noqa: E402
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+rng = np.random.default_rng(987654321)
+sm = scenes.small_synth_case()
+bad = 0
+worst = [0.0, 0.0]
+for case in range(n_cases):
+    K = int(rng.choice([1, 2, 3, 7, 20, 33]))
+    voxel = float(rng.choice([0.1, 0.25, 0.37, 0.5, 1.0]))
+    g, og = lom.VoxelGrid(voxel, K), oracle.VoxelGrid(voxel, K)
+    for rnd in range(3):
+        n = int(rng.integers(1, 5000))
+        centers = rng.uniform(-6, 6, size=(int(rng.integers(1, 40)), 3))
+        pts = (centers[rng.integers(0, len(centers), n)] + rng.normal(0, rng.uniform(0.01, 0.8), (n, 3))).astype(np.float32)
+        pts[rng.random(n) < 0.05] *= np.float32(0.01)
+        nrm = rng.standard_normal((n, 3)).astype(np.float32)
+        g.addCloud(pts, nrm)
+        og.addCloud(pts, nrm)
+        if rnd == 1:
+            c = rng.uniform(-3, 3, 3).astype(np.float32)
+            r = float(rng.uniform(2, 9))
+            g.radiusCleanup(c, r)
+            og.radiusCleanup(c, r)
+        q = rng.uniform(-7, 7, (int(rng.integers(1, 3000)), 3)).astype(np.float32)
+        pose = (rng.uniform(-0.5, 0.5, 3), scenes.angle_axis_q(rng.uniform(-0.3, 0.3), scenes._unit(rng.standard_normal(3))))
+        d = float(rng.choice([0.05, 0.3, 1.0]))
+        a, b = g.findMatchingPairs(q, lom.Pose3D(*pose), d), og.findMatchingPairs(q, oracle.Pose3D(*pose), d)
+        same = (np.array_equal(a["index"], b["index"]) and a["sq_dist"].tobytes() == b["sq_dist"].tobytes()
+                and a["origin"].tobytes() == b["origin"].tobytes() and a["normal"].tobytes() == b["normal"].tobytes()
+                and np.array_equal(a["n_cand"], b["n_cand"]) and np.array_equal(a["n_occ"], b["n_occ"]))
+        if not same:
+            bad += 1
+            print("SEARCH MISMATCH", case, rnd, voxel, K, flush=True)
+    # align on the structured scene with this case's voxel / cap
+    g2, og2 = lom.VoxelGrid(voxel, K), oracle.VoxelGrid(voxel, K)
+    g2.addCloud(sm["map_xyz"], sm["map_nrm"])
+    og2.addCloud(sm["map_xyz"], sm["map_nrm"])
+    m, om = lom.CloudMatcher(), oracle.CloudMatcher()
+    n = int(rng.choice([3, 100, 777, len(sm["scan"])]))
+    sel = np.sort(rng.choice(len(sm["scan"]), n, replace=False))
+    scan = np.ascontiguousarray(sm["scan"][sel])
+    t = rng.uniform(-0.2, 0.2, 3)
+    qq = scenes.angle_axis_q(rng.uniform(-0.03, 0.03), scenes._unit(rng.standard_normal(3)))
+    p, op = m.align(g2, scan, lom.Pose3D(t, qq)), om.align(og2, scan, oracle.Pose3D(t, qq))
+    dt, dr = scenes.pose_delta(p.translation, p.rotation, op.translation, op.rotation)
+    worst = [max(worst[0], dt), max(worst[1], dr)]
+    if dt > 1e-4 or dr > 1e-4 or m.stats["outer_iterations"] != om.stats["outer_iterations"]:
+        bad += 1
+        print("ALIGN MISMATCH", case, voxel, K, n, dt, dr, m.stats["outer_iterations"], om.stats["outer_iterations"], flush=True)
+print(f"{n_cases} cases: mismatches {bad}; worst align delta {worst[0]:.2e} m {worst[1]:.2e} rad")
+sys.exit(1 if bad else 0)
