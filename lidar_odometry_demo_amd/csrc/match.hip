@@ -920,9 +920,16 @@ __device__ __forceinline__ void lmw_assemble(const double *s, const double *xx, 
 
 __device__ __forceinline__ double lmw_pick(const double v[6], int r)  // v[r], r varies by lane
 {
+    // Conditional moves, kept as such: the compiler recognises a select chain over one index as v[r]
+    // and implements that as an array in scratch memory (stores + a dependent scratch load in the
+    // middle of the policy's chain).  An opaque copy of the index per comparison prevents it.
     double o = v[0];
 #pragma unroll
-    for (int j = 1; j < 6; j++) o = (r == j) ? v[j] : o;
+    for (int j = 1; j < 6; j++) {
+        int rj = r;
+        asm volatile("" : "+v"(rj));
+        o = (rj == j) ? v[j] : o;
+    }
     return o;
 }
 
@@ -1405,7 +1412,7 @@ __global__ __launch_bounds__(kEvalThreads) void k_lm(const MatchRec *__restrict_
 #undef LM_STAMP
     if (blockIdx.x != 0 || tid != 0) return;
     // ---- end of the outer iteration (workgroup 0, one lane) ----
-    const LmState S = s_lm;
+    const LmState &S = s_lm;  // read the few fields needed where they live (LDS)
     const int outer = first_outer ? 0 : state->outer_done;
     float pq[4], pt[3];
     for (int a = 0; a < 4; a++) pq[a] = (float)S.x[a];      // :161-164
