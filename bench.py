@@ -60,11 +60,23 @@ def build_workload(n_gpus, rank, config="C2"):
         scan, ring, az, _ = synth.make_scan(64, 2048, boxes=boxes)
         map_xyz, map_nrm = synth.make_map_points(2_000_000, boxes=boxes)
         return dict(scan=scan, shard=scan, map_xyz=map_xyz, map_nrm=map_nrm,
-                    name="C3: 64x2048 scan vs 2M-pt map, voxel 0.5 m, cap 20")
+                    name="C3 (BASELINE configs[2]): 64x2048 scan vs 2M-pt map, voxel 0.5 m, cap 20")
+    if config == "C4":
+        # BASELINE.json configs[3]: 128 beams x 2048 azimuth steps (<= 262,144 returns) vs the 2M-point map
+        # replicated on every GPU; the scan is split into `n_gpus` contiguous index ranges (SURVEY.md 8d:
+        # 8 x 32,768 on 8 GPUs; "also run with 1/2/4 ranks"), one exchange of the 32 reduced sums per
+        # residual evaluation.  Total work is fixed: strong scaling.
+        scan, ring, az, _ = synth.make_scan(128, 2048, boxes=boxes)
+        map_xyz, map_nrm = synth.make_map_points(2_000_000, boxes=boxes)
+        lo, hi = len(scan) * rank // n_gpus, len(scan) * (rank + 1) // n_gpus
+        shard = np.ascontiguousarray(scan[lo:hi])
+        return dict(scan=scan, shard=shard, map_xyz=map_xyz, map_nrm=map_nrm,
+                    name=f"C4: 128x2048 scan ({len(scan)} returns) in {n_gpus} contiguous index range(s) "
+                         f"vs replicated 2M-pt map, voxel 0.5 m, cap 20")
     if n_gpus == 1:
         scan, ring, az, _ = synth.make_scan(16, 1800, boxes=boxes)
         shard = scan
-        name = "C2: VLP16 16x1800 scan vs 500k-pt map, voxel 0.5 m, cap 20"
+        name = "C2 (BASELINE configs[1]): VLP16 16x1800 scan vs 500k-pt map, voxel 0.5 m, cap 20"
     else:
         el = synth.beam_elevations(16)
         # 16*N beams spanning the VLP16 elevation range, firing (azimuth-major) order
@@ -83,7 +95,7 @@ def build_workload(n_gpus, rank, config="C2"):
         scan = scan[order]
         lo, hi = len(scan) * rank // n_gpus, len(scan) * (rank + 1) // n_gpus
         shard = np.ascontiguousarray(scan[lo:hi])
-        name = (f"C2 weak-scaled: {n_beams}x1800 scan, sector-major, in {n_gpus} contiguous index ranges "
+        name = (f"C2 (BASELINE configs[1]) weak-scaled: {n_beams}x1800 scan, sector-major, in {n_gpus} contiguous index ranges "
                 f"vs replicated 500k-pt map, voxel 0.5 m, cap 20")
     map_xyz, map_nrm = synth.make_map_points(500_000, boxes=boxes)
     return dict(scan=scan, shard=shard, map_xyz=map_xyz, map_nrm=map_nrm, name=name)
@@ -194,9 +206,11 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--config", choices=["C2", "C3", "C5"], default="C2",
-                    help="C2 = BASELINE.json configs[1] (the bench line); C3 = configs[2], single GPU only; "
-                         "C5 = configs[4], streaming LidarOdometry::processCloud (--steps = frames)")
+    ap.add_argument("--config", choices=["C2", "C3", "C4", "C5"], default="C2",
+                    help="C2 = BASELINE.json configs[1] (the bench line; weak-scaled with --gpus N); C3 = configs[2], "
+                         "single GPU only; C4 = configs[3], 128x2048 scan range-sharded over --gpus N ranks (any N "
+                         "incl. 1, strong scaling); C5 = configs[4], streaming LidarOdometry::processCloud "
+                         "(--steps = frames)")
     args = ap.parse_args()
     claim_stdout()
 
@@ -232,7 +246,7 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
 
-    if args.config != "C2" and n != 1:
+    if args.config not in ("C2", "C4") and n != 1:
         raise SystemExit(f"--config {args.config} is a single-GPU configuration")
     if args.config == "C5":
         return streaming(args, lom)
@@ -388,7 +402,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if (args.config == "C4" and n > 1) else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "dtype_note": "f32 distances on f64-transformed queries (search); f64 residuals, Jacobians and solve",

@@ -172,6 +172,9 @@ typedef struct {
     double host_launch_ms;     /* host time spent inside kernel-launch calls                   */
     double host_wait_ms;       /* host time spent waiting for evaluation results               */
     int64_t profiled_launches; /* correspondence launches that carried the HIP event pair      */
+    int32_t host_fallback;     /* 1: the device-resident loop gave up (its workgroups were not all
+                                  resident in time) and the align was redone by the host-driven loop */
+    int32_t reserved;
 } lom_align_stats;
 
 /* Replaces CloudMatcher::align (cloud_matcher.h:15-16): up to 35 outer iterations of
@@ -203,6 +206,22 @@ int lom_match_align_repeat(lom_map *m, const float *d_src_xyz, size_t n, size_t 
 int lom_debug_match_stamps(lom_map *m, const float *d_src_xyz, size_t n, size_t stride_bytes, const float t[3],
                            const float q_wxyz[4], float max_dist, unsigned long long *stamps_out,
                            size_t cap_blocks, uint32_t *n_blocks_out);
+
+/* Parity entries for PointToPlaneErrorAnalytic::Evaluate (src/cloud_matcher.cpp:38-103) and the reduction
+ * ceres::Solve performs inside the reference (the tests compare them with the oracle sum by sum).
+ * lom_debug_eval_sums: one correspondence search at the f32 pose (pose_t, pose_q) with the align's 0.3 m
+ * gate, then ONE evaluation of the LOM_NSUMS reduced sums at the f64 point (q, t) -- q need not be a unit
+ * quaternion, exactly as inside an align -- through the kernels of the host-driven path. */
+int lom_debug_eval_sums(lom_map *m, const float *src_xyz, size_t n, size_t stride_bytes, const float pose_t[3],
+                        const float pose_q_wxyz[4], const double q[4], const double t[3], double out[LOM_NSUMS]);
+/* lom_debug_lm_trace: lom_match_align on the device-resident path, also returning what the LM policy
+ * inside k_lm saw during outer iteration `outer_index`: trace_out[e * 40 + 0..6] = the point [q, t] of
+ * evaluation e, trace_out[e * 40 + 8 .. + 39] = its LOM_NSUMS totals (after the in-kernel reduction and
+ * exchange); *n_evals_out = evaluations of that solve (<= 5; 0 when the align ended earlier).
+ * trace_out holds 200 doubles. */
+int lom_debug_lm_trace(lom_map *m, const float *src_xyz, size_t n, size_t stride_bytes, const float guess_t[3],
+                       const float guess_q_wxyz[4], int outer_index, double *trace_out, int *n_evals_out,
+                       float out_t[3], float out_q_wxyz[4], lom_align_stats *stats_or_null);
 
 /* Record a HIP event pair around the correspondence launches of lom_match_align*
  * (stats->match_kernel_ms over stats->profiled_launches launches).  `period` = 0: off; 1: every
@@ -318,6 +337,12 @@ int lom_odometry_create(const lom_odometry_params *p, int device, lom_odometry *
 void lom_odometry_destroy(lom_odometry *o);
 int lom_odometry_process_cloud(lom_odometry *o, const lom_point_xyzirt *pts, size_t n); /* :22-77 */
 int lom_odometry_get_pose(const lom_odometry *o, lom_pose *out);   /* getCurrentPose, :87-89 */
+/* getTempCloud(), lidar_odometry.h:73-75 (the node publishes it as /deskewed_cloud,
+ * lidar_odometry_node.cpp:66-75): the time-normalised, deskewed input cloud of the last processCloud
+ * (lidar_odometry.cpp:30-31), all fields kept.  Returns the number of points it holds (0 before the
+ * first frame, where the reference returns a null pointer); writes at most `cap` records; out may be
+ * NULL with cap 0 (count only). */
+int64_t lom_odometry_get_temp_cloud(const lom_odometry *o, lom_point_xyzirt *out, size_t cap);
 int lom_odometry_get_stats(const lom_odometry *o, lom_odometry_frame_stats *out);
 lom_map *lom_odometry_keyframe(lom_odometry *o); /* keyframe_ (getKeyFrameCloud / getFullKeyFrameCloud via lom_map_export) */
 const char *lom_odometry_last_error(const lom_odometry *o);

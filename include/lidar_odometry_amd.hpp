@@ -355,6 +355,17 @@ public:
     }
     PointCloud<PointXYZ>::Ptr getKeyFrameCloud() const { return export_(LOM_EXPORT_FIRST_PER_VOXEL); }      // :79-81
     PointCloud<PointXYZ>::Ptr getFullKeyFrameCloud() const { return export_(LOM_EXPORT_FULL_NO_NORMALS); }  // :83-85
+    // lidar_odometry.h:73-75; null before the first frame, like the reference's unset shared_ptr
+    CloudType::Ptr getTempCloud() const
+    {
+        const int64_t n = lom_odometry_get_temp_cloud(h_, nullptr, 0);
+        if (n < 0) throw Error((int)n, lom_odometry_last_error(h_));
+        if (n == 0) return nullptr;
+        auto out = std::make_shared<CloudType>();
+        out->points.resize((size_t)n);
+        lom_odometry_get_temp_cloud(h_, out->points.data(), (size_t)n);
+        return out;
+    }
     lom_odometry_frame_stats lastFrameStats() const
     {
         lom_odometry_frame_stats s;

@@ -221,6 +221,35 @@ class CloudMatcher:
         self.stats = st.asdict()
         return Pose3D(np.array(ot[:], np.float32), np.array(oq[:], np.float32))
 
+    def debugEvalSums(self, keyframe, planar_cloud, transform, q=None, t=None):
+        """One search at the f32 pose `transform`, then the LOM_NSUMS reduced sums of
+        PointToPlaneErrorAnalytic::Evaluate (cloud_matcher.cpp:38-103) at the f64 point (q, t)
+        (default: the widened pose) -- parity entry, host-driven path's kernels."""
+        xyz = capi.xyz_array(planar_cloud)
+        q = np.asarray(transform.rotation if q is None else q, np.float64)
+        t = np.asarray(transform.translation if t is None else t, np.float64)
+        out = (C.c_double * 32)()
+        capi.check(capi.lib().lom_debug_eval_sums(
+            keyframe.handle, xyz.ctypes.data, len(xyz), 12, capi.f3(transform.translation), capi.f4(transform.rotation),
+            (C.c_double * 4)(*q), (C.c_double * 3)(*t), out), keyframe.handle)
+        return np.array(out[:], np.float64)
+
+    def debugLmTrace(self, keyframe, planar_cloud, position_guess, outer_index=0):
+        """align() on the device-resident path plus what k_lm's policy saw in outer iteration
+        `outer_index`: [(x[7], sums[32]), ...] per evaluation.  Returns (pose, trace)."""
+        xyz = capi.xyz_array(planar_cloud)
+        ot, oq = (C.c_float * 3)(), (C.c_float * 4)()
+        st = capi.AlignStats()
+        raw = (C.c_double * 200)()
+        ne = C.c_int()
+        capi.check(capi.lib().lom_debug_lm_trace(
+            keyframe.handle, xyz.ctypes.data, len(xyz), 12, capi.f3(position_guess.translation),
+            capi.f4(position_guess.rotation), int(outer_index), raw, C.byref(ne), ot, oq, C.byref(st)), keyframe.handle)
+        self.stats = st.asdict()
+        a = np.array(raw[:], np.float64).reshape(5, 40)
+        trace = [(a[e, :7].copy(), a[e, 8:40].copy()) for e in range(ne.value)]
+        return Pose3D(np.array(ot[:], np.float32), np.array(oq[:], np.float32)), trace
+
     def alignDevice(self, keyframe, d_src_ptr, n, position_guess, stride_bytes=12):
         """Source cloud already resident in HBM (device pointer, e.g. torch tensor.data_ptr())."""
         ot, oq = (C.c_float * 3)(), (C.c_float * 4)()
@@ -316,6 +345,15 @@ class LidarOdometry:
         p = capi.Pose()
         capi.check(capi.lib().lom_odometry_get_pose(self._h, C.byref(p)))
         return Pose3D._from(p)
+
+    def getTempCloud(self):                                # lidar_odometry.h:73-75
+        """The deskewed input cloud of the last processCloud (None before the first frame)."""
+        n = capi.check(capi.lib().lom_odometry_get_temp_cloud(self._h, None, 0))
+        if n == 0:
+            return None
+        out = np.empty(n, capi.POINT_XYZIRT)
+        capi.check(capi.lib().lom_odometry_get_temp_cloud(self._h, out.ctypes.data, n))
+        return out
 
     def _keyframe_export(self, mode):
         kf = capi.lib().lom_odometry_keyframe(self._h)

@@ -49,7 +49,7 @@ class AlignStats(C.Structure):
         ("cand_total", C.c_int64), ("occ_total", C.c_int64), ("final_cost", C.c_double),
         ("last_step_norm", C.c_double), ("match_kernel_ms", C.c_double),
         ("algorithmic_bytes", C.c_double), ("host_launch_ms", C.c_double), ("host_wait_ms", C.c_double),
-        ("profiled_launches", C.c_int64),
+        ("profiled_launches", C.c_int64), ("host_fallback", C.c_int32), ("reserved", C.c_int32),
     ]
 
     def asdict(self):
@@ -98,12 +98,12 @@ EXPORTED = [
     "lom_map_destroy", "lom_last_error", "lom_map_clear", "lom_map_set_max_points", "lom_map_add_points",
     "lom_map_add_points_device", "lom_map_radius_cleanup", "lom_map_size", "lom_map_point_count",
     "lom_map_export", "lom_voxel_downsample", "lom_voxel_downsample_device", "lom_upload_points",
-    "lom_transform_points_device", "lom_map_get_stream", "lom_match_find_pairs", "lom_match_align", "lom_match_align_device", "lom_match_align_repeat", "lom_debug_match_stamps",
+    "lom_transform_points_device", "lom_map_get_stream", "lom_match_find_pairs", "lom_match_align", "lom_match_align_device", "lom_match_align_repeat", "lom_debug_match_stamps", "lom_debug_eval_sums", "lom_debug_lm_trace",
     "lom_map_set_profiling", "lom_profile_match", "lom_map_set_stream", "lom_comm_unique_id", "lom_comm_init",
     "lom_comm_finalize", "lom_comm_host_id", "lom_host_comm_create", "lom_host_comm_allreduce",
     "lom_host_comm_destroy", "lom_host_comm_allgather", "lom_comm_attach_host", "lom_comm_attach_p2p", "lom_align_with_hooks", "lom_point_time_normalize", "lom_transform_non_rigid",
     "lom_range_filter", "lom_cloud_classify", "lom_odometry_default_params", "lom_odometry_create",
-    "lom_odometry_destroy", "lom_odometry_process_cloud", "lom_odometry_get_pose", "lom_odometry_get_stats",
+    "lom_odometry_destroy", "lom_odometry_process_cloud", "lom_odometry_get_pose", "lom_odometry_get_stats", "lom_odometry_get_temp_cloud",
     "lom_odometry_keyframe", "lom_odometry_last_error",
 ]
 
@@ -186,6 +186,9 @@ def lib():
     L.lom_debug_match_stamps.argtypes = [vp, vp, C.c_size_t, C.c_size_t, fp, fp, C.c_float, vp, C.c_size_t,
                                          C.POINTER(C.c_uint32)]
     L.lom_match_align_repeat.argtypes = [vp, vp, C.c_size_t, C.c_size_t, fp, fp, C.c_int, fp, fp, C.POINTER(AlignStats)]
+    L.lom_debug_eval_sums.argtypes = [vp, vp, C.c_size_t, C.c_size_t, fp, fp, dp, dp, dp]
+    L.lom_debug_lm_trace.argtypes = [vp, vp, C.c_size_t, C.c_size_t, fp, fp, C.c_int, dp, C.POINTER(C.c_int), fp, fp,
+                                     C.POINTER(AlignStats)]
     L.lom_map_set_profiling.argtypes = [vp, C.c_int]
     L.lom_map_set_stream.argtypes = [vp, vp]
     L.lom_profile_match.argtypes = [vp, vp, C.c_size_t, C.c_size_t, fp, fp, C.c_float, C.c_int, dp, dp, dp]
@@ -219,6 +222,8 @@ def lib():
     L.lom_odometry_process_cloud.argtypes = [vp, vp, C.c_size_t]
     L.lom_odometry_get_pose.argtypes = [vp, pp]
     L.lom_odometry_get_stats.argtypes = [vp, C.POINTER(OdometryFrameStats)]
+    L.lom_odometry_get_temp_cloud.argtypes = [vp, vp, C.c_size_t]
+    L.lom_odometry_get_temp_cloud.restype = C.c_int64
     L.lom_odometry_keyframe.argtypes = [vp]
     L.lom_odometry_keyframe.restype = vp
     L.lom_odometry_last_error.argtypes = [vp]

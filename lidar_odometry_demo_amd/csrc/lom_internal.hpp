@@ -179,7 +179,8 @@ struct lom_map {
     // report in pinned host memory
     lom::DeviceBuf align_state, xrec;
     void *h_report = nullptr, *d_report = nullptr;
-    unsigned long long report_seq = 0, lm_seq = 0;
+    unsigned long long report_seq = 0, lm_seq = 0, lm_launches = 0;
+    uint32_t lm_max_blocks = 0;  // co-resident k_lm workgroups this device admits (occupancy query, cached)
     double last_counters[4] = {0, 0, 0, 0};  // valid, cand, occ, queries of the last k_match
 
     bool profiling = false;       // this align carries event pairs
@@ -189,7 +190,7 @@ struct lom_map {
 
     // device-to-device exchange (lom_comm_attach_p2p): this rank's buffer and the peers' IPC mappings
     bool p2p = false;
-    void *p2p_local = nullptr;          // [2 sets][kP2pMaxRanks][32] exchange words in this GPU's HBM
+    void *p2p_local = nullptr;          // [4 sets][kP2pMaxRanks][32] exchange words in this GPU's HBM
     void *p2p_peer[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     // RCCL
     void *comm = nullptr;       // RCCL communicator (device-side all-gather)

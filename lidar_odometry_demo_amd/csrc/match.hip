@@ -1192,7 +1192,12 @@ __device__ __forceinline__ int lmw_propose(LmState &S, int lane)
 }
 
 // ---- ranks of one node: the ranks' totals exchanged by the GPUs themselves -------------------
-// Every rank owns a small buffer in its HBM: [2 sets][kP2pMaxRanks][32] exchange words.  Rank r's
+// Every rank owns a small buffer in its HBM: [4 sets][kP2pMaxRanks][32] exchange words.  Inside one
+// launch the sets alternate with the sequence number (the dependency chain of a solve keeps a rank at
+// most one evaluation ahead of its peers); consecutive launches alternate between the set pairs
+// {0,1} and {2,3}, so the first publish of the next k_lm can never overwrite a slot a lagging peer
+// still polls for the previous kernel's last evaluation (the kernels of different ranks are not
+// ordered against each other).  Rank r's
 // workgroup 0 stores its 32 rank totals into slot r of EVERY rank's buffer (its own directly, the
 // peers' through their IPC mappings: xGMI), system-coherent stores, same {bits, seq ^ bits} words as
 // inside a GPU.  Every workgroup of every rank then reads its own GPU's buffer and adds the ranks'
@@ -1200,13 +1205,14 @@ __device__ __forceinline__ int lmw_propose(LmState &S, int lane)
 struct P2pArgs {
     XWord *peer[kP2pMaxRanks];  // peer[r]: rank r's buffer as seen from this GPU (peer[rank] = local)
     int rank, nranks;
+    int set_base;  // 0 or 2: consecutive launches use disjoint pairs of exchange sets (see global_exchange)
 };
 
 __device__ __forceinline__ void global_exchange(const P2pArgs &A, double *s_tot, unsigned long long seq,
                                                 unsigned long long timeout_ticks, int *s_failed, bool publisher,
                                                 int lane)
 {
-    const size_t set_off = (size_t)(seq & 1) * kP2pMaxRanks * kRecWords;
+    const size_t set_off = (size_t)((unsigned)A.set_base + (unsigned)(seq & 1)) * kP2pMaxRanks * kRecWords;
     if (publisher && lane < kRecWords) {
         const unsigned long long b = (unsigned long long)__double_as_longlong(s_tot[lane]);
         for (int r = 0; r < A.nranks; r++) {
@@ -1317,7 +1323,8 @@ __global__ __launch_bounds__(kEvalThreads) void k_lm(const MatchRec *__restrict_
                                                      unsigned long long seq_base, AlignReport *report,
                                                      unsigned long long report_seq,
                                                      unsigned long long timeout_ticks,
-                                                     unsigned long long *dbg_stamps, P2pArgs px)
+                                                     unsigned long long *dbg_stamps, P2pArgs px,
+                                                     double *dbg_trace)
 {
     extern __shared__ __attribute__((aligned(16))) double s_acc[];
     __shared__ double s_tot[kRecWords];
@@ -1379,6 +1386,14 @@ __global__ __launch_bounds__(kEvalThreads) void k_lm(const MatchRec *__restrict_
             global_exchange(px, s_tot, seq, timeout_ticks * 10, &s_failed, blockIdx.x == 0, lane);
         }
         LM_STAMP(3);
+        // lom_debug_lm_trace: the point and the totals of every evaluation of this solve, as the
+        // policy is about to see them ([ev][40]: x[7], pad, sums[32]; [200] = evaluations recorded)
+        if (dbg_trace && blockIdx.x == 0 && wave == 0 && !s_failed && ev < 5) {
+            if (lane < 7) dbg_trace[ev * 40 + lane] = s_x[lane];
+            if (lane < 31) dbg_trace[ev * 40 + 8 + lane] = s_tot[lane];
+            if (lane == 31) dbg_trace[ev * 40 + 8 + 31] = px.nranks > 1 ? s_tot[31] : (double)n;
+            if (lane == 0) dbg_trace[200] = (double)(ev + 1);
+        }
         if (wave == 0 && !s_failed) {
             // the first wave holds the totals (s_tot) and runs the policy (lm_core.hpp's,
             // lane-parallel: lmw_* above) on the state in LDS
@@ -1777,6 +1792,7 @@ static P2pArgs p2p_args(const lom_map *m)
     for (int r = 0; r < kP2pMaxRanks; r++) A.peer[r] = m->p2p ? (XWord *)m->p2p_peer[r] : nullptr;
     A.rank = m->p2p ? m->rank : 0;
     A.nranks = m->p2p ? m->nranks : 1;
+    A.set_base = 0;
     return A;
 }
 
@@ -1798,8 +1814,29 @@ void p2p_detach(lom_map *m)
 // iteration; the pose travels from pair to pair through AlignState in HBM, so the host enqueues
 // pairs without waiting for results.  cloud_matcher.cpp:169-172 cannot stop before the fifth outer
 // iteration (i > 3): five pairs go out at once, then one pair per report until `finished`.
+// returned by align_chained when a workgroup of k_lm gave up waiting for the others (they are not all
+// resident: a caller sharing the GPU, a CU mask) or for a peer rank: the caller redoes the align
+// through the host-driven loop
+constexpr int kDeviceLoopGaveUp = 100;
+
+// k_lm's workgroups wait for each other inside the kernel, so all of them must be resident at once:
+// the grid never exceeds what the occupancy query admits on this device
+static int lm_block_limit(lom_map *m, uint32_t *out)
+{
+    if (!m->lm_max_blocks) {
+        int per_cu = 0, cus = 0;
+        LOM_HIP(m, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(k_lm),
+                                                                kEvalThreads, kEvalLdsBytes));
+        LOM_HIP(m, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, m->device));
+        m->lm_max_blocks = (uint32_t)std::max(1, per_cu * cus);
+    }
+    *out = m->lm_max_blocks;
+    return LOM_OK;
+}
+
 static int align_chained(lom_map *m, const char *d_src, size_t n, size_t stride, const float guess_t[3],
-                         const float guess_q[4], float out_t[3], float out_q[4], lom_align_stats *stats)
+                         const float guess_q[4], float out_t[3], float out_q[4], lom_align_stats *stats,
+                         double *trace_out = nullptr, int trace_outer = 0)
 {
     static_assert(offsetof(AlignReport, finished) == 8 && offsetof(AlignReport, outer_done) == 16 &&
                       offsetof(AlignReport, evaluations) == 24 && offsetof(AlignReport, pose_t) == 32 &&
@@ -1820,12 +1857,20 @@ static int align_chained(lom_map *m, const char *d_src, size_t n, size_t stride,
     for (int a = 0; a < 4; a++) init.q[a] = guess_q[a];
     for (int a = 0; a < 3; a++) init.prior_b[a] = (double)guess_t[a];  // :153
     init.max_sq = 0.3f * 0.3f;                                          // :139, voxel_grid.h:215
-    const uint32_t nb = std::min(eval_grid(std::max<uint32_t>(c.n, 1u)), kMaxLmBlocks);
+    uint32_t nb_limit = 0;
+    if ((rc = lm_block_limit(m, &nb_limit)) != LOM_OK) return rc;
+    const uint32_t nb = std::min(std::min(eval_grid(std::max<uint32_t>(c.n, 1u)), kMaxLmBlocks), nb_limit);
+    double *d_trace = nullptr;  // lom_debug_lm_trace: k_lm of outer iteration `trace_outer` records its evaluations
+    if (trace_out) {
+        if ((rc = ensure(m, m->scr[1], 201 * 8)) != LOM_OK) return rc;
+        d_trace = (double *)m->scr[1].p;
+        LOM_HIP(m, hipMemsetAsync(d_trace, 0, 201 * 8, m->stream));
+    }
     volatile AlignReport *rp = reinterpret_cast<volatile AlignReport *>(m->h_report);
     rp->error = 0;
     const unsigned long long seq0 = m->report_seq;
     int launched = 0;
-    const P2pArgs px = p2p_args(m);
+    P2pArgs px = p2p_args(m);
     unsigned long long *dbg = nullptr;  // LOM_DEBUG_LM: phase stamps of the last k_lm of the align
     if (getenv("LOM_DEBUG_LM")) {
         if ((rc = ensure(m, m->scr[0], 4096)) != LOM_OK) return rc;
@@ -1838,11 +1883,12 @@ static int align_chained(lom_map *m, const char *d_src, size_t n, size_t stride,
         if (r != LOM_OK) return r;
         const double t_l = now_s();
         m->lm_seq += 8;  // a solve spends at most 5 evaluations
+        px.set_base = (int)((m->lm_launches++ & 1ull) * 2ull);  // same launch count on every rank
         hipLaunchKernelGGL(k_lm, dim3(nb), dim3(kEvalThreads), kEvalLdsBytes, m->stream,
                            (const MatchRec *)m->scan_on.p, c.n, (AlignState *)m->align_state.p, init, i == 0 ? 1 : 0,
                            (const uint32_t *)d_block_counters(m), c.match_blocks, (XWord *)m->xrec.p, m->lm_seq,
                            reinterpret_cast<AlignReport *>(m->d_report), seq0 + (unsigned long long)i + 1,
-                           server_timeout_ticks(), dbg, px);
+                           server_timeout_ticks(), dbg, px, (d_trace && i == trace_outer) ? d_trace : (double *)nullptr);
         LOM_HIP(m, hipGetLastError());
         c.launch_s += now_s() - t_l;
         launched++;
@@ -1874,7 +1920,8 @@ static int align_chained(lom_map *m, const char *d_src, size_t n, size_t stride,
         if (rp->error) {
             (void)hipStreamSynchronize(m->stream);
             m->report_seq = want;
-            return set_error(m, LOM_ERR_HIP, "device solve: a workgroup timed out waiting for the others");
+            set_error(m, LOM_ERR_HIP, "device solve: a workgroup timed out waiting for the others");
+            return kDeviceLoopGaveUp;
         }
         if (rp->finished || launched >= 35) break;
         if ((rc = launch_pair()) != LOM_OK) return rc;
@@ -1914,6 +1961,10 @@ static int align_chained(lom_map *m, const char *d_src, size_t n, size_t stride,
     st.host_launch_ms = c.launch_s * 1e3;
     st.host_wait_ms = c.wait_s * 1e3;
     if (stats) *stats = st;
+    if (trace_out) {
+        LOM_HIP(m, hipMemcpyAsync(trace_out, d_trace, 201 * 8, hipMemcpyDeviceToHost, m->stream));
+        LOM_HIP(m, hipStreamSynchronize(m->stream));
+    }
     if (dbg) {
         unsigned long long h[40];
         LOM_HIP(m, hipMemcpyAsync(h, dbg, sizeof h, hipMemcpyDeviceToHost, m->stream));
@@ -1933,17 +1984,33 @@ static int align_device(lom_map *m, const char *d_src, size_t n, size_t stride, 
 {
     if (n >= 0x7FFFFFFFull) return set_error(m, LOM_ERR_ARG, "too many source points");
     m->profiling = m->profile_period > 0 && (m->align_count++ % (unsigned)m->profile_period) == 0;
+    bool fell_back = false;
     if (!m->comm && (!m->host_comm || m->p2p) && !getenv("LOM_HOST_LM")) {
         server_stop(m);
-        const int rc = align_chained(m, d_src, n, stride, guess_t, guess_q, out_t, out_q, stats);
-        if (rc == LOM_OK || !m->p2p) return rc;
-        // A rank that gives up stops publishing, so every rank gives up on the same align: all of
-        // them fall back to the host-driven loop over the host exchange (still attached) and redo it.
-        fprintf(stderr, "lidar_odometry_amd: device-to-device exchange failed (%s); rank %d continues with the host exchange\n",
-                m->last_error.c_str(), m->rank);
-        (void)hipStreamSynchronize(m->stream);
-        m->p2p = false;
+        int rc = align_chained(m, d_src, n, stride, guess_t, guess_q, out_t, out_q, stats);
+        if (m->p2p) {
+            // The ranks agree on the outcome of every align: a time-out that lands on the last exchange
+            // of an align lets the peers that already hold all words finish with LOM_OK, and the rank
+            // that gave up must not redo the align alone (the host exchange pairs operations by its
+            // own counter only).  One status word through the host exchange; any failure anywhere
+            // sends every rank to the host-driven loop below.
+            double verdict[1] = {rc == LOM_OK ? 0.0 : 1.0};
+            if (lom_host_comm_allreduce((lom_host_comm *)m->host_comm, verdict, 1) != LOM_OK)
+                return set_error(m, LOM_ERR_COMM, "status exchange after a device-to-device align failed");
+            if (rc != LOM_OK && rc != kDeviceLoopGaveUp) return rc;
+            if (verdict[0] == 0.0) return LOM_OK;
+            fprintf(stderr, "lidar_odometry_amd: device-to-device exchange failed on some rank (%s); rank %d continues with the host exchange\n",
+                    m->last_error.empty() ? "a peer gave up" : m->last_error.c_str(), m->rank);
+            (void)hipStreamSynchronize(m->stream);
+            m->p2p = false;
+        } else if (rc != kDeviceLoopGaveUp) {
+            return rc;
+        }
+        // single GPU: k_lm's workgroups were not all resident within their patience (another process or
+        // handle on the GPU, a CU mask): same align again through the host-driven loop, whose
+        // workgroups never wait for each other
         m->last_error.clear();
+        fell_back = true;
     }
     int rc = scan_buffers(m, (uint32_t)n, false);
     if (rc != LOM_OK) return rc;
@@ -1971,6 +2038,7 @@ static int align_device(lom_map *m, const char *d_src, size_t n, size_t stride, 
     }
     st.host_launch_ms = c.launch_s * 1e3;
     st.host_wait_ms = c.wait_s * 1e3;
+    st.host_fallback = fell_back ? 1 : 0;
     if (stats) *stats = st;
     return LOM_OK;
 }
@@ -2041,7 +2109,7 @@ int lom_comm_attach_p2p(lom_map *m, lom_host_comm *hc)
     server_stop(m);
     // From here on every step is collective: a rank that fails locally still takes part in the
     // exchanges below, so that all ranks reach the same verdict.
-    const size_t bytes = (size_t)2 * kP2pMaxRanks * kRecWords * sizeof(XWord);
+    const size_t bytes = (size_t)4 * kP2pMaxRanks * kRecWords * sizeof(XWord);
     int ok = 1;
     struct Blob {
         hipIpcMemHandle_t handle;
@@ -2171,6 +2239,61 @@ int lom_match_align_device(lom_map *m, const float *d_src, size_t n, size_t stri
     return align_device(m, (const char *)d_src, n, stride, guess_t, guess_q, out_t, out_q, stats);
 }
 
+// parity entry: one search at the f32 pose, then ONE evaluation of the reduced normal equations at (q, t)
+// through the host-driven path's kernels (k_match + k_eval_server: accumulate_point, LDS reduction,
+// record per workgroup, workgroup-ordered host sum)
+int lom_debug_eval_sums(lom_map *m, const float *src, size_t n, size_t stride, const float pose_t[3],
+                        const float pose_q[4], const double q[4], const double t[3], double out[LOM_NSUMS])
+{
+    if (!m || (n && !src) || !pose_t || !pose_q || !q || !t || !out || stride < 12 || (stride & 3)) return LOM_ERR_ARG;
+    if (n >= 0x7FFFFFFFull) return LOM_ERR_ARG;
+    if (m->comm || m->host_comm) return set_error(m, LOM_ERR_STATE, "not with an attached exchange");
+    LOM_HIP(m, hipSetDevice(m->device));
+    m->last_error.clear();
+    const char *d_src = nullptr;
+    int rc = stage_scan(m, src, n, stride, &d_src);
+    if (rc != LOM_OK) return rc;
+    if ((rc = scan_buffers(m, (uint32_t)n, false)) != LOM_OK) return rc;
+    ScanCtx c{m, d_src, stride, (uint32_t)n, 0};
+    const bool was = m->profiling;
+    m->profiling = false;
+    rc = launch_match(c, pose_t, pose_q, 0.3f, false);  // cloud_matcher.cpp:139
+    if (rc == LOM_OK) rc = launch_eval(c, q, t, true, out);
+    server_stop(m);
+    m->profiling = was;
+    if (rc == LOM_OK && hipStreamSynchronize(m->stream) != hipSuccess) rc = LOM_ERR_HIP;
+    return rc;
+}
+
+// parity entry: a whole align on the device-resident path (k_match / k_lm chain) that also returns what
+// k_lm's policy saw in outer iteration `outer_index`: for every evaluation of that solve the point
+// x = [q, t] it was made at and the 32 totals after the in-kernel reduction and exchange
+int lom_debug_lm_trace(lom_map *m, const float *src, size_t n, size_t stride, const float guess_t[3],
+                       const float guess_q[4], int outer_index, double *trace_out, int *n_evals_out, float out_t[3],
+                       float out_q[4], lom_align_stats *stats)
+{
+    if (!m || (n && !src) || !guess_t || !guess_q || !trace_out || !n_evals_out || !out_t || !out_q || stride < 12 ||
+        (stride & 3) || outer_index < 0 || outer_index >= 35)
+        return LOM_ERR_ARG;
+    if (n >= 0x7FFFFFFFull) return LOM_ERR_ARG;
+    if (m->comm || m->host_comm) return set_error(m, LOM_ERR_STATE, "not with an attached exchange");
+    LOM_HIP(m, hipSetDevice(m->device));
+    m->last_error.clear();
+    const char *d_src = nullptr;
+    int rc = stage_scan(m, src, n, stride, &d_src);
+    if (rc != LOM_OK) return rc;
+    server_stop(m);
+    m->profiling = false;
+    double raw[201];
+    rc = align_chained(m, d_src, n, stride, guess_t, guess_q, out_t, out_q, stats, raw, outer_index);
+    if (rc == kDeviceLoopGaveUp) return LOM_ERR_HIP;
+    if (rc != LOM_OK) return rc;
+    const int ne = (int)raw[200];
+    *n_evals_out = ne;
+    for (int e = 0; e < ne && e < 5; e++) std::memcpy(trace_out + (size_t)e * 40, raw + (size_t)e * 40, 40 * sizeof(double));
+    return LOM_OK;
+}
+
 // diagnostic: per-workgroup phase stamps of one correspondence launch (shader clock ticks)
 int lom_debug_match_stamps(lom_map *m, const float *d_src, size_t n, size_t stride, const float t[3],
                            const float q[4], float max_dist, unsigned long long *stamps_out, size_t cap_blocks,
@@ -2228,6 +2351,7 @@ int lom_match_align_repeat(lom_map *m, const float *d_src, size_t n, size_t stri
         acc.host_launch_ms += st.host_launch_ms;
         acc.host_wait_ms += st.host_wait_ms;
         acc.profiled_launches += st.profiled_launches;
+        acc.host_fallback += st.host_fallback;
     }
     if (total) *total = acc;
     return LOM_OK;

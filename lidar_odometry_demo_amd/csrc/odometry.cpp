@@ -498,6 +498,7 @@ struct lom_odometry {
     lom_pose previous, current;        // lidar_odometry.h:84-85
     lom_odometry_frame_stats last{};
     std::vector<lom_point_xyzirt> normalized, deskewed;
+    size_t temp_points = 0;  // temp_cloud_ (lidar_odometry.h:73-77) = the first temp_points records of `deskewed`
     ClassifyScratch classify_scratch;
     std::vector<float> planar, planar_n, filtered, filtered_n, down, down_n, match, upd, upd_n;
     std::string error;
@@ -608,6 +609,15 @@ int lom_odometry_get_pose(const lom_odometry *o, lom_pose *out)
     return LOM_OK;
 }
 
+// getTempCloud(), lidar_odometry.h:73-75: the deskewed input cloud of the last processCloud (:31)
+int64_t lom_odometry_get_temp_cloud(const lom_odometry *o, lom_point_xyzirt *out, size_t cap)
+{
+    if (!o || (cap && !out)) return LOM_ERR_ARG;
+    const size_t n = o->temp_points;
+    if (out && cap) std::memcpy(static_cast<void *>(out), o->deskewed.data(), std::min(n, cap) * sizeof(lom_point_xyzirt));
+    return (int64_t)n;
+}
+
 int lom_odometry_get_stats(const lom_odometry *o, lom_odometry_frame_stats *out)
 {
     if (!o || !out) return LOM_ERR_ARG;
@@ -634,10 +644,14 @@ int lom_odometry_process_cloud(lom_odometry *o, const lom_point_xyzirt *pts, siz
         time_normalize(pts, n, o->normalized.data(), o->pool.get());  // :25
         lom_pose relative, rel_inv, ident, guess, result;
         lom_pose_relative_to(&o->previous, &o->current, &relative);  // :27
-        o->previous = o->current;                                    // :28
+        // :28 previous_transform_ = current_transform_ -- committed where the frame succeeds (the
+        // reference has no error channel; here a frame that fails must leave the state as it found it,
+        // or the next frame's constant-velocity guess and deskew would start from a zero motion)
+        const lom_pose previous_next = o->current;
         lom::pose_inverse(relative, rel_inv);
         lom_pose_identity(&ident);
         transform_non_rigid(o->normalized.data(), n, rel_inv, ident, o->deskewed.data(), o->pool.get());  // :30
+        o->temp_points = n;  // :31 temp_cloud_ = deskewed_input_cloud
         tm.lap("norm+deskew");
         size_t nu = 0;
         const size_t np = classify(o->deskewed.data(), n, o->planar.data(), o->planar_n.data(), &nu, nullptr,
@@ -650,7 +664,8 @@ int lom_odometry_process_cloud(lom_odometry *o, const lom_point_xyzirt *pts, siz
         tm.lap("classify+filter");
         int rc;
         // the previous frame's keyframe update ran beside the host stages above; it must be through
-        // before this frame touches a handle
+        // before this frame touches a handle.  Its failure is reported here, by the call after the one
+        // it belongs to; this frame is then not processed and poses / keyframe stay as they were.
         if ((rc = o->settle()) != LOM_OK) return rc;
         tm.lap("settle");
         // From here on the frame lives in HBM: one upload of the filtered cloud, both down-samplers,
@@ -672,6 +687,7 @@ int lom_odometry_process_cloud(lom_odometry *o, const lom_point_xyzirt *pts, siz
             cur.initialised_keyframe = 1;
             cur.keyframe_voxels = lom_map_size(o->keyframe);
             o->last = cur;
+            o->previous = previous_next;  // :28
             return LOM_OK;
         }
         // VoxelGrid matching_downsampler(matching_voxel_size, 1); addCloud(filtered); getCloudWithoutNormals()   :46-47,50
@@ -702,6 +718,7 @@ int lom_odometry_process_cloud(lom_odometry *o, const lom_point_xyzirt *pts, siz
                 cur.unstable_rotation = 1;
             }
         }
+        o->previous = previous_next;                                                                  // :28
         o->current = result;                                                                          // :65
         o->last = cur;
         // keyframe update (:67-70): same calls in the same order, on the helper thread when there is one

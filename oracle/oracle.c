@@ -722,6 +722,7 @@ static int qr_solve6(double *A, double *b, size_t rows, double y[6])
 typedef struct {
     int recorded_iterations; /* summary.iterations.size() */
     int evaluations;
+    int points;            /* distinct parameter points evaluated: iteration 0 + every candidate */
     double last_step_norm; /* summary.iterations.back().step_norm */
     double cost;
 } lm_result;
@@ -752,6 +753,7 @@ static int lm_solve(const match_t *M, size_t nm, double x[7], const double prior
 
     out->recorded_iterations = 1; /* iteration 0 */
     out->evaluations = 1;
+    out->points = 1;
     out->last_step_norm = 0.0;
 
     /* IterationZero: cost, residuals, Jacobian, gradient; Jacobi scaling once */
@@ -821,6 +823,7 @@ static int lm_solve(const match_t *M, size_t nm, double x[7], const double prior
         manifold_plus(x, delta, cand);
         const double cand_cost = evaluate(M, nm, cand, prior_b, NULL, NULL);
         out->evaluations++;
+        out->points++;
         double sn = 0.0;
         for (int i = 0; i < 7; i++) sn += (x[i] - cand[i]) * (x[i] - cand[i]);
         sn = sqrt(sn);
@@ -925,6 +928,7 @@ int orc_align(const orc_map *m, const float *src, size_t n, size_t stride, const
         s.outer_iterations = i + 1;
         s.lm_iterations += lr.recorded_iterations;
         s.evaluations += lr.evaluations;
+        s.points_evaluated += lr.points;
         s.queries += (int64_t)n;
         s.valid_last = (int64_t)nm;
         s.final_cost = lr.cost;

@@ -115,6 +115,10 @@ typedef struct {
     double last_step_norm;    /* summary.iterations.back().step_norm       */
     double search_seconds;    /* wall time in correspondence search        */
     double solve_seconds;     /* wall time in the LM solve                 */
+    int points_evaluated;     /* distinct parameter points evaluated (iteration 0 + every LM
+                                 candidate, total): Ceres evaluates an accepted candidate twice (cost,
+                                 then Jacobian), the product once -- this is the comparable count */
+    int pad;
 } orc_align_stats;
 
 int orc_align(const orc_map *m, const float *src_xyz, size_t n, size_t stride_bytes,

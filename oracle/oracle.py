@@ -61,6 +61,8 @@ class AlignStats(C.Structure):
         ("last_step_norm", C.c_double),
         ("search_seconds", C.c_double),
         ("solve_seconds", C.c_double),
+        ("points_evaluated", C.c_int),
+        ("pad", C.c_int),
     ]
 
     def asdict(self):
@@ -284,6 +286,22 @@ class Shard:
     @property
     def handle(self):
         return self._h
+
+    def match_eval(self, pose_t, pose_q, q, t):
+        """New correspondences at the f32 pose, then the NSUMS reduced sums at the f64 point (q, t)."""
+        out = (C.c_double * NSUMS)()
+        rc = lib().orc_shard_match_eval(self._h, _f3(pose_t), _f4(pose_q), (C.c_double * 4)(*[float(v) for v in q]),
+                                        (C.c_double * 3)(*[float(v) for v in t]), out)
+        if rc != 0:
+            raise RuntimeError(f"oracle error {rc}")
+        return np.array(out[:], np.float64)
+
+    def eval_fixed(self, q, t):
+        """The sums at (q, t) for the correspondences of the last match_eval."""
+        out = (C.c_double * NSUMS)()
+        lib().orc_shard_eval_fixed(self._h, (C.c_double * 4)(*[float(v) for v in q]),
+                                   (C.c_double * 3)(*[float(v) for v in t]), out)
+        return np.array(out[:], np.float64)
 
 
 # ---- callers of the hot path (oracle/pipeline.c), tests only ---------------------------------

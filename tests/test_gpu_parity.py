@@ -433,20 +433,32 @@ def test_evaluation_server_timeout_recovery(lom, monkeypatch):
     assert again.translation.tobytes() == ref.translation.tobytes()
 
 
-def test_device_loop_gives_up_cleanly_and_recovers(lom, monkeypatch):
-    """Every wait inside the device-resident solve is bounded: with a 1-tick patience the
-    workgroups give up waiting for each other, the grid drains, the call returns an error instead
-    of hanging -- and the handle works again afterwards (same bits as before)."""
+def test_device_loop_gives_up_cleanly_and_falls_back(lom, monkeypatch):
+    """Every wait inside the device-resident solve is bounded: with a 1-tick patience the workgroups
+    give up waiting for each other and the grid drains (what happens when they are not all resident:
+    a caller sharing the GPU, a CU mask).  The align is then redone by the host-driven loop, whose
+    workgroups never wait for each other: the call still returns the pose -- the bits of the
+    host-driven path -- and says so in the stats; the handle is on the device loop again afterwards."""
     sm = scenes.small_synth_case()
     g = lom.VoxelGrid(0.5, 20)
     g.addCloud(sm["map_xyz"], sm["map_nrm"])
     m = lom.CloudMatcher()
     ref = m.align(g, sm["scan"], lom.Pose3D())
+    assert m.stats["host_fallback"] == 0
+    monkeypatch.setenv("LOM_HOST_LM", "1")
+    host = m.align(g, sm["scan"], lom.Pose3D())
+    host_stats = dict(m.stats)
+    monkeypatch.delenv("LOM_HOST_LM")
     monkeypatch.setenv("LOM_TEST_SERVER_TIMEOUT_TICKS", "1")
-    with pytest.raises(lom.LomError):
-        m.align(g, sm["scan"], lom.Pose3D())
+    got = m.align(g, sm["scan"], lom.Pose3D())
+    assert m.stats["host_fallback"] == 1
+    assert got.translation.tobytes() == host.translation.tobytes()
+    assert got.rotation.tobytes() == host.rotation.tobytes()
+    for k in ("outer_iterations", "lm_iterations", "evaluations", "queries", "cand_total", "valid_last"):
+        assert m.stats[k] == host_stats[k], k
     monkeypatch.delenv("LOM_TEST_SERVER_TIMEOUT_TICKS")
     again = m.align(g, sm["scan"], lom.Pose3D())
+    assert m.stats["host_fallback"] == 0
     assert again.translation.tobytes() == ref.translation.tobytes()
     assert again.rotation.tobytes() == ref.rotation.tobytes()
 
@@ -618,3 +630,42 @@ def test_c3_full_size_properties(lom, oracle):
     assert dt < POSE_TOL_M and dr < POSE_TOL_RAD, (dt, dr)
     p2 = m.align(g, c["scan"], lom.Pose3D())
     assert p.translation.tobytes() == p2.translation.tobytes()
+
+
+@pytest.fixture(scope="module")
+def c4_case():
+    return scenes.synth_case(128, 2048, 2_000_000)
+
+
+def test_c4_full_size_single_rank(lom, oracle, c4_case):
+    """C4 (BASELINE.json configs[3]: 128-beam x 2048 scan, <= 262,144 returns, vs the 2M-point map) with all
+    index ranges on one rank: winners and counters exact, pose within the bar, LM numbers equal the
+    oracle's.  The sharded runs (2 and 3 ranks on this GPU) are in tests/test_p2p_gpu.py."""
+    c = c4_case
+    assert 200_000 < len(c["scan"]) <= 262_144
+    g, og = _both(lom, oracle, 0.5, 20)
+    g.addCloud(c["map_xyz"], c["map_nrm"])
+    og.addCloud(c["map_xyz"], c["map_nrm"])
+    assert g.size() == og.size() and g.pointCount() == og.pointCount()
+    pairs = g.findMatchingPairs(c["scan"], lom.Pose3D(), 0.3)
+    opairs = og.findMatchingPairs(c["scan"], oracle.Pose3D(), 0.3, nthreads=8)
+    _assert_same_pairs(pairs, opairs)
+    m, om = lom.CloudMatcher(), oracle.CloudMatcher(nthreads=8)
+    p = m.align(g, c["scan"], lom.Pose3D())
+    o = om.align(og, c["scan"], oracle.Pose3D())
+    dt, dr = scenes.pose_delta(p.translation, p.rotation, o.translation, o.rotation)
+    assert dt < POSE_TOL_M and dr < POSE_TOL_RAD, (dt, dr)
+    for k in ("outer_iterations", "lm_iterations", "queries", "cand_total", "occ_total", "valid_last"):
+        assert m.stats[k] == om.stats[k], k
+    assert m.stats["evaluations"] == om.stats["points_evaluated"]
+    assert abs(m.stats["last_step_norm"] - om.stats["last_step_norm"]) < 1e-9
+    p2 = m.align(g, c["scan"], lom.Pose3D())
+    assert p.translation.tobytes() == p2.translation.tobytes() and p.rotation.tobytes() == p2.rotation.tobytes()
+    # the 8 contiguous ranges of the 8-GPU configuration, one after the other on this GPU: the ranges'
+    # reduced sums add up to the whole scan's (what the exchange step computes)
+    from tests.test_eval_parity import assert_sums_close
+
+    pose = lom.Pose3D((0.03, -0.02, 0.01), scenes.angle_axis_q(0.004, (0, 0, 1)))
+    n = len(c["scan"])
+    parts = [m.debugEvalSums(g, np.ascontiguousarray(c["scan"][n * r // 8: n * (r + 1) // 8]), pose) for r in range(8)]
+    assert_sums_close(np.sum(parts, axis=0), m.debugEvalSums(g, c["scan"], pose), "C4 ranges")

@@ -95,3 +95,68 @@ def test_ranks_exchange_on_the_device(lom, world):
                                    ref.translation, ref.rotation)
         assert dt < 1e-6 and dr < 1e-6, (dt, dr)
         assert s0["outer_iterations"] == m.stats["outer_iterations"] and s0["queries"] == m.stats["queries"]
+
+
+def _rank_main_c4(rank, world, ident, q, case_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["LOM_TEST_SERVER_TIMEOUT_TICKS"] = "1000000000"    # 10 s: fresh processes build a 2M-point map unevenly
+    import lidar_odometry_demo_amd as lom
+
+    L = lom.capi.lib()
+    scan = np.load(os.path.join(case_dir, "scan.npy"), mmap_mode="r")
+    g = lom.VoxelGrid(0.5, 20)
+    g.addCloud(np.load(os.path.join(case_dir, "map_xyz.npy")), np.load(os.path.join(case_dir, "map_nrm.npy")))
+    hc = C.c_void_p()
+    assert L.lom_host_comm_create(rank, world, ident, C.byref(hc)) == 0
+    rc = L.lom_comm_attach_p2p(g.handle, hc)
+    if rc != 0:
+        q.put((rank, "attach failed", rc, L.lom_last_error(g.handle).decode()))
+        return
+    lo, hi = len(scan) * rank // world, len(scan) * (rank + 1) // world      # contiguous index range of this rank
+    shard = np.ascontiguousarray(scan[lo:hi])
+    m = lom.CloudMatcher()
+    buf = (C.c_double * 1)(0.0)
+    L.lom_host_comm_allreduce(hc, buf, 1)
+    p = m.align(g, shard, lom.Pose3D())
+    L.lom_comm_finalize(g.handle)
+    L.lom_host_comm_destroy(hc)
+    q.put((rank, "ok", (p.translation.tobytes(), p.rotation.tobytes(), dict(m.stats))))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_c4_range_sharded_on_the_device(lom, oracle, world, tmp_path):
+    """BASELINE.json configs[3] (C4): the 128 x 2048 scan split into `world` contiguous index ranges, the
+    2M-point map replicated on every rank, the ranks' sums exchanged by the GPUs (here: `world` processes
+    on the one GPU of the box).  Poses bitwise equal on all ranks, within 1e-4 m / 1e-4 rad of the oracle's
+    single-process align, totals and iteration counts equal.  RCCL itself refuses several ranks on one
+    device, so the `rccl` transport is covered with one rank only (test_comm_path_single_rank)."""
+    from tests import scenes
+
+    c = scenes.synth_case(128, 2048, 2_000_000)
+    for k in ("scan", "map_xyz", "map_nrm"):
+        np.save(tmp_path / f"{k}.npy", c[k])
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ident = os.urandom(16) + bytes(112)
+    procs = [ctx.Process(target=_rank_main_c4, args=(r, world, ident, q, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    og = oracle.VoxelGrid(0.5, 20)                      # the oracle works while the ranks run
+    og.addCloud(c["map_xyz"], c["map_nrm"])
+    om = oracle.CloudMatcher(nthreads=8)
+    ref = om.align(og, c["scan"], oracle.Pose3D())
+    res = sorted(q.get(timeout=400) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[1] == "ok" for r in res), res
+    t0, q0, s0 = res[0][2]
+    assert all(r[2][0] == t0 and r[2][1] == q0 for r in res)          # every rank holds the same bits
+    dt, dr = scenes.pose_delta(np.frombuffer(t0, np.float32), np.frombuffer(q0, np.float32), ref.translation, ref.rotation)
+    assert dt < 1e-4 and dr < 1e-4, (dt, dr)
+    for r in res:
+        s = r[2][2]
+        assert s["host_fallback"] == 0
+        for k in ("outer_iterations", "lm_iterations", "queries", "cand_total", "occ_total", "valid_last"):
+            assert s[k] == om.stats[k], (r[0], k)                     # totals over all ranks
+        assert s["evaluations"] == om.stats["points_evaluated"]
