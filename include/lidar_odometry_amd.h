@@ -316,6 +316,23 @@ size_t lom_range_filter(const float *xyz, const float *nrm, size_t n, float min_
 size_t lom_cloud_classify(const lom_point_xyzirt *in, size_t n, float *xyz_out, float *nrm_out,
                           size_t *unclassified_out, size_t grid_out[2]);
 
+/* ---- file input: pcl::io::loadPCDFile<pcl::PointXYZ> (test/test.cpp:194) ---------------------------- */
+/* PCD v0.7 reader, host code without PCL: `DATA ascii` and `DATA binary`, fields located by name (x y z,
+ * optionally normal_x normal_y normal_z), any SIZE / TYPE / COUNT layout -- e.g. the reference's shipped
+ * test/test_data/intersection00056.pcd (FIELDS rgb _ x y z _, 32-byte records).  NaN points are kept,
+ * like loadPCDFile does.  Returns the number of points in the file (negative: lom_status, text via
+ * lom_pcd_last_error()); writes at most `cap` packed xyz triples (and normals, zero when the file has
+ * none, if nrm_out != NULL). */
+typedef struct {
+    uint64_t points;
+    uint32_t width, height;
+    uint32_t point_step; /* bytes per record in the file */
+    int32_t has_normals;
+    int32_t data_kind;   /* 0 ascii, 1 binary */
+} lom_pcd_info;
+int64_t lom_pcd_read(const char *path, float *xyz_out, float *nrm_out, size_t cap, lom_pcd_info *info_or_null);
+const char *lom_pcd_last_error(void);
+
 /* LidarOdometry::Params, src/lidar_odometry.h:23-48 */
 typedef struct {
     float lidar_min_range, lidar_max_range;
@@ -344,6 +361,9 @@ int lom_odometry_get_pose(const lom_odometry *o, lom_pose *out);   /* getCurrent
  * NULL with cap 0 (count only). */
 int64_t lom_odometry_get_temp_cloud(const lom_odometry *o, lom_point_xyzirt *out, size_t cap);
 int lom_odometry_get_stats(const lom_odometry *o, lom_odometry_frame_stats *out);
+/* test hook (teacher-forced parity tests): overwrite previous_transform_ / current_transform_
+ * (lidar_odometry.h:84-85); the keyframe itself can be replaced through lom_odometry_keyframe() */
+int lom_odometry_debug_set_state(lom_odometry *o, const lom_pose *previous, const lom_pose *current);
 lom_map *lom_odometry_keyframe(lom_odometry *o); /* keyframe_ (getKeyFrameCloud / getFullKeyFrameCloud via lom_map_export) */
 const char *lom_odometry_last_error(const lom_odometry *o);
 

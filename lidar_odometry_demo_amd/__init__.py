@@ -15,7 +15,7 @@ from . import capi
 from .capi import LomError  # noqa: F401
 
 __all__ = ["Pose3D", "VoxelGrid", "CloudMatcher", "LidarOdometry", "transform_points", "pointTimeNormalize",
-           "transformNonRigid", "rangeFilter", "classify", "LomError", "capi"]
+           "transformNonRigid", "rangeFilter", "classify", "loadPCDFile", "LomError", "capi"]
 
 
 class Pose3D:
@@ -311,6 +311,21 @@ def classify(points):
     return xyz[:n].copy(), nrm[:n].copy(), int(nu.value), (int(grid[0]), int(grid[1]))
 
 
+def loadPCDFile(path, with_normals=False):
+    """pcl::io::loadPCDFile<pcl::PointXYZ> (test/test.cpp:194) without PCL: (n, 3) float32 xyz
+    (and normals when asked; zeros if the file has none)."""
+    info = capi.PcdInfo()
+    n = capi.lib().lom_pcd_read(str(path).encode(), None, None, 0, C.byref(info))
+    if n < 0:
+        raise LomError(int(n), capi.lib().lom_pcd_last_error().decode())
+    xyz = np.empty((n, 3), np.float32)
+    nrm = np.empty((n, 3), np.float32) if with_normals else None
+    m = capi.lib().lom_pcd_read(str(path).encode(), xyz.ctypes.data, nrm.ctypes.data if with_normals else None, n, None)
+    if m < 0:
+        raise LomError(int(m), capi.lib().lom_pcd_last_error().decode())
+    return (xyz, nrm) if with_normals else xyz
+
+
 class LidarOdometry:
     """reference src/lidar_odometry.{h,cpp}; `params` overrides LidarOdometry::Params defaults by name."""
 
@@ -354,6 +369,24 @@ class LidarOdometry:
         out = np.empty(n, capi.POINT_XYZIRT)
         capi.check(capi.lib().lom_odometry_get_temp_cloud(self._h, out.ctypes.data, n))
         return out
+
+    def debugSetState(self, previous, current, keyframe_xyz=None, keyframe_normals=None):
+        """Test hook: overwrite the two poses and, if given, rebuild the keyframe from a full export
+        (creation order, insertion order inside a voxel: re-inserting it reproduces the map)."""
+        capi.check(capi.lib().lom_odometry_debug_set_state(self._h, C.byref(previous._c()), C.byref(current._c())))
+        if keyframe_xyz is not None:
+            kf = capi.lib().lom_odometry_keyframe(self._h)
+            xyz, nrm = capi.xyz_array(keyframe_xyz), capi.xyz_array(keyframe_normals)
+            capi.check(capi.lib().lom_map_clear(kf, float(self.params.keyframe_voxel_size)), kf)
+            capi.check(capi.lib().lom_map_add_points(kf, xyz.ctypes.data, nrm.ctypes.data, len(xyz), 12), kf)
+
+    def getFullKeyFrameCloudWithNormals(self):
+        kf = capi.lib().lom_odometry_keyframe(self._h)
+        n = capi.check(capi.lib().lom_map_export(kf, capi.EXPORT_FULL, None, None, 0), kf)
+        xyz, nrm = np.empty((n, 3), np.float32), np.empty((n, 3), np.float32)
+        if n:
+            capi.check(capi.lib().lom_map_export(kf, capi.EXPORT_FULL, xyz.ctypes.data, nrm.ctypes.data, n), kf)
+        return xyz, nrm
 
     def _keyframe_export(self, mode):
         kf = capi.lib().lom_odometry_keyframe(self._h)

@@ -79,6 +79,11 @@ class OdometryFrameStats(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "pad"}
 
 
+class PcdInfo(C.Structure):
+    _fields_ = [("points", C.c_uint64), ("width", C.c_uint32), ("height", C.c_uint32), ("point_step", C.c_uint32),
+                ("has_normals", C.c_int32), ("data_kind", C.c_int32)]
+
+
 MATCH_EVAL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float),
                             C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double))
 EVAL_FIXED_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double),
@@ -103,8 +108,8 @@ EXPORTED = [
     "lom_comm_finalize", "lom_comm_host_id", "lom_host_comm_create", "lom_host_comm_allreduce",
     "lom_host_comm_destroy", "lom_host_comm_allgather", "lom_comm_attach_host", "lom_comm_attach_p2p", "lom_align_with_hooks", "lom_point_time_normalize", "lom_transform_non_rigid",
     "lom_range_filter", "lom_cloud_classify", "lom_odometry_default_params", "lom_odometry_create",
-    "lom_odometry_destroy", "lom_odometry_process_cloud", "lom_odometry_get_pose", "lom_odometry_get_stats", "lom_odometry_get_temp_cloud",
-    "lom_odometry_keyframe", "lom_odometry_last_error",
+    "lom_odometry_destroy", "lom_odometry_process_cloud", "lom_odometry_get_pose", "lom_odometry_get_stats", "lom_odometry_get_temp_cloud", "lom_odometry_debug_set_state",
+    "lom_odometry_keyframe", "lom_odometry_last_error", "lom_pcd_read", "lom_pcd_last_error",
 ]
 
 _lib = None
@@ -224,10 +229,14 @@ def lib():
     L.lom_odometry_get_stats.argtypes = [vp, C.POINTER(OdometryFrameStats)]
     L.lom_odometry_get_temp_cloud.argtypes = [vp, vp, C.c_size_t]
     L.lom_odometry_get_temp_cloud.restype = C.c_int64
+    L.lom_odometry_debug_set_state.argtypes = [vp, pp, pp]
     L.lom_odometry_keyframe.argtypes = [vp]
     L.lom_odometry_keyframe.restype = vp
     L.lom_odometry_last_error.argtypes = [vp]
     L.lom_odometry_last_error.restype = C.c_char_p
+    L.lom_pcd_read.argtypes = [C.c_char_p, vp, vp, C.c_size_t, C.POINTER(PcdInfo)]
+    L.lom_pcd_read.restype = C.c_int64
+    L.lom_pcd_last_error.restype = C.c_char_p
     _lib = L
     return L
 

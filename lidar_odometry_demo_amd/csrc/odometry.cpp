@@ -618,6 +618,17 @@ int64_t lom_odometry_get_temp_cloud(const lom_odometry *o, lom_point_xyzirt *out
     return (int64_t)n;
 }
 
+// test hook: overwrite previous_transform_ / current_transform_ (lidar_odometry.h:84-85); together with
+// clear + add on lom_odometry_keyframe() this lets a test put the pipeline into a given state before a frame
+int lom_odometry_debug_set_state(lom_odometry *o, const lom_pose *previous, const lom_pose *current)
+{
+    if (!o || !previous || !current) return LOM_ERR_ARG;
+    const int rc = o->settle();
+    o->previous = *previous;
+    o->current = *current;
+    return rc;
+}
+
 int lom_odometry_get_stats(const lom_odometry *o, lom_odometry_frame_stats *out)
 {
     if (!o || !out) return LOM_ERR_ARG;

@@ -435,6 +435,13 @@ class LidarOdometry:
         lib().orc_map_export(kf, mode, xyz.ctypes.data, None, n)
         return xyz
 
+    def getFullKeyFrameCloudWithNormals(self):
+        kf = _pipeline_lib().orc_odom_keyframe(self._h)
+        n = lib().orc_map_export(kf, EXPORT_FULL, None, None, 0)
+        xyz, nrm = np.empty((n, 3), np.float32), np.empty((n, 3), np.float32)
+        lib().orc_map_export(kf, EXPORT_FULL, xyz.ctypes.data, nrm.ctypes.data, n)
+        return xyz, nrm
+
     def getKeyFrameCloud(self):
         return self._export(EXPORT_FIRST_PER_VOXEL)
 
