@@ -89,6 +89,13 @@ int lom_map_add_points(lom_map *m, const float *xyz, const float *nrm, size_t n,
 /* same with device-resident input (pointers valid on the handle's device) */
 int lom_map_add_points_device(lom_map *m, const float *d_xyz, const float *d_nrm, size_t n,
                               size_t stride_bytes);
+/* the same, enqueued only: the range verdict (a call with a point out of range inserts nothing) is not
+ * waited for; lom_map_status() waits for everything enqueued on the handle and returns the first deferred
+ * error since the last check (LOM_ERR_RANGE, LOM_ERR_HIP) -- for callers that keep a frame in HBM and look at
+ * the host only once per frame */
+int lom_map_add_points_device_nowait(lom_map *m, const float *d_xyz, const float *d_nrm, size_t n,
+                                     size_t stride_bytes);
+int lom_map_status(lom_map *m);
 int lom_map_radius_cleanup(lom_map *m, const float center[3], float radius); /* :236-246 */
 int64_t lom_map_size(const lom_map *m);        /* number of voxels, :248-251 */
 int64_t lom_map_point_count(const lom_map *m); /* number of stored points */

@@ -373,12 +373,12 @@ class LidarOdometry:
     def debugSetState(self, previous, current, keyframe_xyz=None, keyframe_normals=None):
         """Test hook: overwrite the two poses and, if given, rebuild the keyframe from a full export
         (creation order, insertion order inside a voxel: re-inserting it reproduces the map)."""
-        capi.check(capi.lib().lom_odometry_debug_set_state(self._h, C.byref(previous._c()), C.byref(current._c())))
         if keyframe_xyz is not None:
             kf = capi.lib().lom_odometry_keyframe(self._h)
             xyz, nrm = capi.xyz_array(keyframe_xyz), capi.xyz_array(keyframe_normals)
             capi.check(capi.lib().lom_map_clear(kf, float(self.params.keyframe_voxel_size)), kf)
             capi.check(capi.lib().lom_map_add_points(kf, xyz.ctypes.data, nrm.ctypes.data, len(xyz), 12), kf)
+        capi.check(capi.lib().lom_odometry_debug_set_state(self._h, C.byref(previous._c()), C.byref(current._c())))
 
     def getFullKeyFrameCloudWithNormals(self):
         kf = capi.lib().lom_odometry_keyframe(self._h)

@@ -101,7 +101,7 @@ EXPORTED = [
     "lom_abi_version", "lom_device_count", "lom_device_local_cpus", "lom_pose_identity", "lom_pose_compose", "lom_pose_inverse",
     "lom_pose_relative_to", "lom_pose_rotation_matrix", "lom_transform_points", "lom_map_create",
     "lom_map_destroy", "lom_last_error", "lom_map_clear", "lom_map_set_max_points", "lom_map_add_points",
-    "lom_map_add_points_device", "lom_map_radius_cleanup", "lom_map_size", "lom_map_point_count",
+    "lom_map_add_points_device", "lom_map_add_points_device_nowait", "lom_map_status", "lom_map_radius_cleanup", "lom_map_size", "lom_map_point_count",
     "lom_map_export", "lom_voxel_downsample", "lom_voxel_downsample_device", "lom_upload_points",
     "lom_transform_points_device", "lom_map_get_stream", "lom_match_find_pairs", "lom_match_align", "lom_match_align_device", "lom_match_align_repeat", "lom_debug_match_stamps", "lom_debug_eval_sums", "lom_debug_lm_trace",
     "lom_map_set_profiling", "lom_profile_match", "lom_map_set_stream", "lom_comm_unique_id", "lom_comm_init",
@@ -167,6 +167,8 @@ def lib():
     L.lom_map_set_max_points.argtypes = [vp, C.c_size_t]
     L.lom_map_add_points.argtypes = [vp, vp, vp, C.c_size_t, C.c_size_t]
     L.lom_map_add_points_device.argtypes = [vp, vp, vp, C.c_size_t, C.c_size_t]
+    L.lom_map_add_points_device_nowait.argtypes = [vp, vp, vp, C.c_size_t, C.c_size_t]
+    L.lom_map_status.argtypes = [vp]
     L.lom_map_radius_cleanup.argtypes = [vp, fp, C.c_float]
     L.lom_map_size.argtypes = [vp]
     L.lom_map_size.restype = C.c_int64

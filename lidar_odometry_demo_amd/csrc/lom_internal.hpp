@@ -157,7 +157,11 @@ struct lom_map {
     uint32_t alt_cap = 0;
 
     // scratch (grown on demand, never shrunk)
-    lom::DeviceBuf scr[12];
+    lom::DeviceBuf scr[16];
+    // sequence number of the last map-maintenance call (tags block aggregates and error words: no resets),
+    // the one up to which lom_map_status has looked, and whether the table is known to be all-empty
+    uint32_t call_seq = 0, status_seq = 0;
+    bool table_clean = true;
     // per-scan buffers of align/find_pairs
     lom::DeviceBuf scan_src, scan_idx, scan_on, scan_stats, partials, results;
 
@@ -177,7 +181,7 @@ struct lom_map {
     bool eval_attr_set = false;
     // device-resident outer loop (single GPU): state in HBM, exchange records of k_lm's workgroups,
     // report in pinned host memory
-    lom::DeviceBuf align_state, xrec;
+    lom::DeviceBuf align_state, xrec, dbg_trace, dbg_stamps;
     void *h_report = nullptr, *d_report = nullptr;
     unsigned long long report_seq = 0, lm_seq = 0, lm_launches = 0;
     uint32_t lm_max_blocks = 0;  // co-resident k_lm workgroups this device admits (occupancy query, cached)

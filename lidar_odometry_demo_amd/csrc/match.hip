@@ -1862,8 +1862,8 @@ static int align_chained(lom_map *m, const char *d_src, size_t n, size_t stride,
     const uint32_t nb = std::min(std::min(eval_grid(std::max<uint32_t>(c.n, 1u)), kMaxLmBlocks), nb_limit);
     double *d_trace = nullptr;  // lom_debug_lm_trace: k_lm of outer iteration `trace_outer` records its evaluations
     if (trace_out) {
-        if ((rc = ensure(m, m->scr[1], 201 * 8)) != LOM_OK) return rc;
-        d_trace = (double *)m->scr[1].p;
+        if ((rc = ensure(m, m->dbg_trace, 201 * 8)) != LOM_OK) return rc;
+        d_trace = (double *)m->dbg_trace.p;
         LOM_HIP(m, hipMemsetAsync(d_trace, 0, 201 * 8, m->stream));
     }
     volatile AlignReport *rp = reinterpret_cast<volatile AlignReport *>(m->h_report);
@@ -1873,8 +1873,8 @@ static int align_chained(lom_map *m, const char *d_src, size_t n, size_t stride,
     P2pArgs px = p2p_args(m);
     unsigned long long *dbg = nullptr;  // LOM_DEBUG_LM: phase stamps of the last k_lm of the align
     if (getenv("LOM_DEBUG_LM")) {
-        if ((rc = ensure(m, m->scr[0], 4096)) != LOM_OK) return rc;
-        dbg = (unsigned long long *)m->scr[0].p;
+        if ((rc = ensure(m, m->dbg_stamps, 4096)) != LOM_OK) return rc;
+        dbg = (unsigned long long *)m->dbg_stamps.p;
         LOM_HIP(m, hipMemsetAsync(dbg, 0, 40 * 8, m->stream));
     }
     auto launch_pair = [&]() -> int {

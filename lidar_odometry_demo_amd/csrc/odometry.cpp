@@ -498,6 +498,7 @@ struct lom_odometry {
     lom_pose previous, current;        // lidar_odometry.h:84-85
     lom_odometry_frame_stats last{};
     std::vector<lom_point_xyzirt> normalized, deskewed;
+    bool keyframe_has_voxels = false;  // keyframe_.size() != 0 (lidar_odometry.cpp:40), tracked on the host
     size_t temp_points = 0;  // temp_cloud_ (lidar_odometry.h:73-77) = the first temp_points records of `deskewed`
     ClassifyScratch classify_scratch;
     std::vector<float> planar, planar_n, filtered, filtered_n, down, down_n, match, upd, upd_n;
@@ -626,6 +627,7 @@ int lom_odometry_debug_set_state(lom_odometry *o, const lom_pose *previous, cons
     const int rc = o->settle();
     o->previous = *previous;
     o->current = *current;
+    o->keyframe_has_voxels = lom_map_size(o->keyframe) > 0;  // the test may have replaced the keyframe
     return rc;
 }
 
@@ -692,11 +694,14 @@ int lom_odometry_process_cloud(lom_odometry *o, const lom_point_xyzirt *pts, siz
         if (nd < 0) return fail((int)nd, o->update_ds);
         cur.update_points = nd;
         tm.lap("update_ds");
-        if (lom_map_size(o->keyframe) == 0) {  // :40-44 init keyframe
+        // :40 keyframe_.size() == 0 -- known on the host: the keyframe is empty until a frame has put voxels
+        // into it (nd > 0 points always create at least one), and stays non-empty unless a cleanup empties it
+        if (!o->keyframe_has_voxels) {  // :40-44 init keyframe
             if ((rc = lom_map_add_points_device(o->keyframe, d_down, d_down_n, (size_t)nd, 12)) != LOM_OK)
                 return fail(rc, o->keyframe);
             cur.initialised_keyframe = 1;
             cur.keyframe_voxels = lom_map_size(o->keyframe);
+            o->keyframe_has_voxels = cur.keyframe_voxels > 0;
             o->last = cur;
             o->previous = previous_next;  // :28
             return LOM_OK;
@@ -747,9 +752,12 @@ int lom_odometry_process_cloud(lom_odometry *o, const lom_point_xyzirt *pts, siz
             if ((rc = lom_transform_points_device(o->keyframe, &pose_now, d_down, d_down_n, n_down, 12, &d_upd,
                                                   &d_upd_n)) != LOM_OK)  // :69
                 return bad(rc, o->keyframe);
-            if ((rc = lom_map_add_points_device(o->keyframe, d_upd, d_upd_n, n_down, 12)) != LOM_OK)  // :70
+            if ((rc = lom_map_add_points_device_nowait(o->keyframe, d_upd, d_upd_n, n_down, 12)) != LOM_OK)  // :70
                 return bad(rc, o->keyframe);
+            // one look at the host per update: the deferred verdict of the insert and the voxel count
+            if ((rc = lom_map_status(o->keyframe)) != LOM_OK) return bad(rc, o->keyframe);
             o->last.keyframe_voxels = lom_map_size(o->keyframe);
+            o->keyframe_has_voxels = o->last.keyframe_voxels > 0;
             return LOM_OK;
         };
         if (o->deferred) {

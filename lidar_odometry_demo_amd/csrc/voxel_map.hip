@@ -26,6 +26,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <type_traits>
 
 #include "lom_internal.hpp"
 #include "pose_math.hpp"
@@ -98,8 +99,12 @@ enum {
     S_BKT_CNT,
     S_BKT_HEAD,
     S_BKT_OFF,
+    S_BKT_OLD,
+    S_PT_OFF,
+    S_PT_M,
     S_ITEMS,
     S_SCAN,
+    S_DS_HEAD,
     S_MISC
 };
 
@@ -232,45 +237,18 @@ __device__ inline const float *point_at(const char *base, size_t i, size_t strid
     return reinterpret_cast<const float *>(base + i * stride);
 }
 
-__global__ void k_validate(const char *xyz, size_t stride, uint32_t n, float vs, uint32_t *bad)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float *p = point_at(xyz, i, stride);
-    int a;
-    if (!voxel_index(p[0], vs, a) || !voxel_index(p[1], vs, a) || !voxel_index(p[2], vs, a)) *bad = 1u;
-}
-
-// voxel_grid.h:80-82: index + find; claims a slot for a voxel seen for the first time
-__global__ void k_ins_claim(Slot *table, uint32_t mask, uint32_t shift, const char *xyz, size_t stride,
-                            uint32_t n, float vs, uint32_t *pt_slot, uint32_t *pt_pos, uint32_t *bkt_cnt,
-                            uint32_t *bkt_head)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float *p = point_at(xyz, i, stride);
-    int ix = 0, iy = 0, iz = 0;
-    voxel_index(p[0], vs, ix);
-    voxel_index(p[1], vs, iy);
-    voxel_index(p[2], vs, iz);
-    const uint32_t h = claim_slot(table, mask, shift, pack_key(ix, iy, iz));
-    pt_slot[i] = h;
-    pt_pos[i] = atomicAdd(&bkt_cnt[h], 1u);  // arbitrary order; fixed up by rank below
-    atomicMin(&bkt_head[h], i);              // earliest input index touching the voxel
-}
-
 // per point: low word = 1 if it is the first point of a voxel seen for the first time (creation
 // order = order of first appearance, voxel_grid.h:83-87), high word = size of the voxel's bucket
 // if the point is the bucket's head.  One 64-bit exclusive scan then yields the new voxel's slab
 // rank and the bucket's offset in the scratch list -- no same-address atomics.
 __global__ void k_ins_heads(const Slot *table, uint32_t n, const uint32_t *pt_slot, const uint32_t *bkt_cnt,
-                            const uint32_t *bkt_head, unsigned long long *flag64)
+                            const uint32_t *bkt_head, unsigned long long *flag64, uint32_t seq, const uint32_t *words)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t h = pt_slot[i];
     unsigned long long f = 0;
-    if (bkt_head[h] == i) {
+    if (words[5] != seq && h != 0xFFFFFFFFu && bkt_head[h] == i) {
         f = (unsigned long long)bkt_cnt[h] << 32;
         if (table[h].slab == kNoSlab) f |= 1ull;  // voxel_grid.h:83 it == end()
     }
@@ -279,15 +257,17 @@ __global__ void k_ins_heads(const Slot *table, uint32_t n, const uint32_t *pt_sl
 
 __global__ void k_ins_assign(Slot *table, uint32_t n, const uint32_t *pt_slot, const uint32_t *bkt_head,
                              const unsigned long long *flag64, const unsigned long long *scan64,
-                             const uint32_t *n_vox_dev, unsigned long long *slab_key, uint32_t *bkt_off)
+                             const uint32_t *n_vox_dev, unsigned long long *slab_key, uint32_t *bkt_off,
+                             uint32_t *bkt_old, uint32_t seq, const uint32_t *words)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    if (i >= n || words[5] == seq) return;
     const uint32_t h = pt_slot[i];
-    if (bkt_head[h] != i) return;
-    const uint32_t n_vox_before = *n_vox_dev;  // device-side voxel counter (bumped after this insert)
+    if (h == 0xFFFFFFFFu || bkt_head[h] != i) return;
+    const uint32_t n_vox_before = *n_vox_dev;  // device-side voxel counter (bumped by k_ins_place2)
     const unsigned long long sc = scan64[i];
     bkt_off[h] = (uint32_t)(sc >> 32);
+    bkt_old[h] = (flag64[i] & 1ull) ? 0u : table[h].count;
     if (flag64[i] & 1ull) {
         const uint32_t slab = n_vox_before + (uint32_t)sc;
         table[h].slab = slab;
@@ -295,70 +275,9 @@ __global__ void k_ins_assign(Slot *table, uint32_t n, const uint32_t *pt_slot, c
     }
 }
 
-// n_vox += number of new voxels of the insert that just ran (low word of the 64-bit scan total)
-__global__ void k_nvox_bump(uint32_t *n_vox_dev, const unsigned long long *total64)
-{
-    if (threadIdx.x == 0 && blockIdx.x == 0) *n_vox_dev += (uint32_t)(*total64);
-}
-
 __global__ void k_set_word(uint32_t *w, uint32_t v)
 {
     if (threadIdx.x == 0 && blockIdx.x == 0) *w = v;
-}
-
-__global__ void k_ins_scatter(uint32_t n, const uint32_t *pt_slot, const uint32_t *pt_pos,
-                              const uint32_t *bkt_off, uint32_t *items)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    items[bkt_off[pt_slot[i]] + pt_pos[i]] = i;
-}
-
-// voxel_grid.h:86,89-90: append while size() < max_points_, in input order
-__global__ void k_ins_place(const Slot *table, uint32_t n, const uint32_t *pt_slot, const uint32_t *bkt_cnt,
-                            const uint32_t *bkt_off, const uint32_t *items, const char *xyz, const char *nrm,
-                            size_t stride, uint32_t K, float *pts, float *nrm_out)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t h = pt_slot[i];
-    const Slot s = table[h];
-    if (s.count >= K) return;
-    const uint32_t room = K - s.count;
-    const uint32_t m = bkt_cnt[h];
-    const uint32_t *it = items + bkt_off[h];
-    uint32_t rank = 0;
-    for (uint32_t j = 0; j < m && rank < room; j++) rank += it[j] < i;
-    if (rank >= room) return;
-    const size_t dst = ((size_t)s.slab * K + s.count + rank) * 3;
-    const float *p = point_at(xyz, i, stride);
-    pts[dst + 0] = p[0];
-    pts[dst + 1] = p[1];
-    pts[dst + 2] = p[2];
-    if (nrm) {
-        const float *q = point_at(nrm, i, stride);
-        nrm_out[dst + 0] = q[0];
-        nrm_out[dst + 1] = q[1];
-        nrm_out[dst + 2] = q[2];
-    } else {  // voxel_grid.h:103,107
-        nrm_out[dst + 0] = 0.f;
-        nrm_out[dst + 1] = 0.f;
-        nrm_out[dst + 2] = 0.f;
-    }
-}
-
-__global__ void k_ins_finalize(Slot *table, uint32_t n, const uint32_t *pt_slot, const uint32_t *bkt_cnt,
-                               const uint32_t *bkt_head, uint32_t K, uint32_t *slab_count)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t h = pt_slot[i];
-    if (bkt_head[h] != i) return;
-    const Slot s = table[h];
-    const uint32_t want = s.count + bkt_cnt[h];
-    const uint32_t nc = want < K ? want : K;
-    table[h].count = nc;
-    slab_count[s.slab] = nc;
 }
 
 // ---------------------------------------------------------------------------
@@ -369,14 +288,14 @@ __global__ void k_ins_finalize(Slot *table, uint32_t n, const uint32_t *pt_slot,
 // index is that minimum, compact them by a scan over the input.  No payload slabs are touched.
 // ---------------------------------------------------------------------------
 __global__ void k_ds_claim(Slot *table, uint32_t mask, uint32_t shift, const char *xyz, size_t stride, uint32_t n,
-                           float vs, uint32_t *pt_slot, uint32_t *head, uint32_t *bad)
+                           float vs, uint32_t *pt_slot, uint32_t *head, uint32_t seq, uint32_t *bad)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float *p = point_at(xyz, i, stride);
     int ix = 0, iy = 0, iz = 0;
     if (!voxel_index(p[0], vs, ix) || !voxel_index(p[1], vs, iy) || !voxel_index(p[2], vs, iz)) {
-        *bad = 1u;  // out of range / not finite: the call fails, nothing is returned
+        __hip_atomic_store(bad, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // out of range / not finite: the call fails
         pt_slot[i] = 0xFFFFFFFFu;
         return;
     }
@@ -421,10 +340,20 @@ __global__ void k_transform(const char *xyz, const char *nrm, size_t stride, uin
 }
 
 __global__ void k_ds_write(uint32_t n, const uint32_t *flag, const uint32_t *rank, const char *xyz, const char *nrm,
-                           size_t stride, float *out_xyz, float *out_nrm)
+                           size_t stride, float *out_xyz, float *out_nrm, Slot *table, const uint32_t *pt_slot,
+                           uint32_t *head)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n || !flag[i]) return;
+    {  // the workspace goes back to rest: the kept point frees its voxel's slot and head word
+        const uint32_t h = pt_slot[i];
+        Slot e;
+        e.key = kEmptyKey;
+        e.count = 0;
+        e.slab = kNoSlab;
+        table[h] = e;
+        head[h] = 0xFFFFFFFFu;
+    }
     const size_t d = (size_t)rank[i] * 3;
     const float *p = point_at(xyz, i, stride);
     out_xyz[d] = p[0];
@@ -443,6 +372,286 @@ __global__ void k_ds_write(uint32_t n, const uint32_t *flag, const uint32_t *ran
 }
 
 // ---------------------------------------------------------------------------
+// Single-pass variants for per-frame sizes (n <= kOnePassMax): one element per thread, at most 256
+// workgroups of 256, all resident at once.  What used to be {flag kernel, 1-3 scan launches, consumer
+// kernel} is one kernel: block-local scan, then every workgroup publishes its total as a tagged 8-byte
+// word {call sequence number, value} (one store; no reset between calls, the sequence number tells
+// fresh from stale) and adds up the totals of the workgroups before it -- <= 255 words, one per
+// thread, fixed order, so the prefix is deterministic.  Every wait is bounded (s_memrealtime); a
+// workgroup that gives up writes the call's sequence number into the error word and carries on
+// with a zero prefix: the host sees the error at its next read-back.
+//
+// Per-slot scratch (batch count, earliest input index, down-sampler head) is kept "at rest" between
+// calls -- zero / 0xFFFFFFFF everywhere -- by the one thread per voxel that consumed it, so no call
+// pays a memset proportional to the table capacity.
+// ---------------------------------------------------------------------------
+constexpr uint32_t kOnePassMax = 256u * kThreads;
+constexpr uint32_t kInvalidSlot = 0xFFFFFFFFu;
+constexpr unsigned long long kGridWaitTicks = 2000000ull;  // 20 ms of s_memrealtime (100 MHz)
+
+struct __attribute__((aligned(8))) Granule {
+    uint32_t seq, val;
+};
+
+__device__ __forceinline__ void granule_store(Granule *g, uint32_t seq, uint32_t val)
+{
+    const unsigned long long w = ((unsigned long long)val << 32) | seq;
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(g), w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ uint32_t granule_wait(const Granule *g, uint32_t seq, uint32_t *err_word)
+{
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    for (;;) {
+        const unsigned long long w = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(g), __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_AGENT);
+        if ((uint32_t)w == seq) return (uint32_t)(w >> 32);
+        if (__builtin_amdgcn_s_memrealtime() - t0 > kGridWaitTicks) {
+            __hip_atomic_store(err_word, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return 0u;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
+// exclusive scan of one packed u64 per thread over the workgroup (two u32 quantities, no carry while
+// the low sums stay below 2^32); s_w: 8 words of LDS; total = the workgroup's sum
+__device__ __forceinline__ unsigned long long block_scan64(unsigned long long v, unsigned long long *s_w,
+                                                           unsigned long long &total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned long long o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) s_w[wave] = inc;
+    __syncthreads();
+    unsigned long long off = 0;
+    total = 0;
+#pragma unroll
+    for (int w = 0; w < kThreads / 64; w++) {
+        if (w < wave) off += s_w[w];
+        total += s_w[w];
+    }
+    __syncthreads();
+    return off + inc - v;
+}
+
+// sum of the (lo, hi) totals of all workgroups before this one; agg: [gridDim.x][2] granules
+__device__ __forceinline__ unsigned long long grid_prefix64(unsigned long long my_total, Granule *agg, uint32_t seq,
+                                                            uint32_t *err_word, unsigned long long *s_w)
+{
+    if (threadIdx.x == 0) {
+        granule_store(agg + 2 * blockIdx.x, seq, (uint32_t)my_total);
+        granule_store(agg + 2 * blockIdx.x + 1, seq, (uint32_t)(my_total >> 32));
+    }
+    unsigned long long v = 0;
+    if (threadIdx.x < blockIdx.x) {
+        const uint32_t lo = granule_wait(agg + 2 * threadIdx.x, seq, err_word);
+        const uint32_t hi = granule_wait(agg + 2 * threadIdx.x + 1, seq, err_word);
+        v = ((unsigned long long)hi << 32) | lo;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) s_w[4 + wave] = v;
+    __syncthreads();
+    unsigned long long sum = 0;
+#pragma unroll
+    for (int w = 0; w < kThreads / 64; w++) sum += s_w[4 + w];
+    __syncthreads();
+    return sum;
+}
+
+// ---- down-sampler, two kernels ------------------------------------------------------------------
+// k_ds_claim (above) leaves pt_slot[] and head[]; this kernel keeps the first point of every voxel in
+// order of first appearance and puts the workspace back to rest: the head point of a voxel frees its
+// table slot and its head word, so neither a table re-initialisation nor a memset follows.
+__global__ __launch_bounds__(kThreads) void k_ds_emit(Slot *table, uint32_t n, const uint32_t *__restrict__ pt_slot,
+                                                      uint32_t *head, const char *xyz, const char *nrm, size_t stride,
+                                                      float *out_xyz, float *out_nrm, Granule *agg, uint32_t seq,
+                                                      uint32_t *words)
+{
+    __shared__ unsigned long long s_w[8];
+    const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
+    uint32_t h = kInvalidSlot;
+    bool keep = false;
+    if (i < n) {
+        h = pt_slot[i];
+        keep = h != kInvalidSlot && head[h] == i;
+    }
+    unsigned long long total;
+    const unsigned long long excl = block_scan64(keep ? 1ull : 0ull, s_w, total);
+    const unsigned long long before = grid_prefix64(total, agg, seq, words + 7, s_w);
+    if (keep) {
+        const size_t d = (size_t)(before + excl) * 3;
+        const float *p = point_at(xyz, i, stride);
+        out_xyz[d] = p[0];
+        out_xyz[d + 1] = p[1];
+        out_xyz[d + 2] = p[2];
+        if (out_nrm) {
+            if (nrm) {
+                const float *q = point_at(nrm, i, stride);
+                out_nrm[d] = q[0];
+                out_nrm[d + 1] = q[1];
+                out_nrm[d + 2] = q[2];
+            } else {
+                out_nrm[d] = out_nrm[d + 1] = out_nrm[d + 2] = 0.f;
+            }
+        }
+        Slot e;
+        e.key = kEmptyKey;
+        e.count = 0;
+        e.slab = kNoSlab;
+        table[h] = e;
+        head[h] = 0xFFFFFFFFu;
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) words[4] = (uint32_t)(before + total);  // voxels kept
+}
+
+// ---- insert, four kernels ----------------------------------------------------------------------
+// 1. k_ins_claim2   slot per point (CAS), arrival position in the voxel's bucket, earliest input index;
+//                   range check folded in (a call with a bad point inserts nothing: the later kernels
+//                   see the call's sequence number in the error word and only put the scratch to rest)
+// 2. k_ins_assign2  one 64-bit scan: creation order of the new voxels (low word) and bucket offsets
+//                   (high word); the head point of a voxel assigns slab, offset and the old count
+// 3. k_ins_scatter2 bucket lists; every point takes a private copy of its bucket's size and offset
+// 4. k_ins_place2   rank by input index inside the voxel (= insertion order, voxel_grid.h:86-90), store
+//                   the first K - count; the head point publishes the new count and resets the scratch
+__global__ __launch_bounds__(kThreads) void k_ins_claim2(Slot *table, uint32_t mask, uint32_t shift, const char *xyz,
+                                                         size_t stride, uint32_t n, float vs, uint32_t *pt_slot,
+                                                         uint32_t *pt_pos, uint32_t *bkt_cnt, uint32_t *bkt_head,
+                                                         uint32_t seq, uint32_t *words)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float *p = point_at(xyz, i, stride);
+    int ix = 0, iy = 0, iz = 0;
+    if (!voxel_index(p[0], vs, ix) || !voxel_index(p[1], vs, iy) || !voxel_index(p[2], vs, iz)) {
+        pt_slot[i] = kInvalidSlot;
+        __hip_atomic_store(words + 5, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // LOM_ERR_RANGE for this call
+        return;
+    }
+    const uint32_t h = claim_slot(table, mask, shift, pack_key(ix, iy, iz));
+    pt_slot[i] = h;
+    pt_pos[i] = atomicAdd(&bkt_cnt[h], 1u);  // arbitrary order; fixed up by rank in k_ins_place2
+    atomicMin(&bkt_head[h], i);              // earliest input index touching the voxel
+}
+
+__global__ __launch_bounds__(kThreads) void k_ins_assign2(Slot *table, uint32_t n, const uint32_t *__restrict__ pt_slot,
+                                                          const uint32_t *__restrict__ bkt_cnt,
+                                                          const uint32_t *__restrict__ bkt_head, uint32_t *bkt_off,
+                                                          uint32_t *bkt_old, const uint32_t *n_vox_dev,
+                                                          unsigned long long *slab_key, Granule *agg, uint32_t seq,
+                                                          uint32_t *words)
+{
+    __shared__ unsigned long long s_w[8];
+    const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
+    const bool failed = words[5] == seq;  // a point of this call was out of range: nothing is inserted
+    uint32_t h = kInvalidSlot;
+    bool is_head = false, is_new = false;
+    uint32_t old_count = 0, m = 0;
+    if (i < n && !failed) {
+        h = pt_slot[i];
+        is_head = bkt_head[h] == i;
+        if (is_head) {
+            const Slot s = table[h];
+            is_new = s.slab == kNoSlab;  // voxel_grid.h:83 it == end()
+            old_count = is_new ? 0u : s.count;
+            m = bkt_cnt[h];
+        }
+    }
+    unsigned long long total;
+    const unsigned long long v = ((unsigned long long)m << 32) | (is_new ? 1ull : 0ull);
+    const unsigned long long excl = block_scan64(v, s_w, total);
+    const unsigned long long before = grid_prefix64(total, agg, seq, words + 7, s_w);
+    if (is_head) {
+        const unsigned long long at = before + excl;
+        bkt_off[h] = (uint32_t)(at >> 32);
+        bkt_old[h] = old_count;
+        if (is_new) {
+            const uint32_t slab = *n_vox_dev + (uint32_t)at;  // creation order = order of first appearance
+            table[h].slab = slab;
+            slab_key[slab] = table[h].key;
+        }
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) words[0] = (uint32_t)(before + total);  // new voxels of this call
+}
+
+__global__ __launch_bounds__(kThreads) void k_ins_scatter2(uint32_t n, const uint32_t *__restrict__ pt_slot,
+                                                           const uint32_t *__restrict__ pt_pos,
+                                                           const uint32_t *__restrict__ bkt_off,
+                                                           const uint32_t *__restrict__ bkt_cnt, uint32_t *items,
+                                                           uint32_t *pt_off, uint32_t *pt_m, uint32_t seq,
+                                                           const uint32_t *words)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || words[5] == seq) return;
+    const uint32_t h = pt_slot[i];
+    const uint32_t off = bkt_off[h];
+    items[off + pt_pos[i]] = i;
+    pt_off[i] = off;
+    pt_m[i] = bkt_cnt[h];
+}
+
+__global__ __launch_bounds__(kThreads) void k_ins_place2(Slot *table, uint32_t n, const uint32_t *__restrict__ pt_slot,
+                                                         const uint32_t *__restrict__ pt_off,
+                                                         const uint32_t *__restrict__ pt_m, uint32_t *bkt_cnt,
+                                                         uint32_t *bkt_head, const uint32_t *__restrict__ bkt_old,
+                                                         const uint32_t *__restrict__ items, const char *xyz,
+                                                         const char *nrm, size_t stride, uint32_t K, float *pts,
+                                                         float *nrm_out, uint32_t *slab_count, uint32_t *n_vox_dev,
+                                                         uint32_t seq, const uint32_t *words)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t h = pt_slot[i];
+    if (h == kInvalidSlot) return;
+    const bool is_head = bkt_head[h] == i;  // only this thread resets the word, and only after this read
+    if (words[5] != seq) {
+        const uint32_t old = bkt_old[h];
+        const uint32_t slab = table[h].slab;
+        const uint32_t m = pt_m[i];
+        if (old < K) {
+            const uint32_t room = K - old;
+            const uint32_t *it = items + pt_off[i];
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < m && rank < room; j++) rank += it[j] < i;
+            if (rank < room) {  // voxel_grid.h:86,89-90: append while size() < max_points_, in input order
+                const size_t dst = ((size_t)slab * K + old + rank) * 3;
+                const float *p = point_at(xyz, i, stride);
+                pts[dst + 0] = p[0];
+                pts[dst + 1] = p[1];
+                pts[dst + 2] = p[2];
+                if (nrm) {
+                    const float *q = point_at(nrm, i, stride);
+                    nrm_out[dst + 0] = q[0];
+                    nrm_out[dst + 1] = q[1];
+                    nrm_out[dst + 2] = q[2];
+                } else {  // voxel_grid.h:103,107
+                    nrm_out[dst + 0] = 0.f;
+                    nrm_out[dst + 1] = 0.f;
+                    nrm_out[dst + 2] = 0.f;
+                }
+            }
+        }
+        if (is_head) {
+            const uint32_t want = old + m;
+            const uint32_t nc = want < K ? want : K;
+            table[h].count = nc;
+            slab_count[slab] = nc;
+        }
+        if (i == 0) *n_vox_dev += words[0];  // point 0 is always the head of its voxel's bucket... and exists once
+    }
+    if (is_head) {  // scratch back to rest
+        bkt_cnt[h] = 0u;
+        bkt_head[h] = 0xFFFFFFFFu;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // cleanup / export kernels
 // ---------------------------------------------------------------------------
 // voxel_grid.h:238-241: erase iff (getOrigin() - point).squaredNorm() > radius_sq (f32, strict)
@@ -457,12 +666,51 @@ __global__ void k_cleanup_flag(const float *pts, uint32_t K, uint32_t n_vox, flo
     keep[s] = (d2 > r2) ? 0u : 1u;
 }
 
+// the same flags and their exclusive scan in one kernel (kItems consecutive voxels per thread, <= 256
+// workgroups): keep[], newid[] and the number of voxels kept (words[4])
+template <int kItems>
+__global__ __launch_bounds__(kThreads) void k_cleanup_scan(const float *pts, uint32_t K, uint32_t n_vox, float cx, float cy,
+                                                           float cz, float r2, uint32_t *keep, uint32_t *newid,
+                                                           Granule *agg, uint32_t seq, uint32_t *words)
+{
+    __shared__ unsigned long long s_w[8];
+    const uint32_t base = (blockIdx.x * kThreads + threadIdx.x) * kItems;
+    uint32_t f[kItems], mine = 0;
+#pragma unroll
+    for (int k = 0; k < kItems; k++) {
+        const uint32_t s = base + k;
+        f[k] = 0;
+        if (s < n_vox) {
+            const float *o = pts + (size_t)s * K * 3;  // voxel_with_planes.h:32-35 front()
+            const float dx = o[0] - cx, dy = o[1] - cy, dz = o[2] - cz;
+            const float d2 = dx * dx + (dy * dy + dz * dz);
+            f[k] = (d2 > r2) ? 0u : 1u;  // voxel_grid.h:238-241
+        }
+        mine += f[k];
+    }
+    unsigned long long total;
+    const unsigned long long excl = block_scan64(mine, s_w, total);
+    const unsigned long long before = grid_prefix64(total, agg, seq, words + 7, s_w);
+    uint32_t run = (uint32_t)(before + excl);
+#pragma unroll
+    for (int k = 0; k < kItems; k++) {
+        const uint32_t s = base + k;
+        if (s < n_vox) {
+            keep[s] = f[k];
+            newid[s] = run;
+        }
+        run += f[k];
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) words[4] = (uint32_t)(before + total);
+}
+
 __global__ void k_compact(const uint32_t *keep, const uint32_t *newid, uint32_t n_vox, uint32_t K,
                           const unsigned long long *key_in, const uint32_t *cnt_in, const float *pts_in,
                           const float *nrm_in, unsigned long long *key_out, uint32_t *cnt_out, float *pts_out,
-                          float *nrm_out)
+                          float *nrm_out, uint32_t *n_vox_dev, uint32_t n_keep)
 {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx == 0) *n_vox_dev = n_keep;  // the device-side voxel counter follows the compaction
     if (idx >= (size_t)n_vox * K) return;
     const uint32_t s = (uint32_t)(idx / K), j = (uint32_t)(idx % K);
     if (!keep[s]) return;
@@ -629,89 +877,132 @@ int read_words(lom_map *m, int first, int n)
     return LOM_OK;
 }
 
+// grow-only scratch that is kept at rest (every byte == fill) between calls: a fresh allocation is
+// filled once; whoever dirties a word puts it back
+static int ensure_rest(lom_map *m, DeviceBuf &b, size_t bytes, int fill)
+{
+    if (bytes <= b.bytes) return LOM_OK;
+    const int rc = ensure(m, b, bytes);
+    if (rc != LOM_OK) return rc;
+    LOM_HIP(m, hipMemsetAsync(b.p, fill, b.bytes, m->stream));
+    return LOM_OK;
+}
+
+static Granule *d_agg(lom_map *m) { return (Granule *)((char *)m->scr[S_MISC].p + 256); }
+
+// deferred verdict of the calls enqueued since the last check (waits for them): a point out of range
+// (such a call inserted / returned nothing) or a workgroup that gave up waiting inside a single-pass kernel
+static int map_status(lom_map *m)
+{
+    int rc = read_words(m, 5, 3);  // [0] range flag, [1] voxel counter, [2] grid error: sequence numbers of failed calls
+    if (rc != LOM_OK) return rc;
+    const uint32_t checked = m->status_seq;
+    m->status_seq = m->call_seq;
+    if (m->n_vox_stale) {
+        m->n_vox = m->h_flags[1];
+        m->n_vox_ub = m->n_vox;
+        m->n_vox_stale = false;
+    }
+    if (m->h_flags[2] > checked) return set_error(m, LOM_ERR_HIP, "a workgroup timed out waiting for the others of its grid");
+    if (m->h_flags[0] > checked) return set_error(m, LOM_ERR_RANGE, "coordinate / voxel_size out of range or not finite");
+    return LOM_OK;
+}
+
+// sync_status: wait for the insert's verdict (LOM_ERR_RANGE when a point's index is out of range; such a
+// call inserts nothing).  Without it the call only enqueues; lom_map_status() reports later.
 static int add_points_device(lom_map *m, const char *d_xyz, const char *d_nrm, size_t n, size_t stride,
-                             bool validated_on_host)
+                             bool validated_on_host, bool sync_status)
 {
     if (n == 0) return LOM_OK;
     if (n >= 0x7FFFFFFFull) return set_error(m, LOM_ERR_ARG, "too many points in one call");
     const uint32_t N = (uint32_t)n;
     int rc;
-    // 1. validate (a failing call inserts nothing)
-    LOM_HIP(m, hipMemsetAsync(d_word(m, 2), 0, 12, m->stream));  // flag, cursor, total
-    if (!validated_on_host) {
-        hipLaunchKernelGGL(k_validate, dim3(blocks_for(N)), dim3(kThreads), 0, m->stream, d_xyz, stride, N,
-                           m->voxel_size, d_word(m, 2));
-        LOM_HIP(m, hipGetLastError());
-        if ((rc = read_words(m, 2, 1)) != LOM_OK) return rc;
-        if (m->h_flags[0]) return set_error(m, LOM_ERR_RANGE, "coordinate / voxel_size out of range or not finite");
-    }
-    // 2. table capacity for the worst case (every point a new voxel); shrunk afterwards
+    // 1. table capacity for the worst case (every point a new voxel); shrunk afterwards
     uint64_t worst = (uint64_t)m->n_vox_ub + N;
     if ((uint64_t)m->cap < 2 * worst) {
         if ((rc = refresh_nvox(m)) != LOM_OK) return rc;
         worst = (uint64_t)m->n_vox + N;
         if ((uint64_t)m->cap < 2 * worst && (rc = rehash(m, next_pow2(4 * worst))) != LOM_OK) return rc;
     }
-    // 3. scratch
+    // 2. scratch
+    const bool one_pass = N <= kOnePassMax;
     if ((rc = ensure(m, m->scr[S_PT_SLOT], (size_t)N * 4)) != LOM_OK) return rc;
     if ((rc = ensure(m, m->scr[S_PT_POS], (size_t)N * 4)) != LOM_OK) return rc;
-    if ((rc = ensure(m, m->scr[S_FLAG], (size_t)N * 8)) != LOM_OK) return rc;
-    if ((rc = ensure(m, m->scr[S_RANK], (size_t)N * 8)) != LOM_OK) return rc;
+    if ((rc = ensure(m, m->scr[S_PT_OFF], (size_t)N * 4)) != LOM_OK) return rc;
+    if ((rc = ensure(m, m->scr[S_PT_M], (size_t)N * 4)) != LOM_OK) return rc;
     if ((rc = ensure(m, m->scr[S_ITEMS], (size_t)N * 4)) != LOM_OK) return rc;
-    if ((rc = ensure(m, m->scr[S_BKT_CNT], (size_t)m->cap * 4)) != LOM_OK) return rc;
-    if ((rc = ensure(m, m->scr[S_BKT_HEAD], (size_t)m->cap * 4)) != LOM_OK) return rc;
+    if ((rc = ensure_rest(m, m->scr[S_BKT_CNT], (size_t)m->cap * 4, 0)) != LOM_OK) return rc;
+    if ((rc = ensure_rest(m, m->scr[S_BKT_HEAD], (size_t)m->cap * 4, 0xFF)) != LOM_OK) return rc;
     if ((rc = ensure(m, m->scr[S_BKT_OFF], (size_t)m->cap * 4)) != LOM_OK) return rc;
-    if ((rc = ensure(m, m->scr[S_SCAN], scan_tmp_words(N) * 8)) != LOM_OK) return rc;
+    if ((rc = ensure(m, m->scr[S_BKT_OLD], (size_t)m->cap * 4)) != LOM_OK) return rc;
+    if (!one_pass) {
+        if ((rc = ensure(m, m->scr[S_FLAG], (size_t)N * 8)) != LOM_OK) return rc;
+        if ((rc = ensure(m, m->scr[S_RANK], (size_t)N * 8)) != LOM_OK) return rc;
+        if ((rc = ensure(m, m->scr[S_SCAN], scan_tmp_words(N) * 8)) != LOM_OK) return rc;
+    }
     uint32_t *pt_slot = (uint32_t *)m->scr[S_PT_SLOT].p, *pt_pos = (uint32_t *)m->scr[S_PT_POS].p;
-    unsigned long long *flag64 = (unsigned long long *)m->scr[S_FLAG].p;
-    unsigned long long *scan64 = (unsigned long long *)m->scr[S_RANK].p;
+    uint32_t *pt_off = (uint32_t *)m->scr[S_PT_OFF].p, *pt_m = (uint32_t *)m->scr[S_PT_M].p;
     uint32_t *items = (uint32_t *)m->scr[S_ITEMS].p;
     uint32_t *bcnt = (uint32_t *)m->scr[S_BKT_CNT].p, *bhead = (uint32_t *)m->scr[S_BKT_HEAD].p;
-    uint32_t *boff = (uint32_t *)m->scr[S_BKT_OFF].p;
-    LOM_HIP(m, hipMemsetAsync(bcnt, 0, (size_t)m->cap * 4, m->stream));
-    LOM_HIP(m, hipMemsetAsync(bhead, 0xFF, (size_t)m->cap * 4, m->stream));
+    uint32_t *boff = (uint32_t *)m->scr[S_BKT_OFF].p, *bold = (uint32_t *)m->scr[S_BKT_OLD].p;
+    uint32_t *words = d_word(m, 0);
+    const uint32_t seq = ++m->call_seq;
     const MapView v = view_of(m);
     const dim3 g(blocks_for(N)), b(kThreads);
-    hipLaunchKernelGGL(k_ins_claim, g, b, 0, m->stream, m->d_table, v.mask, v.shift, d_xyz, stride, N,
-                       m->voxel_size, pt_slot, pt_pos, bcnt, bhead);
-    hipLaunchKernelGGL(k_ins_heads, g, b, 0, m->stream, m->d_table, N, pt_slot, bcnt, bhead, flag64);
+    hipLaunchKernelGGL(k_ins_claim2, g, b, 0, m->stream, m->d_table, v.mask, v.shift, d_xyz, stride, N, m->voxel_size,
+                       pt_slot, pt_pos, bcnt, bhead, seq, words);
     LOM_HIP(m, hipGetLastError());
-    unsigned long long *d_total64 = (unsigned long long *)m->scr[S_MISC].p;
-    if ((rc = scan_exclusive<unsigned long long>(m, flag64, scan64, N, d_total64,
-                                                 (unsigned long long *)m->scr[S_SCAN].p)) != LOM_OK)
-        return rc;
     // If even the worst case fits the allocated slabs nothing below depends on a host decision:
     // enqueue the rest and return (the voxel counter lives on the device).  Otherwise wait for the
     // exact number of new voxels and grow the slabs first.
     const bool no_wait = worst <= m->slab_cap;
     uint32_t n_new = 0;
-    if (!no_wait) {
-        LOM_HIP(m, hipMemcpyAsync(m->h_flags, d_word(m, 0), 4, hipMemcpyDeviceToHost, m->stream));
-        LOM_HIP(m, hipMemcpyAsync(m->h_flags + 1, d_nvox(m), 4, hipMemcpyDeviceToHost, m->stream));
-        LOM_HIP(m, hipStreamSynchronize(m->stream));
-        n_new = m->h_flags[0];          // low word of the total = number of new voxels
-        m->n_vox = m->h_flags[1];       // exact: every earlier insert has bumped the counter
-        m->n_vox_ub = m->n_vox;
-        m->n_vox_stale = false;
-        if ((rc = ensure_slabs(m, (uint64_t)m->n_vox + n_new)) != LOM_OK) return rc;
+    if (!one_pass || !no_wait) {
+        // large batches, or the slabs may have to grow: flags, one 64-bit scan (1-3 launches), assignment
+        if ((rc = ensure(m, m->scr[S_FLAG], (size_t)N * 8)) != LOM_OK) return rc;
+        if ((rc = ensure(m, m->scr[S_RANK], (size_t)N * 8)) != LOM_OK) return rc;
+        if ((rc = ensure(m, m->scr[S_SCAN], scan_tmp_words(N) * 8)) != LOM_OK) return rc;
+        unsigned long long *flag64 = (unsigned long long *)m->scr[S_FLAG].p;
+        unsigned long long *scan64 = (unsigned long long *)m->scr[S_RANK].p;
+        hipLaunchKernelGGL(k_ins_heads, g, b, 0, m->stream, m->d_table, N, pt_slot, bcnt, bhead, flag64, seq, words);
+        LOM_HIP(m, hipGetLastError());
+        unsigned long long *d_total64 = (unsigned long long *)m->scr[S_MISC].p;
+        if ((rc = scan_exclusive<unsigned long long>(m, flag64, scan64, N, d_total64,
+                                                     (unsigned long long *)m->scr[S_SCAN].p)) != LOM_OK)
+            return rc;
+        if (!no_wait) {
+            LOM_HIP(m, hipMemcpyAsync(m->h_flags, d_word(m, 0), 4, hipMemcpyDeviceToHost, m->stream));
+            LOM_HIP(m, hipMemcpyAsync(m->h_flags + 1, d_nvox(m), 4, hipMemcpyDeviceToHost, m->stream));
+            LOM_HIP(m, hipStreamSynchronize(m->stream));
+            n_new = m->h_flags[0];     // low word of the total = number of new voxels
+            m->n_vox = m->h_flags[1];  // exact: every earlier insert has bumped the counter
+            m->n_vox_ub = m->n_vox;
+            m->n_vox_stale = false;
+            if ((rc = ensure_slabs(m, (uint64_t)m->n_vox + n_new)) != LOM_OK) return rc;
+        }
+        hipLaunchKernelGGL(k_ins_assign, g, b, 0, m->stream, m->d_table, N, pt_slot, bhead, flag64, scan64, d_nvox(m),
+                           m->d_slab_key, boff, bold, seq, words);
+    } else {
+        hipLaunchKernelGGL(k_ins_assign2, g, b, 0, m->stream, m->d_table, N, pt_slot, bcnt, bhead, boff, bold, d_nvox(m),
+                           m->d_slab_key, d_agg(m), seq, words);
     }
-    hipLaunchKernelGGL(k_ins_assign, g, b, 0, m->stream, m->d_table, N, pt_slot, bhead, flag64, scan64, d_nvox(m),
-                       m->d_slab_key, boff);
-    hipLaunchKernelGGL(k_ins_scatter, g, b, 0, m->stream, N, pt_slot, pt_pos, boff, items);
-    hipLaunchKernelGGL(k_ins_place, g, b, 0, m->stream, m->d_table, N, pt_slot, bcnt, boff, items, d_xyz, d_nrm,
-                       stride, m->K, m->d_pts, m->d_nrm);
-    hipLaunchKernelGGL(k_ins_finalize, g, b, 0, m->stream, m->d_table, N, pt_slot, bcnt, bhead, m->K,
-                       m->d_slab_count);
-    hipLaunchKernelGGL(k_nvox_bump, dim3(1), dim3(1), 0, m->stream, d_nvox(m), d_total64);
+    hipLaunchKernelGGL(k_ins_scatter2, g, b, 0, m->stream, N, pt_slot, pt_pos, boff, bcnt, items, pt_off, pt_m, seq, words);
+    hipLaunchKernelGGL(k_ins_place2, g, b, 0, m->stream, m->d_table, N, pt_slot, pt_off, pt_m, bcnt, bhead, bold, items,
+                       d_xyz, d_nrm, stride, m->K, m->d_pts, m->d_nrm, m->d_slab_count, d_nvox(m), seq, words);
     LOM_HIP(m, hipGetLastError());
+    m->table_clean = false;
     if (no_wait) {
-        m->n_vox_ub = (uint32_t)worst;
+        m->n_vox_ub = (uint32_t)std::min<uint64_t>(worst, 0xFFFFFFFFull);
         m->n_vox_stale = true;
-        return LOM_OK;
+    } else {
+        m->n_vox += n_new;
+        m->n_vox_ub = m->n_vox;
     }
-    m->n_vox += n_new;
-    m->n_vox_ub = m->n_vox;
-    // 4. keep the table dense enough to stay cache-resident: load factor in (1/16, 1/2]
+    if (sync_status && !validated_on_host) {
+        if ((rc = map_status(m)) != LOM_OK) return rc;
+    }
+    if (no_wait) return LOM_OK;
+    // 3. keep the table dense enough to stay cache-resident: load factor in (1/16, 1/2]
     // (measured on C2/C3: 2 slots per voxel costs the search 5-10 %, 4..16 are equal within noise)
     const uint32_t target = std::max(m->min_cap, next_pow2(4ull * m->n_vox));
     if (m->cap > 4 * target) {
@@ -867,9 +1158,10 @@ int lom_map_create(float voxel_size, size_t max_points, size_t capacity_hint, in
     std::memset(m->h_cmd, 0, 256);
     std::memset(m->h_report, 0, 256);
     m->min_cap = next_pow2(4ull * std::max<size_t>(capacity_hint, 256));
-    int rc = ensure(m, m->scr[S_MISC], 256);
+    // status / counter words (256 bytes) + the block aggregates of the single-pass kernels (256 x 2 granules)
+    int rc = ensure(m, m->scr[S_MISC], 256 + 256 * 2 * sizeof(Granule));
     if (rc == LOM_OK) {
-        if (hipMemsetAsync(m->scr[S_MISC].p, 0, 256, m->stream) != hipSuccess) rc = LOM_ERR_HIP;
+        if (hipMemsetAsync(m->scr[S_MISC].p, 0, m->scr[S_MISC].bytes, m->stream) != hipSuccess) rc = LOM_ERR_HIP;
     }
     if (rc == LOM_OK) rc = table_alloc(m, m->min_cap, &m->d_table);
     if (rc == LOM_OK) m->cap = m->min_cap;
@@ -903,7 +1195,7 @@ void lom_map_destroy(lom_map *m)
     for (auto &b : m->scr)
         if (b.p) (void)hipFree(b.p);
     for (DeviceBuf *b : {&m->scan_src, &m->scan_idx, &m->scan_on, &m->scan_stats, &m->partials, &m->results, &m->gather,
-                         &m->align_state, &m->xrec})
+                         &m->align_state, &m->xrec, &m->dbg_trace, &m->dbg_stamps})
         if (b->p) (void)hipFree(b->p);
     if (m->h_results) (void)hipHostFree(m->h_results);
     if (m->h_flags) (void)hipHostFree(m->h_flags);
@@ -945,9 +1237,12 @@ int lom_map_clear(lom_map *m, float voxel_size)
     m->n_vox_ub = 0;
     m->n_vox_stale = false;
     m->n_points = 0;
-    hipLaunchKernelGGL(k_table_init, dim3(blocks_for(m->cap)), dim3(kThreads), 0, m->stream, m->d_table, m->cap);
-    LOM_HIP(m, hipMemsetAsync(d_nvox(m), 0, 4, m->stream));
-    LOM_HIP(m, hipGetLastError());
+    if (!m->table_clean) {
+        hipLaunchKernelGGL(k_table_init, dim3(blocks_for(m->cap)), dim3(kThreads), 0, m->stream, m->d_table, m->cap);
+        LOM_HIP(m, hipMemsetAsync(d_nvox(m), 0, 4, m->stream));
+        LOM_HIP(m, hipGetLastError());
+        m->table_clean = true;
+    }
     return LOM_OK;
 }
 
@@ -983,7 +1278,21 @@ int lom_map_add_points_device(lom_map *m, const float *d_xyz, const float *d_nrm
 {
     if (!m || (n && !d_xyz) || stride < 12 || (stride & 3)) return LOM_ERR_ARG;
     LOM_HIP(m, hipSetDevice(m->device));
-    return add_points_device(m, (const char *)d_xyz, (const char *)d_nrm, n, stride, false);
+    return add_points_device(m, (const char *)d_xyz, (const char *)d_nrm, n, stride, false, true);
+}
+
+int lom_map_add_points_device_nowait(lom_map *m, const float *d_xyz, const float *d_nrm, size_t n, size_t stride)
+{
+    if (!m || (n && !d_xyz) || stride < 12 || (stride & 3)) return LOM_ERR_ARG;
+    LOM_HIP(m, hipSetDevice(m->device));
+    return add_points_device(m, (const char *)d_xyz, (const char *)d_nrm, n, stride, false, false);
+}
+
+int lom_map_status(lom_map *m)
+{
+    if (!m) return LOM_ERR_ARG;
+    LOM_HIP(m, hipSetDevice(m->device));
+    return map_status(m);
 }
 
 int lom_map_add_points(lom_map *m, const float *xyz, const float *nrm, size_t n, size_t stride)
@@ -1008,7 +1317,7 @@ int lom_map_add_points(lom_map *m, const float *xyz, const float *nrm, size_t n,
     int rc = stage_host_points(m, xyz, nrm, n, stride, &dx, &dn);
     if (rc != LOM_OK) return rc;
     // the caller's buffer has been copied into the pinned bounce buffer: no need to wait for the GPU
-    return add_points_device(m, dx, dn, n, stride, true);
+    return add_points_device(m, dx, dn, n, stride, true, false);
 }
 
 int lom_map_radius_cleanup(lom_map *m, const float center[3], float radius)
@@ -1024,11 +1333,31 @@ int lom_map_radius_cleanup(lom_map *m, const float center[3], float radius)
     if ((rc = ensure(m, m->scr[S_SCAN], scan_tmp_words(nv) * 4)) != LOM_OK) return rc;
     uint32_t *keep = (uint32_t *)m->scr[S_FLAG].p, *newid = (uint32_t *)m->scr[S_RANK].p;
     const float r2 = radius * radius;  // voxel_grid.h:238
-    hipLaunchKernelGGL(k_cleanup_flag, dim3(blocks_for(nv)), dim3(kThreads), 0, m->stream, m->d_pts, m->K, nv,
-                       center[0], center[1], center[2], r2, keep);
+    const uint32_t seq = ++m->call_seq;
+    bool one_pass = true;
+    auto launch_scan = [&](auto items) {
+        constexpr int kItems = decltype(items)::value;
+        hipLaunchKernelGGL((k_cleanup_scan<kItems>), dim3(blocks_for((nv + kItems - 1) / kItems)), dim3(kThreads), 0,
+                           m->stream, m->d_pts, m->K, nv, center[0], center[1], center[2], r2, keep, newid, d_agg(m), seq,
+                           d_word(m, 0));
+    };
+    if (nv <= kOnePassMax)
+        launch_scan(std::integral_constant<int, 1>());
+    else if (nv <= 4 * kOnePassMax)
+        launch_scan(std::integral_constant<int, 4>());
+    else if (nv <= 16 * kOnePassMax)
+        launch_scan(std::integral_constant<int, 16>());
+    else
+        one_pass = false;
+    if (!one_pass) {
+        hipLaunchKernelGGL(k_cleanup_flag, dim3(blocks_for(nv)), dim3(kThreads), 0, m->stream, m->d_pts, m->K, nv,
+                           center[0], center[1], center[2], r2, keep);
+        LOM_HIP(m, hipGetLastError());
+        if ((rc = scan_exclusive(m, keep, newid, nv, d_word(m, 4), (uint32_t *)m->scr[S_SCAN].p)) != LOM_OK) return rc;
+    }
     LOM_HIP(m, hipGetLastError());
-    if ((rc = scan_exclusive(m, keep, newid, nv, d_word(m, 4), (uint32_t *)m->scr[S_SCAN].p)) != LOM_OK) return rc;
-    if ((rc = read_words(m, 4, 1)) != LOM_OK) return rc;
+    if ((rc = read_words(m, 4, 4)) != LOM_OK) return rc;
+    if (m->h_flags[3] == seq) return set_error(m, LOM_ERR_HIP, "a workgroup timed out waiting for the others of its grid");
     const uint32_t n_keep = m->h_flags[0];
     if (n_keep == nv) return LOM_OK;
     // stable compaction into the second (persistent) set of slab arrays, swap, rebuild the table
@@ -1051,7 +1380,7 @@ int lom_map_radius_cleanup(lom_map *m, const float center[3], float radius)
     const size_t work = (size_t)nv * m->K;
     hipLaunchKernelGGL(k_compact, dim3(blocks_for(work)), dim3(kThreads), 0, m->stream, keep, newid, nv, m->K,
                        m->d_slab_key, m->d_slab_count, m->d_pts, m->d_nrm, m->alt_key, m->alt_count, m->alt_pts,
-                       m->alt_nrm);
+                       m->alt_nrm, d_nvox(m), n_keep);
     LOM_HIP(m, hipGetLastError());
     std::swap(m->d_slab_key, m->alt_key);
     std::swap(m->d_slab_count, m->alt_count);
@@ -1059,7 +1388,6 @@ int lom_map_radius_cleanup(lom_map *m, const float center[3], float radius)
     std::swap(m->d_nrm, m->alt_nrm);
     m->n_vox = n_keep;
     m->n_vox_ub = n_keep;
-    hipLaunchKernelGGL(k_set_word, dim3(1), dim3(1), 0, m->stream, d_nvox(m), n_keep);
     const MapView v = view_of(m);
     hipLaunchKernelGGL(k_table_init, dim3(blocks_for(m->cap)), dim3(kThreads), 0, m->stream, m->d_table, m->cap);
     if (n_keep) {
@@ -1089,39 +1417,50 @@ int64_t lom_map_point_count(const lom_map *cm)
 }
 
 // shared body of the down-samplers: device input, results left in the workspace's scratch
-// (S_ITEMS: xyz, S_PT_POS: normals), voxel count in word 4, range flag in word 5 of S_MISC
+// (S_ITEMS: xyz, S_PT_POS: normals), voxel count in word 4, range flag in word 5 of S_MISC.
+// wait: read the count and the verdict back (one synchronisation); otherwise the call only enqueues and
+// the count stays on the device (d_word(m, 4)) for the kernels that consume the result.
 static int downsample_core(lom_map *m, float voxel_size, const char *dx, const char *dn, uint32_t N, size_t stride,
-                           bool want_normals)
+                           bool want_normals, bool wait)
 {
     int rc;
     if ((uint64_t)m->cap < 2ull * N) {
         if ((rc = rehash(m, next_pow2(4ull * N))) != LOM_OK) return rc;
     }
+    const bool one_pass = N <= kOnePassMax;
     if ((rc = ensure(m, m->scr[S_PT_SLOT], (size_t)N * 4)) != LOM_OK) return rc;
-    if ((rc = ensure(m, m->scr[S_FLAG], (size_t)N * 4)) != LOM_OK) return rc;
-    if ((rc = ensure(m, m->scr[S_RANK], (size_t)N * 4)) != LOM_OK) return rc;
-    if ((rc = ensure(m, m->scr[S_BKT_HEAD], (size_t)m->cap * 4)) != LOM_OK) return rc;
-    if ((rc = ensure(m, m->scr[S_SCAN], scan_tmp_words(N) * 4)) != LOM_OK) return rc;
+    if ((rc = ensure_rest(m, m->scr[S_DS_HEAD], (size_t)m->cap * 4, 0xFF)) != LOM_OK) return rc;
     if ((rc = ensure(m, m->scr[S_ITEMS], (size_t)N * 12)) != LOM_OK) return rc;     // compacted xyz
     if ((rc = ensure(m, m->scr[S_PT_POS], (size_t)N * 12)) != LOM_OK) return rc;    // compacted normals
-    uint32_t *pt_slot = (uint32_t *)m->scr[S_PT_SLOT].p, *flag = (uint32_t *)m->scr[S_FLAG].p;
-    uint32_t *rank = (uint32_t *)m->scr[S_RANK].p, *head = (uint32_t *)m->scr[S_BKT_HEAD].p;
+    uint32_t *pt_slot = (uint32_t *)m->scr[S_PT_SLOT].p, *head = (uint32_t *)m->scr[S_DS_HEAD].p;
     float *oxyz = (float *)m->scr[S_ITEMS].p, *onrm = want_normals ? (float *)m->scr[S_PT_POS].p : nullptr;
-    LOM_HIP(m, hipMemsetAsync(head, 0xFF, (size_t)m->cap * 4, m->stream));
-    LOM_HIP(m, hipMemsetAsync(d_word(m, 5), 0, 4, m->stream));
+    const uint32_t seq = ++m->call_seq;
     const MapView v = view_of(m);
     const dim3 g(blocks_for(N)), b(kThreads);
     hipLaunchKernelGGL(k_ds_claim, g, b, 0, m->stream, m->d_table, v.mask, v.shift, dx, stride, N, voxel_size, pt_slot,
-                       head, d_word(m, 5));
-    hipLaunchKernelGGL(k_ds_flag, g, b, 0, m->stream, N, pt_slot, head, flag);
-    LOM_HIP(m, hipGetLastError());
-    if ((rc = scan_exclusive(m, flag, rank, N, d_word(m, 4), (uint32_t *)m->scr[S_SCAN].p)) != LOM_OK) return rc;
-    hipLaunchKernelGGL(k_ds_write, g, b, 0, m->stream, N, flag, rank, dx, dn, stride, oxyz, onrm);
-    // leave the workspace empty again (its table holds claimed keys without payload)
-    hipLaunchKernelGGL(k_table_init, dim3(blocks_for(m->cap)), dim3(kThreads), 0, m->stream, m->d_table, m->cap);
-    LOM_HIP(m, hipGetLastError());
-    if ((rc = read_words(m, 4, 2)) != LOM_OK) return rc;  // [0] voxels, [1] range flag
-    if (m->h_flags[1]) return set_error(m, LOM_ERR_RANGE, "coordinate / voxel_size out of range or not finite");
+                       head, seq, d_word(m, 5));
+    if (one_pass) {
+        hipLaunchKernelGGL(k_ds_emit, g, b, 0, m->stream, m->d_table, N, pt_slot, head, dx, dn, stride, oxyz, onrm,
+                           d_agg(m), seq, d_word(m, 0));
+        LOM_HIP(m, hipGetLastError());
+    } else {
+        if ((rc = ensure(m, m->scr[S_FLAG], (size_t)N * 4)) != LOM_OK) return rc;
+        if ((rc = ensure(m, m->scr[S_RANK], (size_t)N * 4)) != LOM_OK) return rc;
+        if ((rc = ensure(m, m->scr[S_SCAN], scan_tmp_words(N) * 4)) != LOM_OK) return rc;
+        uint32_t *flag = (uint32_t *)m->scr[S_FLAG].p, *rank = (uint32_t *)m->scr[S_RANK].p;
+        hipLaunchKernelGGL(k_ds_flag, g, b, 0, m->stream, N, pt_slot, head, flag);
+        LOM_HIP(m, hipGetLastError());
+        if ((rc = scan_exclusive(m, flag, rank, N, d_word(m, 4), (uint32_t *)m->scr[S_SCAN].p)) != LOM_OK) return rc;
+        // the kept point of every voxel also frees its table slot and head word: the workspace is at rest again
+        hipLaunchKernelGGL(k_ds_write, g, b, 0, m->stream, N, flag, rank, dx, dn, stride, oxyz, onrm, m->d_table, pt_slot,
+                           head);
+        LOM_HIP(m, hipGetLastError());
+    }
+    if (!wait) return LOM_OK;
+    if ((rc = read_words(m, 4, 4)) != LOM_OK) return rc;  // [0] voxels, [1] range flag, [3] grid error
+    m->status_seq = seq;
+    if (m->h_flags[3] == seq) return set_error(m, LOM_ERR_HIP, "a workgroup timed out waiting for the others of its grid");
+    if (m->h_flags[1] == seq) return set_error(m, LOM_ERR_RANGE, "coordinate / voxel_size out of range or not finite");
     return LOM_OK;
 }
 
@@ -1137,7 +1476,7 @@ int64_t lom_voxel_downsample(lom_map *ws, float voxel_size, const float *xyz, co
     const char *dx = nullptr, *dn = nullptr;
     if ((rc = stage_host_points(m, xyz, nrm, n, stride, &dx, &dn)) != LOM_OK) return rc;
     // the range rule of addCloud is checked by the claim kernel (flag read back with the count)
-    if ((rc = downsample_core(m, voxel_size, dx, dn, (uint32_t)n, stride, nrm_out != nullptr)) != LOM_OK) return rc;
+    if ((rc = downsample_core(m, voxel_size, dx, dn, (uint32_t)n, stride, nrm_out != nullptr, true)) != LOM_OK) return rc;
     const size_t total = m->h_flags[0];
     const size_t take = std::min(total, cap);
     if (take) {
@@ -1161,7 +1500,7 @@ int64_t lom_voxel_downsample_device(lom_map *ws, float voxel_size, const float *
     int rc = lom_map_clear(m, voxel_size);
     if (rc != LOM_OK || n == 0) return rc;
     if ((rc = downsample_core(m, voxel_size, (const char *)d_xyz, (const char *)d_nrm, (uint32_t)n, stride,
-                              d_nrm_out != nullptr)) != LOM_OK)
+                              d_nrm_out != nullptr, true)) != LOM_OK)
         return rc;
     *d_xyz_out = (const float *)m->scr[S_ITEMS].p;
     if (d_nrm_out) *d_nrm_out = (const float *)m->scr[S_PT_POS].p;
