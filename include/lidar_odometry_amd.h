@@ -132,6 +132,14 @@ int lom_upload_points(lom_map *m, const float *xyz, const float *nrm, size_t n, 
 int64_t lom_voxel_downsample_device(lom_map *workspace, float voxel_size, const float *d_xyz, const float *d_nrm,
                                     size_t n, size_t stride_bytes, const float **d_xyz_out,
                                     const float **d_nrm_out);
+/* the same, enqueued only: the input size may live on the device (*d_n, with n_bound its upper bound known
+ * to the host, <= 65536 then; d_n == NULL: n_bound points), and the number of voxels is left in a device word
+ * (*d_count_out) for the kernels that consume the result; lom_map_status() reports a point out of range. */
+int lom_voxel_downsample_device_nowait(lom_map *workspace, float voxel_size, const float *d_xyz, const float *d_nrm,
+                                       size_t n_bound, const uint32_t *d_n, size_t stride_bytes,
+                                       const float **d_xyz_out, const float **d_nrm_out, const uint32_t **d_count_out);
+/* one synchronisation for up to 32 device words of any handle on this handle's stream */
+int lom_map_read_device_words(lom_map *m, const uint32_t *const *d_ptrs, int n, uint32_t *out);
 /* lom_transform_points on the device (same f32 arithmetic): packed 12-byte output in the handle's
  * staging buffers, valid until the next upload / host-input call on this handle. */
 int lom_transform_points_device(lom_map *m, const lom_pose *pose, const float *d_xyz, const float *d_nrm, size_t n,
@@ -322,6 +330,35 @@ size_t lom_range_filter(const float *xyz, const float *nrm, size_t n, float min_
  * width} are optional outputs.  Returns the number of planar points. */
 size_t lom_cloud_classify(const lom_point_xyzirt *in, size_t n, float *xyz_out, float *nrm_out,
                           size_t *unclassified_out, size_t grid_out[2]);
+
+/* ---- the same four callers on the device: a frame stays in HBM from its upload to its pose ------------- */
+/* Per-frame front end = pointTimeNormalize + transformNonRigid + CloudClassifier::classify + rangeFilter
+ * (the references above) as four HIP kernels; results bit-equal to the host functions above.  Sizes the
+ * host does not know (planar / filtered point counts, organised-cloud shape) stay on the device as words
+ * the consumers read (lom_voxel_downsample_device_nowait takes such a count).  A frame the device cannot
+ * decide bit-exactly (an azimuth within 2e-14 rad of a bin boundary, where the device's atan2 could pick
+ * another cell than the host's; an organised cloud beyond the device buffers) is reported by
+ * lom_frontend_wait() == 1 and is redone by the caller with the host functions. */
+typedef struct lom_frontend lom_frontend;
+int lom_frontend_create(int device, void *hip_stream_or_null, lom_frontend **out);
+void lom_frontend_destroy(lom_frontend *f);
+const char *lom_frontend_last_error(const lom_frontend *f);
+/* enqueue one frame: upload, time normalisation, deskew from start_pose to end_pose, classification, range filter */
+int lom_frontend_process(lom_frontend *f, const lom_point_xyzirt *pts, size_t n, const lom_pose *start_pose,
+                         const lom_pose *end_pose, float min_range, float max_range);
+/* device pointers of the last frame's filtered planar cloud (packed xyz, normals), the host's upper bound of
+ * its size, and the device words {planar points, filtered points, grid height, grid width, ...} */
+int lom_frontend_results(lom_frontend *f, const float **d_xyz, const float **d_nrm, const uint32_t **d_counts,
+                         uint32_t *bound);
+/* wait for the frame: 0 = done on the device, 1 = redo this frame on the host, < 0 = lom_status;
+ * counts_out = {planar, filtered, height, width} */
+int lom_frontend_wait(lom_frontend *f, uint32_t counts_out[4]);
+/* host copies: what = 0 the deskewed cloud (lom_point_xyzirt records into out_a), what = 1 the filtered planar
+ * cloud (packed xyz into out_a, normals into out_b); returns the number of points available */
+int64_t lom_frontend_fetch(lom_frontend *f, int what, void *out_a, void *out_b, size_t cap);
+void *lom_frontend_stream(lom_frontend *f);
+/* test hook: the device's restatement of glibc's sinf (used by the per-point slerp) on n host values */
+int lom_debug_sinf(lom_frontend *f, const float *x, size_t n, float *out);
 
 /* ---- file input: pcl::io::loadPCDFile<pcl::PointXYZ> (test/test.cpp:194) ---------------------------- */
 /* PCD v0.7 reader, host code without PCL: `DATA ascii` and `DATA binary`, fields located by name (x y z,

@@ -15,7 +15,7 @@ from . import capi
 from .capi import LomError  # noqa: F401
 
 __all__ = ["Pose3D", "VoxelGrid", "CloudMatcher", "LidarOdometry", "transform_points", "pointTimeNormalize",
-           "transformNonRigid", "rangeFilter", "classify", "loadPCDFile", "LomError", "capi"]
+           "transformNonRigid", "rangeFilter", "classify", "loadPCDFile", "FrontEnd", "LomError", "capi"]
 
 
 class Pose3D:
@@ -309,6 +309,51 @@ def classify(points):
     grid = (C.c_size_t * 2)()
     n = capi.lib().lom_cloud_classify(a.ctypes.data, len(a), xyz.ctypes.data, nrm.ctypes.data, C.byref(nu), grid)
     return xyz[:n].copy(), nrm[:n].copy(), int(nu.value), (int(grid[0]), int(grid[1]))
+
+
+class FrontEnd:
+    """The per-frame front end on the device (csrc/frontend.hip): pointTimeNormalize + transformNonRigid +
+    CloudClassifier::classify + rangeFilter, results left in HBM."""
+
+    def __init__(self, device=0):
+        h = C.c_void_p()
+        rc = capi.lib().lom_frontend_create(int(device), None, C.byref(h))
+        if rc != 0:
+            raise LomError(int(rc), "lom_frontend_create failed")
+        self._h = h
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h and capi is not None:
+            capi.lib().lom_frontend_destroy(h)
+            self._h = None
+
+    def _check(self, rc):
+        if rc < 0:
+            raise LomError(int(rc), capi.lib().lom_frontend_last_error(self._h).decode())
+        return rc
+
+    def process(self, points, start_pose, end_pose, min_range, max_range):
+        """Returns dict(deskewed, planar_points, xyz, normals, grid, redo_on_host)."""
+        a = _cloud(points)
+        L = capi.lib()
+        self._check(L.lom_frontend_process(self._h, a.ctypes.data, len(a), C.byref(start_pose._c()),
+                                           C.byref(end_pose._c()), float(min_range), float(max_range)))
+        counts = (C.c_uint32 * 4)()
+        redo = self._check(L.lom_frontend_wait(self._h, counts))
+        desk = np.empty(len(a), capi.POINT_XYZIRT)
+        self._check(L.lom_frontend_fetch(self._h, 0, desk.ctypes.data, None, len(a)))
+        nf = int(counts[1])
+        xyz, nrm = np.empty((nf, 3), np.float32), np.empty((nf, 3), np.float32)
+        self._check(L.lom_frontend_fetch(self._h, 1, xyz.ctypes.data, nrm.ctypes.data, nf))
+        return dict(deskewed=desk, planar_points=int(counts[0]), xyz=xyz, normals=nrm,
+                    grid=(int(counts[2]), int(counts[3])), redo_on_host=bool(redo))
+
+    def sinf(self, x):
+        x = np.ascontiguousarray(x, np.float32)
+        out = np.empty_like(x)
+        self._check(capi.lib().lom_debug_sinf(self._h, x.ctypes.data, x.size, out.ctypes.data))
+        return out
 
 
 def loadPCDFile(path, with_normals=False):

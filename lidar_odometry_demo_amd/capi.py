@@ -109,7 +109,9 @@ EXPORTED = [
     "lom_host_comm_destroy", "lom_host_comm_allgather", "lom_comm_attach_host", "lom_comm_attach_p2p", "lom_align_with_hooks", "lom_point_time_normalize", "lom_transform_non_rigid",
     "lom_range_filter", "lom_cloud_classify", "lom_odometry_default_params", "lom_odometry_create",
     "lom_odometry_destroy", "lom_odometry_process_cloud", "lom_odometry_get_pose", "lom_odometry_get_stats", "lom_odometry_get_temp_cloud", "lom_odometry_debug_set_state",
-    "lom_odometry_keyframe", "lom_odometry_last_error", "lom_pcd_read", "lom_pcd_last_error",
+    "lom_odometry_keyframe", "lom_odometry_last_error", "lom_pcd_read", "lom_pcd_last_error", "lom_frontend_create", "lom_frontend_destroy", "lom_frontend_last_error",
+    "lom_frontend_process", "lom_frontend_results", "lom_frontend_wait", "lom_frontend_fetch", "lom_frontend_stream", "lom_debug_sinf",
+    "lom_voxel_downsample_device_nowait", "lom_map_read_device_words",
 ]
 
 _lib = None
@@ -236,6 +238,22 @@ def lib():
     L.lom_odometry_keyframe.restype = vp
     L.lom_odometry_last_error.argtypes = [vp]
     L.lom_odometry_last_error.restype = C.c_char_p
+    L.lom_frontend_create.argtypes = [C.c_int, vp, C.POINTER(vp)]
+    L.lom_frontend_destroy.argtypes = [vp]
+    L.lom_frontend_destroy.restype = None
+    L.lom_frontend_last_error.argtypes = [vp]
+    L.lom_frontend_last_error.restype = C.c_char_p
+    L.lom_frontend_process.argtypes = [vp, vp, C.c_size_t, pp, pp, C.c_float, C.c_float]
+    L.lom_frontend_results.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_uint32)]
+    L.lom_frontend_wait.argtypes = [vp, C.POINTER(C.c_uint32)]
+    L.lom_frontend_fetch.argtypes = [vp, C.c_int, vp, vp, C.c_size_t]
+    L.lom_frontend_fetch.restype = C.c_int64
+    L.lom_frontend_stream.argtypes = [vp]
+    L.lom_frontend_stream.restype = vp
+    L.lom_debug_sinf.argtypes = [vp, vp, C.c_size_t, vp]
+    L.lom_voxel_downsample_device_nowait.argtypes = [vp, C.c_float, vp, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(vp),
+                                                     C.POINTER(vp), C.POINTER(vp)]
+    L.lom_map_read_device_words.argtypes = [vp, C.POINTER(vp), C.c_int, C.POINTER(C.c_uint32)]
     L.lom_pcd_read.argtypes = [C.c_char_p, vp, vp, C.c_size_t, C.POINTER(PcdInfo)]
     L.lom_pcd_read.restype = C.c_int64
     L.lom_pcd_last_error.restype = C.c_char_p

@@ -28,6 +28,7 @@
 #include <new>
 #include <type_traits>
 
+#include "grid_scan.hpp"
 #include "lom_internal.hpp"
 #include "pose_math.hpp"
 
@@ -108,8 +109,6 @@ enum {
     S_MISC
 };
 
-constexpr int kThreads = 256;
-static inline uint32_t blocks_for(size_t n, int t = kThreads) { return (uint32_t)((n + t - 1) / t); }
 
 // ---------------------------------------------------------------------------
 // exclusive prefix scan of uint32 (tile = 256 threads x 8 items)
@@ -287,10 +286,12 @@ __global__ void k_set_word(uint32_t *w, uint32_t v)
 // That is: claim a slot per voxel, take the minimum input index per slot, keep the points whose
 // index is that minimum, compact them by a scan over the input.  No payload slabs are touched.
 // ---------------------------------------------------------------------------
+// n_dev (optional): the number of input points when only the device knows it (n is then its upper bound)
 __global__ void k_ds_claim(Slot *table, uint32_t mask, uint32_t shift, const char *xyz, size_t stride, uint32_t n,
-                           float vs, uint32_t *pt_slot, uint32_t *head, uint32_t seq, uint32_t *bad)
+                           const uint32_t *n_dev, float vs, uint32_t *pt_slot, uint32_t *head, uint32_t seq, uint32_t *bad)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n_dev) n = min(n, *n_dev);
     if (i >= n) return;
     const float *p = point_at(xyz, i, stride);
     int ix = 0, iy = 0, iz = 0;
@@ -385,97 +386,18 @@ __global__ void k_ds_write(uint32_t n, const uint32_t *flag, const uint32_t *ran
 // calls -- zero / 0xFFFFFFFF everywhere -- by the one thread per voxel that consumed it, so no call
 // pays a memset proportional to the table capacity.
 // ---------------------------------------------------------------------------
-constexpr uint32_t kOnePassMax = 256u * kThreads;
-constexpr uint32_t kInvalidSlot = 0xFFFFFFFFu;
-constexpr unsigned long long kGridWaitTicks = 2000000ull;  // 20 ms of s_memrealtime (100 MHz)
-
-struct __attribute__((aligned(8))) Granule {
-    uint32_t seq, val;
-};
-
-__device__ __forceinline__ void granule_store(Granule *g, uint32_t seq, uint32_t val)
-{
-    const unsigned long long w = ((unsigned long long)val << 32) | seq;
-    __hip_atomic_store(reinterpret_cast<unsigned long long *>(g), w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-__device__ __forceinline__ uint32_t granule_wait(const Granule *g, uint32_t seq, uint32_t *err_word)
-{
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    for (;;) {
-        const unsigned long long w = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(g), __ATOMIC_RELAXED,
-                                                       __HIP_MEMORY_SCOPE_AGENT);
-        if ((uint32_t)w == seq) return (uint32_t)(w >> 32);
-        if (__builtin_amdgcn_s_memrealtime() - t0 > kGridWaitTicks) {
-            __hip_atomic_store(err_word, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return 0u;
-        }
-        __builtin_amdgcn_s_sleep(1);
-    }
-}
-
-// exclusive scan of one packed u64 per thread over the workgroup (two u32 quantities, no carry while
-// the low sums stay below 2^32); s_w: 8 words of LDS; total = the workgroup's sum
-__device__ __forceinline__ unsigned long long block_scan64(unsigned long long v, unsigned long long *s_w,
-                                                           unsigned long long &total)
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    unsigned long long inc = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const unsigned long long o = __shfl_up(inc, d, 64);
-        if (lane >= d) inc += o;
-    }
-    if (lane == 63) s_w[wave] = inc;
-    __syncthreads();
-    unsigned long long off = 0;
-    total = 0;
-#pragma unroll
-    for (int w = 0; w < kThreads / 64; w++) {
-        if (w < wave) off += s_w[w];
-        total += s_w[w];
-    }
-    __syncthreads();
-    return off + inc - v;
-}
-
-// sum of the (lo, hi) totals of all workgroups before this one; agg: [gridDim.x][2] granules
-__device__ __forceinline__ unsigned long long grid_prefix64(unsigned long long my_total, Granule *agg, uint32_t seq,
-                                                            uint32_t *err_word, unsigned long long *s_w)
-{
-    if (threadIdx.x == 0) {
-        granule_store(agg + 2 * blockIdx.x, seq, (uint32_t)my_total);
-        granule_store(agg + 2 * blockIdx.x + 1, seq, (uint32_t)(my_total >> 32));
-    }
-    unsigned long long v = 0;
-    if (threadIdx.x < blockIdx.x) {
-        const uint32_t lo = granule_wait(agg + 2 * threadIdx.x, seq, err_word);
-        const uint32_t hi = granule_wait(agg + 2 * threadIdx.x + 1, seq, err_word);
-        v = ((unsigned long long)hi << 32) | lo;
-    }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) s_w[4 + wave] = v;
-    __syncthreads();
-    unsigned long long sum = 0;
-#pragma unroll
-    for (int w = 0; w < kThreads / 64; w++) sum += s_w[4 + w];
-    __syncthreads();
-    return sum;
-}
-
 // ---- down-sampler, two kernels ------------------------------------------------------------------
 // k_ds_claim (above) leaves pt_slot[] and head[]; this kernel keeps the first point of every voxel in
 // order of first appearance and puts the workspace back to rest: the head point of a voxel frees its
 // table slot and its head word, so neither a table re-initialisation nor a memset follows.
-__global__ __launch_bounds__(kThreads) void k_ds_emit(Slot *table, uint32_t n, const uint32_t *__restrict__ pt_slot,
-                                                      uint32_t *head, const char *xyz, const char *nrm, size_t stride,
-                                                      float *out_xyz, float *out_nrm, Granule *agg, uint32_t seq,
-                                                      uint32_t *words)
+__global__ __launch_bounds__(kThreads) void k_ds_emit(Slot *table, uint32_t n, const uint32_t *n_dev,
+                                                      const uint32_t *__restrict__ pt_slot, uint32_t *head, const char *xyz,
+                                                      const char *nrm, size_t stride, float *out_xyz, float *out_nrm,
+                                                      Granule *agg, uint32_t seq, uint32_t *words)
 {
     __shared__ unsigned long long s_w[8];
     const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
+    if (n_dev) n = min(n, *n_dev);
     uint32_t h = kInvalidSlot;
     bool keep = false;
     if (i < n) {
@@ -852,10 +774,11 @@ static int ensure_slabs(lom_map *m, uint64_t want)
     Slabs s;
     int rc = slabs_alloc(m, nc, s);
     if (rc != LOM_OK) return rc;
-    if (m->n_vox) {
-        const size_t pb = (size_t)m->n_vox * m->K * 3 * sizeof(float);
-        LOM_HIP(m, hipMemcpyAsync(s.key, m->d_slab_key, (size_t)m->n_vox * 8, hipMemcpyDeviceToDevice, m->stream));
-        LOM_HIP(m, hipMemcpyAsync(s.count, m->d_slab_count, (size_t)m->n_vox * 4, hipMemcpyDeviceToDevice, m->stream));
+    const uint32_t live = std::min(std::max(m->n_vox, m->n_vox_ub), m->slab_cap);  // upper bound of the slabs in use
+    if (live) {
+        const size_t pb = (size_t)live * m->K * 3 * sizeof(float);
+        LOM_HIP(m, hipMemcpyAsync(s.key, m->d_slab_key, (size_t)live * 8, hipMemcpyDeviceToDevice, m->stream));
+        LOM_HIP(m, hipMemcpyAsync(s.count, m->d_slab_count, (size_t)live * 4, hipMemcpyDeviceToDevice, m->stream));
         LOM_HIP(m, hipMemcpyAsync(s.pts, m->d_pts, pb, hipMemcpyDeviceToDevice, m->stream));
         LOM_HIP(m, hipMemcpyAsync(s.nrm, m->d_nrm, pb, hipMemcpyDeviceToDevice, m->stream));
     }
@@ -952,13 +875,12 @@ static int add_points_device(lom_map *m, const char *d_xyz, const char *d_nrm, s
     hipLaunchKernelGGL(k_ins_claim2, g, b, 0, m->stream, m->d_table, v.mask, v.shift, d_xyz, stride, N, m->voxel_size,
                        pt_slot, pt_pos, bcnt, bhead, seq, words);
     LOM_HIP(m, hipGetLastError());
-    // If even the worst case fits the allocated slabs nothing below depends on a host decision:
-    // enqueue the rest and return (the voxel counter lives on the device).  Otherwise wait for the
-    // exact number of new voxels and grow the slabs first.
-    const bool no_wait = worst <= m->slab_cap;
-    uint32_t n_new = 0;
-    if (!one_pass || !no_wait) {
-        // large batches, or the slabs may have to grow: flags, one 64-bit scan (1-3 launches), assignment
+    // Nothing below depends on a host decision: the slabs are grown for the worst case up front (memory is
+    // not the constraint on a 288 GB device; the voxel counter lives on the device), so the call only
+    // enqueues.  The exact voxel count is read back by whoever needs it (refresh_nvox).
+    if (worst > m->slab_cap && (rc = ensure_slabs(m, worst + worst / 2)) != LOM_OK) return rc;
+    if (!one_pass) {
+        // large batches: flags, one 64-bit scan (1-3 launches), assignment
         if ((rc = ensure(m, m->scr[S_FLAG], (size_t)N * 8)) != LOM_OK) return rc;
         if ((rc = ensure(m, m->scr[S_RANK], (size_t)N * 8)) != LOM_OK) return rc;
         if ((rc = ensure(m, m->scr[S_SCAN], scan_tmp_words(N) * 8)) != LOM_OK) return rc;
@@ -970,16 +892,6 @@ static int add_points_device(lom_map *m, const char *d_xyz, const char *d_nrm, s
         if ((rc = scan_exclusive<unsigned long long>(m, flag64, scan64, N, d_total64,
                                                      (unsigned long long *)m->scr[S_SCAN].p)) != LOM_OK)
             return rc;
-        if (!no_wait) {
-            LOM_HIP(m, hipMemcpyAsync(m->h_flags, d_word(m, 0), 4, hipMemcpyDeviceToHost, m->stream));
-            LOM_HIP(m, hipMemcpyAsync(m->h_flags + 1, d_nvox(m), 4, hipMemcpyDeviceToHost, m->stream));
-            LOM_HIP(m, hipStreamSynchronize(m->stream));
-            n_new = m->h_flags[0];     // low word of the total = number of new voxels
-            m->n_vox = m->h_flags[1];  // exact: every earlier insert has bumped the counter
-            m->n_vox_ub = m->n_vox;
-            m->n_vox_stale = false;
-            if ((rc = ensure_slabs(m, (uint64_t)m->n_vox + n_new)) != LOM_OK) return rc;
-        }
         hipLaunchKernelGGL(k_ins_assign, g, b, 0, m->stream, m->d_table, N, pt_slot, bhead, flag64, scan64, d_nvox(m),
                            m->d_slab_key, boff, bold, seq, words);
     } else {
@@ -991,22 +903,20 @@ static int add_points_device(lom_map *m, const char *d_xyz, const char *d_nrm, s
                        d_xyz, d_nrm, stride, m->K, m->d_pts, m->d_nrm, m->d_slab_count, d_nvox(m), seq, words);
     LOM_HIP(m, hipGetLastError());
     m->table_clean = false;
-    if (no_wait) {
-        m->n_vox_ub = (uint32_t)std::min<uint64_t>(worst, 0xFFFFFFFFull);
-        m->n_vox_stale = true;
-    } else {
-        m->n_vox += n_new;
-        m->n_vox_ub = m->n_vox;
-    }
+    m->n_vox_ub = (uint32_t)std::min<uint64_t>(worst, 0xFFFFFFFFull);
+    m->n_vox_stale = true;
     if (sync_status && !validated_on_host) {
         if ((rc = map_status(m)) != LOM_OK) return rc;
     }
-    if (no_wait) return LOM_OK;
-    // 3. keep the table dense enough to stay cache-resident: load factor in (1/16, 1/2]
-    // (measured on C2/C3: 2 slots per voxel costs the search 5-10 %, 4..16 are equal within noise)
-    const uint32_t target = std::max(m->min_cap, next_pow2(4ull * m->n_vox));
-    if (m->cap > 4 * target) {
-        if ((rc = rehash(m, target)) != LOM_OK) return rc;
+    // keep the table dense enough to stay cache-resident: load factor in (1/16, 1/2] (measured on C2/C3:
+    // 2 slots per voxel costs the search 5-10 %, 4..16 are equal within noise).  Only a batch that made the
+    // table grow far beyond its content (a bulk insert into few voxels) is worth the look at the host.
+    if (N > kOnePassMax && (uint64_t)m->cap >= 16ull * std::max<uint32_t>(m->min_cap, 1u)) {
+        if ((rc = refresh_nvox(m)) != LOM_OK) return rc;
+        const uint32_t target = std::max(m->min_cap, next_pow2(4ull * m->n_vox));
+        if (m->cap > 4 * target) {
+            if ((rc = rehash(m, target)) != LOM_OK) return rc;
+        }
     }
     return LOM_OK;
 }
@@ -1421,7 +1331,7 @@ int64_t lom_map_point_count(const lom_map *cm)
 // wait: read the count and the verdict back (one synchronisation); otherwise the call only enqueues and
 // the count stays on the device (d_word(m, 4)) for the kernels that consume the result.
 static int downsample_core(lom_map *m, float voxel_size, const char *dx, const char *dn, uint32_t N, size_t stride,
-                           bool want_normals, bool wait)
+                           bool want_normals, bool wait, const uint32_t *n_dev = nullptr)
 {
     int rc;
     if ((uint64_t)m->cap < 2ull * N) {
@@ -1437,10 +1347,11 @@ static int downsample_core(lom_map *m, float voxel_size, const char *dx, const c
     const uint32_t seq = ++m->call_seq;
     const MapView v = view_of(m);
     const dim3 g(blocks_for(N)), b(kThreads);
-    hipLaunchKernelGGL(k_ds_claim, g, b, 0, m->stream, m->d_table, v.mask, v.shift, dx, stride, N, voxel_size, pt_slot,
-                       head, seq, d_word(m, 5));
+    if (n_dev && !one_pass) return set_error(m, LOM_ERR_ARG, "device-side point count: at most 65536 points");
+    hipLaunchKernelGGL(k_ds_claim, g, b, 0, m->stream, m->d_table, v.mask, v.shift, dx, stride, N, n_dev, voxel_size,
+                       pt_slot, head, seq, d_word(m, 5));
     if (one_pass) {
-        hipLaunchKernelGGL(k_ds_emit, g, b, 0, m->stream, m->d_table, N, pt_slot, head, dx, dn, stride, oxyz, onrm,
+        hipLaunchKernelGGL(k_ds_emit, g, b, 0, m->stream, m->d_table, N, n_dev, pt_slot, head, dx, dn, stride, oxyz, onrm,
                            d_agg(m), seq, d_word(m, 0));
         LOM_HIP(m, hipGetLastError());
     } else {
@@ -1505,6 +1416,43 @@ int64_t lom_voxel_downsample_device(lom_map *ws, float voxel_size, const float *
     *d_xyz_out = (const float *)m->scr[S_ITEMS].p;
     if (d_nrm_out) *d_nrm_out = (const float *)m->scr[S_PT_POS].p;
     return (int64_t)m->h_flags[0];
+}
+
+int lom_voxel_downsample_device_nowait(lom_map *ws, float voxel_size, const float *d_xyz, const float *d_nrm,
+                                       size_t n_bound, const uint32_t *d_n, size_t stride, const float **d_xyz_out,
+                                       const float **d_nrm_out, const uint32_t **d_count_out)
+{
+    lom_map *m = ws;
+    if (!m || !(voxel_size > 0.f) || (n_bound && !d_xyz) || stride < 12 || (stride & 3) || !d_xyz_out || !d_count_out)
+        return LOM_ERR_ARG;
+    if (n_bound >= 0x7FFFFFFFull) return LOM_ERR_ARG;
+    LOM_HIP(m, hipSetDevice(m->device));
+    *d_xyz_out = nullptr;
+    if (d_nrm_out) *d_nrm_out = nullptr;
+    int rc = lom_map_clear(m, voxel_size);
+    if (rc != LOM_OK) return rc;
+    *d_count_out = d_word(m, 4);
+    if (n_bound == 0) {
+        LOM_HIP(m, hipMemsetAsync(d_word(m, 4), 0, 4, m->stream));
+        return LOM_OK;
+    }
+    if ((rc = downsample_core(m, voxel_size, (const char *)d_xyz, (const char *)d_nrm, (uint32_t)n_bound, stride,
+                              d_nrm_out != nullptr, false, d_n)) != LOM_OK)
+        return rc;
+    *d_xyz_out = (const float *)m->scr[S_ITEMS].p;
+    if (d_nrm_out) *d_nrm_out = (const float *)m->scr[S_PT_POS].p;
+    return LOM_OK;
+}
+
+int lom_map_read_device_words(lom_map *m, const uint32_t *const *d_ptrs, int n, uint32_t *out)
+{
+    if (!m || !d_ptrs || !out || n < 0 || n > 32) return LOM_ERR_ARG;
+    LOM_HIP(m, hipSetDevice(m->device));
+    for (int i = 0; i < n; i++)
+        LOM_HIP(m, hipMemcpyAsync(m->h_flags + i, d_ptrs[i], 4, hipMemcpyDeviceToHost, m->stream));
+    LOM_HIP(m, hipStreamSynchronize(m->stream));
+    for (int i = 0; i < n; i++) out[i] = m->h_flags[i];
+    return LOM_OK;
 }
 
 int lom_upload_points(lom_map *m, const float *xyz, const float *nrm, size_t n, size_t stride, const float **d_xyz_out,
