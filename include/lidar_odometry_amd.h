@@ -138,6 +138,10 @@ int64_t lom_voxel_downsample_device(lom_map *workspace, float voxel_size, const 
 int lom_voxel_downsample_device_nowait(lom_map *workspace, float voxel_size, const float *d_xyz, const float *d_nrm,
                                        size_t n_bound, const uint32_t *d_n, size_t stride_bytes,
                                        const float **d_xyz_out, const float **d_nrm_out, const uint32_t **d_count_out);
+/* for callers that fold a handle's deferred verdict into a read-back of their own: device words that hold the
+ * sequence number of the last call that failed (range / a grid time-out) and the sequence number of the
+ * handle's last call -- a word equal to *seq means that call failed */
+int lom_map_status_words(lom_map *m, const uint32_t **d_range, const uint32_t **d_grid, uint32_t *seq);
 /* one synchronisation for up to 32 device words of any handle on this handle's stream */
 int lom_map_read_device_words(lom_map *m, const uint32_t *const *d_ptrs, int n, uint32_t *out);
 /* lom_transform_points on the device (same f32 arithmetic): packed 12-byte output in the handle's
@@ -252,6 +256,8 @@ int lom_map_set_profiling(lom_map *m, int period);
 int lom_profile_match(lom_map *m, const float *d_src_xyz, size_t n, size_t stride_bytes, const float t[3],
                       const float q_wxyz[4], float max_dist, int reps, double *avg_us_out,
                       double *algorithmic_bytes_out, double *requested_bytes_out);
+/* make the handle's stream wait for a hipEvent_t recorded elsewhere */
+int lom_map_wait_event(lom_map *m, void *hip_event);
 /* run the handle's work on a caller-owned hipStream_t (NULL = handle's own stream) */
 int lom_map_set_stream(lom_map *m, void *hip_stream);
 /* the hipStream_t the handle currently works on (to put several handles on one stream) */
@@ -356,7 +362,16 @@ int lom_frontend_wait(lom_frontend *f, uint32_t counts_out[4]);
 /* host copies: what = 0 the deskewed cloud (lom_point_xyzirt records into out_a), what = 1 the filtered planar
  * cloud (packed xyz into out_a, normals into out_b); returns the number of points available */
 int64_t lom_frontend_fetch(lom_frontend *f, int what, void *out_a, void *out_b, size_t cap);
+/* pinned staging buffer for a frame of n points: a caller that writes the frame there itself (e.g. straight from
+ * its message) passes the same pointer to lom_frontend_process and saves the copy */
+int lom_frontend_stage(lom_frontend *f, size_t n, lom_point_xyzirt **out);
+/* hipEvent_t recorded behind the last frame's kernels; lom_map_wait_event makes a handle's stream wait for it
+ * (the front end runs on a stream of its own, beside the previous frame's keyframe update) */
+void *lom_frontend_done_event(lom_frontend *f);
 void *lom_frontend_stream(lom_frontend *f);
+/* sequence number of the last lom_frontend_process (words [4] / [5] of lom_frontend_results' d_counts hold the
+ * number of the last frame that has to be redone on the host / that hit a grid time-out) */
+uint32_t lom_frontend_sequence(const lom_frontend *f);
 /* test hook: the device's restatement of glibc's sinf (used by the per-point slerp) on n host values */
 int lom_debug_sinf(lom_frontend *f, const float *x, size_t n, float *out);
 
@@ -388,7 +403,8 @@ typedef struct {
 
 typedef struct {
     int64_t planar_points, filtered_points, update_points, matching_points, keyframe_voxels, queries;
-    int32_t outer_iterations, initialised_keyframe, unstable_rotation, pad;
+    int32_t outer_iterations, initialised_keyframe, unstable_rotation;
+    int32_t host_stages; /* 1: the stages before the align ran on the host (LOM_HOST_FRONTEND=1, or a frame the device front end handed back) */
     int64_t queries_total; /* source points x outer iterations of all frames since creation */
 } lom_odometry_frame_stats;
 

@@ -73,7 +73,7 @@ class OdometryFrameStats(C.Structure):
     _fields_ = [("planar_points", C.c_int64), ("filtered_points", C.c_int64), ("update_points", C.c_int64),
                 ("matching_points", C.c_int64), ("keyframe_voxels", C.c_int64), ("queries", C.c_int64),
                 ("outer_iterations", C.c_int32), ("initialised_keyframe", C.c_int32),
-                ("unstable_rotation", C.c_int32), ("pad", C.c_int32), ("queries_total", C.c_int64)]
+                ("unstable_rotation", C.c_int32), ("host_stages", C.c_int32), ("queries_total", C.c_int64)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "pad"}
@@ -110,7 +110,7 @@ EXPORTED = [
     "lom_range_filter", "lom_cloud_classify", "lom_odometry_default_params", "lom_odometry_create",
     "lom_odometry_destroy", "lom_odometry_process_cloud", "lom_odometry_get_pose", "lom_odometry_get_stats", "lom_odometry_get_temp_cloud", "lom_odometry_debug_set_state",
     "lom_odometry_keyframe", "lom_odometry_last_error", "lom_pcd_read", "lom_pcd_last_error", "lom_frontend_create", "lom_frontend_destroy", "lom_frontend_last_error",
-    "lom_frontend_process", "lom_frontend_results", "lom_frontend_wait", "lom_frontend_fetch", "lom_frontend_stream", "lom_debug_sinf",
+    "lom_frontend_process", "lom_frontend_results", "lom_frontend_wait", "lom_frontend_fetch", "lom_frontend_stream", "lom_frontend_stage", "lom_frontend_done_event", "lom_map_wait_event", "lom_frontend_sequence", "lom_map_status_words", "lom_debug_sinf",
     "lom_voxel_downsample_device_nowait", "lom_map_read_device_words",
 ]
 

@@ -399,7 +399,7 @@ struct lom_frontend {
     bool own_stream = false;
     void *h_stage = nullptr;  // pinned bounce buffer for the raw frame
     size_t h_stage_bytes = 0;
-    hipEvent_t stage_ev = nullptr;
+    hipEvent_t stage_ev = nullptr, done_ev = nullptr;
     lom_point_xyzirt *d_in = nullptr, *d_desk = nullptr;
     uint32_t *d_win = nullptr;
     float4 *d_org = nullptr;
@@ -499,7 +499,8 @@ int lom_frontend_create(int device, void *hip_stream, lom_frontend **out)
     if (hipSetDevice(device) != hipSuccess || (hip_stream == nullptr && hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking) != hipSuccess) ||
         hipMalloc((void **)&f->d_stats, 2 * sizeof(FeStats)) != hipSuccess || hipMalloc((void **)&f->d_words, wbytes) != hipSuccess ||
         hipHostMalloc((void **)&f->h_words, 64 * 4, hipHostMallocDefault) != hipSuccess ||
-        hipEventCreateWithFlags(&f->stage_ev, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&f->stage_ev, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&f->done_ev, hipEventDisableTiming) != hipSuccess) {
         (void)hipGetLastError();
         lom_frontend_destroy(f);
         return LOM_ERR_HIP;
@@ -532,6 +533,7 @@ void lom_frontend_destroy(lom_frontend *f)
     if (f->h_stage) (void)hipHostFree(f->h_stage);
     if (f->h_words) (void)hipHostFree(f->h_words);
     if (f->stage_ev) (void)hipEventDestroy(f->stage_ev);
+    if (f->done_ev) (void)hipEventDestroy(f->done_ev);
     if (f->own_stream && f->stream) (void)hipStreamDestroy(f->stream);
     delete f;
 }
@@ -550,21 +552,15 @@ int lom_frontend_process(lom_frontend *f, const lom_point_xyzirt *pts, size_t n,
     const uint32_t N = (uint32_t)n;
     const uint32_t seq = ++f->seq;
     f->n_last = N;
-    // raw frame -> pinned bounce buffer -> HBM (the caller's buffer is free when this returns)
+    // raw frame -> pinned bounce buffer -> HBM (the caller's buffer is free when this returns); a caller that
+    // has written the frame into lom_frontend_stage()'s buffer itself passes that pointer and skips the copy
     const size_t bytes = n * sizeof(lom_point_xyzirt);
-    FE_HIP(f, hipEventSynchronize(f->stage_ev));
-    if (bytes > f->h_stage_bytes) {
-        if (f->h_stage) FE_HIP(f, hipHostFree(f->h_stage));
-        f->h_stage = nullptr;
-        f->h_stage_bytes = 0;
-        const size_t nb = std::max(bytes + bytes / 2, (size_t)1 << 20);
-        FE_HIP(f, hipHostMalloc(&f->h_stage, nb, hipHostMallocDefault));
-        f->h_stage_bytes = nb;
+    if (static_cast<const void *>(pts) != f->h_stage || bytes > f->h_stage_bytes) {
+        lom_point_xyzirt *stage = nullptr;
+        if ((rc = lom_frontend_stage(f, n, &stage)) != LOM_OK) return rc;
+        if (bytes) std::memcpy(static_cast<void *>(stage), pts, bytes);
     }
-    if (bytes) {
-        std::memcpy(f->h_stage, pts, bytes);
-        FE_HIP(f, hipMemcpyAsync(f->d_in, f->h_stage, bytes, hipMemcpyHostToDevice, f->stream));
-    }
+    if (bytes) FE_HIP(f, hipMemcpyAsync(f->d_in, f->h_stage, bytes, hipMemcpyHostToDevice, f->stream));
     FE_HIP(f, hipEventRecord(f->stage_ev, f->stream));
     FrameConst F;
     frame_const(*start, *end, min_range, max_range, F);
@@ -582,8 +578,32 @@ int lom_frontend_process(lom_frontend *f, const lom_point_xyzirt *pts, size_t n,
     hipLaunchKernelGGL(k_fe_planar, dim3(blocks_for((cells_bound + kFeItems - 1) / kFeItems)), dim3(kThreads), 0, f->stream,
                        f->d_org, f->d_win, cells_bound, F, f->d_xyz, f->d_nrm, fe_agg(f), seq, f->d_words);
     FE_HIP(f, hipGetLastError());
+    FE_HIP(f, hipEventRecord(f->done_ev, f->stream));
     return LOM_OK;
 }
+
+// pinned staging buffer for a frame of n points (valid until the next lom_frontend_stage / process of a larger
+// frame); waits until the previous frame's upload has read it
+int lom_frontend_stage(lom_frontend *f, size_t n, lom_point_xyzirt **out)
+{
+    if (!f || !out) return LOM_ERR_ARG;
+    FE_HIP(f, hipSetDevice(f->device));
+    const size_t bytes = n * sizeof(lom_point_xyzirt);
+    FE_HIP(f, hipEventSynchronize(f->stage_ev));
+    if (bytes > f->h_stage_bytes) {
+        if (f->h_stage) FE_HIP(f, hipHostFree(f->h_stage));
+        f->h_stage = nullptr;
+        f->h_stage_bytes = 0;
+        const size_t nb = std::max(bytes + bytes / 2, (size_t)1 << 20);
+        FE_HIP(f, hipHostMalloc(&f->h_stage, nb, hipHostMallocDefault));
+        f->h_stage_bytes = nb;
+    }
+    *out = static_cast<lom_point_xyzirt *>(f->h_stage);
+    return LOM_OK;
+}
+
+// hipEvent_t recorded behind the last frame's kernels: a consumer on another stream waits for it
+void *lom_frontend_done_event(lom_frontend *f) { return f ? (void *)f->done_ev : nullptr; }
 
 // device-side results of the last lom_frontend_process: the filtered planar cloud (packed xyz, normals),
 // an upper bound of its size known to the host, and the words {planar, filtered, H, W, fall-back, error}
@@ -599,6 +619,7 @@ int lom_frontend_results(lom_frontend *f, const float **d_xyz, const float **d_n
 }
 
 void *lom_frontend_stream(lom_frontend *f) { return f ? (void *)f->stream : nullptr; }
+uint32_t lom_frontend_sequence(const lom_frontend *f) { return f ? f->seq : 0u; }
 
 // test hook: the device's restatement of glibc's sinf on n host values
 int lom_debug_sinf(lom_frontend *f, const float *x, size_t n, float *out)

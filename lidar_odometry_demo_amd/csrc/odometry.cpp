@@ -498,6 +498,8 @@ struct lom_odometry {
     lom_pose previous, current;        // lidar_odometry.h:84-85
     lom_odometry_frame_stats last{};
     std::vector<lom_point_xyzirt> normalized, deskewed;
+    lom_frontend *frontend = nullptr;  // :25-35 on the device (csrc/frontend.hip); LOM_HOST_FRONTEND=1 keeps them on the host
+    bool temp_on_device = false;       // temp_cloud_ lives in the front end's HBM buffer
     bool keyframe_has_voxels = false;  // keyframe_.size() != 0 (lidar_odometry.cpp:40), tracked on the host
     size_t temp_points = 0;  // temp_cloud_ (lidar_odometry.h:73-77) = the first temp_points records of `deskewed`
     ClassifyScratch classify_scratch;
@@ -576,6 +578,7 @@ int lom_odometry_create(const lom_odometry_params *params, int device, lom_odome
     // the keyframe update, each step consuming the previous one's device buffers in stream order
     if (rc == LOM_OK) rc = lom_map_set_stream(o->update_ds, lom_map_get_stream(o->keyframe));
     if (rc == LOM_OK) rc = lom_map_set_stream(o->matching_ds, lom_map_get_stream(o->keyframe));
+    if (rc == LOM_OK && !getenv("LOM_HOST_FRONTEND")) rc = lom_frontend_create(device, nullptr, &o->frontend);
     if (rc != LOM_OK) {
         lom_odometry_destroy(o);
         return rc;
@@ -589,7 +592,8 @@ void lom_odometry_destroy(lom_odometry *o)
     if (!o) return;
     (void)o->settle();
     o->deferred.reset();
-    lom_map_destroy(o->update_ds);  // the down-samplers run on the keyframe handle's stream: they go first
+    lom_frontend_destroy(o->frontend);  // the front end and the down-samplers run on the keyframe handle's stream: they go first
+    lom_map_destroy(o->update_ds);
     lom_map_destroy(o->matching_ds);
     lom_map_destroy(o->keyframe);
     delete o;
@@ -615,6 +619,7 @@ int64_t lom_odometry_get_temp_cloud(const lom_odometry *o, lom_point_xyzirt *out
 {
     if (!o || (cap && !out)) return LOM_ERR_ARG;
     const size_t n = o->temp_points;
+    if (o->temp_on_device) return lom_frontend_fetch(o->frontend, 0, out, nullptr, cap);
     if (out && cap) std::memcpy(static_cast<void *>(out), o->deskewed.data(), std::min(n, cap) * sizeof(lom_point_xyzirt));
     return (int64_t)n;
 }
@@ -639,22 +644,152 @@ int lom_odometry_get_stats(const lom_odometry *o, lom_odometry_frame_stats *out)
     return rc;
 }
 
-// LidarOdometry::processCloud, lidar_odometry.cpp:22-77
+}  // extern "C" (the C ABI continues below)
+
+// ---- LidarOdometry::processCloud, lidar_odometry.cpp:22-77 ---------------------------------------
+namespace {
+
+struct FrameInputs {  // what the stages before the align leave in HBM for it and for the keyframe update
+    const float *d_down = nullptr, *d_down_n = nullptr;  // keyframe_downsampler.getCloud()            :37-38,42,69
+    const float *d_match = nullptr;                      // matching_downsampler.getCloudWithoutNormals() :46-47,50
+    int64_t nd = 0, nm = 0;
+};
+
+int fail_map(lom_odometry *o, int rc, lom_map *m)
+{
+    o->error = lom_last_error(m);
+    return rc;
+}
+
+// :25-47 on the host (worker pool), then one upload: the path of frames the device front end hands back
+int stages_on_host(lom_odometry *o, const lom_point_xyzirt *pts, size_t n, const lom_pose &rel_inv, const lom_pose &ident,
+                   lom_odometry_frame_stats &cur, FrameInputs &in, StageTimer &tm)
+{
+    const size_t cap = n ? n : 1;
+    o->normalized.resize(cap);
+    o->deskewed.resize(cap);
+    for (auto *v : {&o->planar, &o->planar_n, &o->filtered, &o->filtered_n}) v->resize(cap * 3);
+    time_normalize(pts, n, o->normalized.data(), o->pool.get());                                      // :25
+    transform_non_rigid(o->normalized.data(), n, rel_inv, ident, o->deskewed.data(), o->pool.get());  // :30
+    o->temp_points = n;  // :31 temp_cloud_ = deskewed_input_cloud
+    o->temp_on_device = false;
+    tm.lap("norm+deskew");
+    size_t nu = 0;
+    const size_t np = classify(o->deskewed.data(), n, o->planar.data(), o->planar_n.data(), &nu, nullptr,
+                               o->classify_scratch, o->pool.get());  // :33
+    const size_t nf = range_filter(o->planar.data(), o->planar_n.data(), np, o->cfg.lidar_min_range,
+                                   o->cfg.lidar_max_range, o->filtered.data(), o->filtered_n.data(), o->pool.get());  // :35
+    cur.planar_points = (int64_t)np;
+    cur.filtered_points = (int64_t)nf;
+    tm.lap("classify+filter");
+    int rc;
+    // the previous frame's keyframe update ran beside the host stages above; it must be through before this
+    // frame touches a handle.  Its failure is reported here, by the call after the one it belongs to; this
+    // frame is then not processed and poses / keyframe stay as they were.
+    if ((rc = o->settle()) != LOM_OK) return rc;
+    const float *d_fx = nullptr, *d_fn = nullptr;
+    if ((rc = lom_upload_points(o->update_ds, o->filtered.data(), o->filtered_n.data(), nf, 12, &d_fx, &d_fn)) != LOM_OK)
+        return fail_map(o, rc, o->update_ds);
+    in.nd = lom_voxel_downsample_device(o->update_ds, o->cfg.keyframe_update_voxel_size, d_fx, d_fn, nf, 12, &in.d_down,
+                                        &in.d_down_n);
+    if (in.nd < 0) return fail_map(o, (int)in.nd, o->update_ds);
+    if (o->keyframe_has_voxels) {
+        in.nm = lom_voxel_downsample_device(o->matching_ds, o->cfg.keyframe_matching_voxel_size, d_fx, nullptr, nf, 12,
+                                            &in.d_match, nullptr);
+        if (in.nm < 0) return fail_map(o, (int)in.nm, o->matching_ds);
+    }
+    tm.lap("down-samplers");
+    return LOM_OK;
+}
+
+// :25-47 on the device: the frame stays in HBM from its upload to its pose.  Front end (4 kernels), both
+// down-samplers (2 kernels each) fed with device-side counts, then ONE look at the host for the sizes the
+// align and the keyframe update are launched with.  Returns 1 when the front end hands the frame back.
+int stages_on_device(lom_odometry *o, const lom_point_xyzirt *pts, size_t n, const lom_pose &rel_inv, const lom_pose &ident,
+                     lom_odometry_frame_stats &cur, FrameInputs &in, StageTimer &tm)
+{
+    int rc;
+    // the frame goes into the front end's pinned buffer by the worker pool (one pass over ~1 MB), then to HBM
+    lom_point_xyzirt *stage = nullptr;
+    if ((rc = lom_frontend_stage(o->frontend, n, &stage)) != LOM_OK) {
+        o->error = lom_frontend_last_error(o->frontend);
+        return rc;
+    }
+    run_parts(o->pool.get(), n, [&](size_t b, size_t e, unsigned) {
+        std::memcpy(static_cast<void *>(stage + b), pts + b, (e - b) * sizeof(lom_point_xyzirt));
+    }, 8192);
+    if ((rc = lom_frontend_process(o->frontend, stage, n, &rel_inv, &ident, o->cfg.lidar_min_range, o->cfg.lidar_max_range)) !=
+        LOM_OK) {
+        if (rc == LOM_ERR_ARG) return 1;  // a frame beyond the front end's size limit
+        o->error = lom_frontend_last_error(o->frontend);
+        return rc;
+    }
+    o->temp_points = n;  // :31 temp_cloud_ = deskewed_input_cloud (fetched from HBM on demand)
+    o->temp_on_device = true;
+    tm.lap("front end enq.");
+    if ((rc = o->settle()) != LOM_OK) return rc;  // as in stages_on_host
+    const float *d_fx = nullptr, *d_fn = nullptr;
+    const uint32_t *d_fe = nullptr, *d_nd = nullptr, *d_nm = nullptr;
+    uint32_t bound = 0;
+    lom_frontend_results(o->frontend, &d_fx, &d_fn, &d_fe, &bound);
+    // the front end ran on its own stream, beside the previous frame's keyframe update; the handles' stream
+    // takes over from here
+    if ((rc = lom_map_wait_event(o->keyframe, lom_frontend_done_event(o->frontend))) != LOM_OK) return fail_map(o, rc, o->keyframe);
+    if ((rc = lom_voxel_downsample_device_nowait(o->update_ds, o->cfg.keyframe_update_voxel_size, d_fx, d_fn, bound, d_fe + 1,
+                                                 12, &in.d_down, &in.d_down_n, &d_nd)) != LOM_OK)
+        return fail_map(o, rc, o->update_ds);
+    if (o->keyframe_has_voxels &&
+        (rc = lom_voxel_downsample_device_nowait(o->matching_ds, o->cfg.keyframe_matching_voxel_size, d_fx, nullptr, bound,
+                                                 d_fe + 1, 12, &in.d_match, nullptr, &d_nm)) != LOM_OK)
+        return fail_map(o, rc, o->matching_ds);
+    // the one synchronisation before the align: counts and verdicts of everything enqueued above
+    const uint32_t *ptrs[12];
+    uint32_t seq_u = 0, seq_m = 0, got[12];
+    const uint32_t *u_range = nullptr, *u_grid = nullptr, *m_range = nullptr, *m_grid = nullptr;
+    lom_map_status_words(o->update_ds, &u_range, &u_grid, &seq_u);
+    lom_map_status_words(o->matching_ds, &m_range, &m_grid, &seq_m);
+    int k = 0;
+    ptrs[k++] = d_fe;      // 0 planar
+    ptrs[k++] = d_fe + 1;  // 1 filtered
+    ptrs[k++] = d_fe + 4;  // 2 front end: redo on the host (sequence number of the frame)
+    ptrs[k++] = d_fe + 5;  // 3 front end: grid error
+    ptrs[k++] = d_nd;      // 4
+    ptrs[k++] = u_range;   // 5
+    ptrs[k++] = u_grid;    // 6
+    if (d_nm) {
+        ptrs[k++] = d_nm;     // 7
+        ptrs[k++] = m_range;  // 8
+        ptrs[k++] = m_grid;   // 9
+    }
+    if ((rc = lom_map_read_device_words(o->keyframe, ptrs, k, got)) != LOM_OK) return fail_map(o, rc, o->keyframe);
+    tm.lap("stages (device)");
+    const uint32_t fe_seq = lom_frontend_sequence(o->frontend);
+    if (got[3] == fe_seq || got[6] == seq_u || (d_nm && got[9] == seq_m)) {
+        o->error = "a workgroup timed out waiting for the others of its grid";
+        return LOM_ERR_HIP;
+    }
+    if (got[2] == fe_seq) return 1;  // an azimuth on a bin boundary, or an organised cloud beyond the buffers
+    if (got[5] == seq_u || (d_nm && got[8] == seq_m)) {
+        o->error = "coordinate / voxel_size out of range or not finite";
+        return LOM_ERR_RANGE;
+    }
+    cur.planar_points = got[0];
+    cur.filtered_points = got[1];
+    in.nd = got[4];
+    in.nm = d_nm ? got[7] : 0;
+    return LOM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
 int lom_odometry_process_cloud(lom_odometry *o, const lom_point_xyzirt *pts, size_t n)
 {
     if (!o || (!pts && n)) return LOM_ERR_ARG;
-    auto fail = [o](int rc, lom_map *m) {
-        o->error = lom_last_error(m);
-        return rc;
-    };
     try {
         lom_odometry_frame_stats cur{};  // becomes o->last when the frame is through
         StageTimer tm;
-        const size_t cap = n ? n : 1;
-        o->normalized.resize(cap);
-        o->deskewed.resize(cap);
-        for (auto *v : {&o->planar, &o->planar_n, &o->filtered, &o->filtered_n}) v->resize(cap * 3);
-        time_normalize(pts, n, o->normalized.data(), o->pool.get());  // :25
         lom_pose relative, rel_inv, ident, guess, result;
         lom_pose_relative_to(&o->previous, &o->current, &relative);  // :27
         // :28 previous_transform_ = current_transform_ -- committed where the frame succeeds (the
@@ -663,42 +798,21 @@ int lom_odometry_process_cloud(lom_odometry *o, const lom_point_xyzirt *pts, siz
         const lom_pose previous_next = o->current;
         lom::pose_inverse(relative, rel_inv);
         lom_pose_identity(&ident);
-        transform_non_rigid(o->normalized.data(), n, rel_inv, ident, o->deskewed.data(), o->pool.get());  // :30
-        o->temp_points = n;  // :31 temp_cloud_ = deskewed_input_cloud
-        tm.lap("norm+deskew");
-        size_t nu = 0;
-        const size_t np = classify(o->deskewed.data(), n, o->planar.data(), o->planar_n.data(), &nu, nullptr,
-                                   o->classify_scratch, o->pool.get());  // :33
-        const size_t nf = range_filter(o->planar.data(), o->planar_n.data(), np, o->cfg.lidar_min_range,
-                                       o->cfg.lidar_max_range, o->filtered.data(), o->filtered_n.data(),
-                                       o->pool.get());  // :35
-        cur.planar_points = (int64_t)np;
-        cur.filtered_points = (int64_t)nf;
-        tm.lap("classify+filter");
-        int rc;
-        // the previous frame's keyframe update ran beside the host stages above; it must be through
-        // before this frame touches a handle.  Its failure is reported here, by the call after the one
-        // it belongs to; this frame is then not processed and poses / keyframe stay as they were.
-        if ((rc = o->settle()) != LOM_OK) return rc;
-        tm.lap("settle");
-        // From here on the frame lives in HBM: one upload of the filtered cloud, both down-samplers,
-        // the align, the rigid transform and the keyframe update consume device buffers in stream order.
-        const float *d_fx = nullptr, *d_fn = nullptr;
-        if ((rc = lom_upload_points(o->update_ds, o->filtered.data(), o->filtered_n.data(), nf, 12, &d_fx, &d_fn)) !=
-            LOM_OK)
-            return fail(rc, o->update_ds);
-        // VoxelGrid keyframe_downsampler(update_voxel_size, 1); addCloud(filtered); getCloud()   :37-38,42,69
-        const float *d_down = nullptr, *d_down_n = nullptr;
-        const int64_t nd = lom_voxel_downsample_device(o->update_ds, o->cfg.keyframe_update_voxel_size, d_fx, d_fn, nf,
-                                                       12, &d_down, &d_down_n);
-        if (nd < 0) return fail((int)nd, o->update_ds);
-        cur.update_points = nd;
-        tm.lap("update_ds");
+        FrameInputs in;
+        int rc = 1;
+        if (o->frontend) rc = stages_on_device(o, pts, n, rel_inv, ident, cur, in, tm);
+        if (rc == 1) {
+            in = FrameInputs();
+            rc = stages_on_host(o, pts, n, rel_inv, ident, cur, in, tm);
+            cur.host_stages = 1;
+        }
+        if (rc != LOM_OK) return rc;
+        cur.update_points = in.nd;
         // :40 keyframe_.size() == 0 -- known on the host: the keyframe is empty until a frame has put voxels
         // into it (nd > 0 points always create at least one), and stays non-empty unless a cleanup empties it
         if (!o->keyframe_has_voxels) {  // :40-44 init keyframe
-            if ((rc = lom_map_add_points_device(o->keyframe, d_down, d_down_n, (size_t)nd, 12)) != LOM_OK)
-                return fail(rc, o->keyframe);
+            if ((rc = lom_map_add_points_device(o->keyframe, in.d_down, in.d_down_n, (size_t)in.nd, 12)) != LOM_OK)
+                return fail_map(o, rc, o->keyframe);
             cur.initialised_keyframe = 1;
             cur.keyframe_voxels = lom_map_size(o->keyframe);
             o->keyframe_has_voxels = cur.keyframe_voxels > 0;
@@ -706,18 +820,12 @@ int lom_odometry_process_cloud(lom_odometry *o, const lom_point_xyzirt *pts, siz
             o->previous = previous_next;  // :28
             return LOM_OK;
         }
-        // VoxelGrid matching_downsampler(matching_voxel_size, 1); addCloud(filtered); getCloudWithoutNormals()   :46-47,50
-        const float *d_match = nullptr;
-        const int64_t nm = lom_voxel_downsample_device(o->matching_ds, o->cfg.keyframe_matching_voxel_size, d_fx,
-                                                       nullptr, nf, 12, &d_match, nullptr);
-        if (nm < 0) return fail((int)nm, o->matching_ds);
-        cur.matching_points = nm;
-        tm.lap("matching_ds");
+        cur.matching_points = in.nm;
         lom_pose_compose(&o->current, &relative, &guess);  // :51
         lom_align_stats ast;
-        if ((rc = lom_match_align_device(o->keyframe, d_match, (size_t)nm, 12, guess.t, guess.q, result.t, result.q,
+        if ((rc = lom_match_align_device(o->keyframe, in.d_match, (size_t)in.nm, 12, guess.t, guess.q, result.t, result.q,
                                          &ast)) != LOM_OK)  // :49-51
-            return fail(rc, o->keyframe);
+            return fail_map(o, rc, o->keyframe);
         cur.outer_iterations = ast.outer_iterations;
         cur.queries = ast.queries;
         o->queries_total += ast.queries;
@@ -739,7 +847,8 @@ int lom_odometry_process_cloud(lom_odometry *o, const lom_point_xyzirt *pts, siz
         o->last = cur;
         // keyframe update (:67-70): same calls in the same order, on the helper thread when there is one
         const lom_pose pose_now = o->current;
-        const size_t n_down = (size_t)nd;
+        const size_t n_down = (size_t)in.nd;
+        const float *d_down = in.d_down, *d_down_n = in.d_down_n;
         auto update = [o, pose_now, d_down, d_down_n, n_down]() -> int {
             auto bad = [o](int rc, lom_map *m) {
                 o->deferred_error = lom_last_error(m);

@@ -1444,6 +1444,24 @@ int lom_voxel_downsample_device_nowait(lom_map *ws, float voxel_size, const floa
     return LOM_OK;
 }
 
+int lom_map_wait_event(lom_map *m, void *hip_event)
+{
+    if (!m || !hip_event) return LOM_ERR_ARG;
+    LOM_HIP(m, hipSetDevice(m->device));
+    LOM_HIP(m, hipStreamWaitEvent(m->stream, (hipEvent_t)hip_event, 0));
+    return LOM_OK;
+}
+
+int lom_map_status_words(lom_map *m, const uint32_t **d_range, const uint32_t **d_grid, uint32_t *seq)
+{
+    if (!m || !d_range || !d_grid || !seq) return LOM_ERR_ARG;
+    *d_range = d_word(m, 5);
+    *d_grid = d_word(m, 7);
+    *seq = m->call_seq;
+    m->status_seq = m->call_seq;  // the caller looks at the words itself
+    return LOM_OK;
+}
+
 int lom_map_read_device_words(lom_map *m, const uint32_t *const *d_ptrs, int n, uint32_t *out)
 {
     if (!m || !d_ptrs || !out || n < 0 || n > 32) return LOM_ERR_ARG;

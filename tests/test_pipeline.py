@@ -195,3 +195,28 @@ def test_get_temp_cloud(lom, oracle):
     assert t0.tobytes() == want.tobytes()
     g.processCloud(f1)
     assert len(g.getTempCloud()) == len(f1)
+
+
+@pytest.mark.gpu
+def test_device_stages_equal_host_stages(lom, monkeypatch):
+    """processCloud with the stages before the align on the device (default) and on the host
+    (LOM_HOST_FRONTEND=1): same counts and the same pose bits, frame after frame; getTempCloud agrees."""
+    boxes = synth.make_boxes()
+    dev = lom.LidarOdometry()
+    monkeypatch.setenv("LOM_HOST_FRONTEND", "1")
+    host = lom.LidarOdometry()
+    monkeypatch.delenv("LOM_HOST_FRONTEND")
+    for k in range(25):
+        f = synth.make_sequence_frame(k, boxes=boxes)
+        dev.processCloud(f)
+        host.processCloud(f)
+        ds, hs = dev.stats, host.stats
+        assert ds["host_stages"] == 0 and hs["host_stages"] == 1
+        for key in ("planar_points", "filtered_points", "update_points", "matching_points", "outer_iterations",
+                    "queries", "keyframe_voxels", "unstable_rotation"):
+            assert ds[key] == hs[key], (k, key)
+        pd, ph = dev.getCurrentPose(), host.getCurrentPose()
+        assert pd.translation.tobytes() == ph.translation.tobytes() and pd.rotation.tobytes() == ph.rotation.tobytes(), k
+        if k in (0, 7):
+            assert dev.getTempCloud().tobytes() == host.getTempCloud().tobytes()
+    assert dev.getFullKeyFrameCloud().tobytes() == host.getFullKeyFrameCloud().tobytes()
