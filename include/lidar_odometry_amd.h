@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define LOM_ABI_VERSION 1
+#define LOM_ABI_VERSION 2
 
 typedef enum {
     LOM_OK = 0,
@@ -194,6 +194,8 @@ typedef struct {
     int32_t host_fallback;     /* 1: the device-resident loop gave up (its workgroups were not all
                                   resident in time) and the align was redone by the host-driven loop */
     int32_t reserved;
+    double lm_kernel_ms;          /* HIP-event time of the k_lm launches of the device-resident loop (profiling on) */
+    int64_t lm_profiled_launches; /* k_lm launches that carried the events                                        */
 } lom_align_stats;
 
 /* Replaces CloudMatcher::align (cloud_matcher.h:15-16): up to 35 outer iterations of
@@ -252,10 +254,16 @@ int lom_map_set_profiling(lom_map *m, int period);
  * packet overhead is amortised.  Returns the average launch duration in microseconds and the
  * algorithmic bytes of one launch (SURVEY.md 8d formula, counted by the kernel), and optionally the
  * bytes the kernel itself requests (candidates of pruned voxels are not read; + 52 B of output per
- * query). */
+ * query).  pair_avg_us_out (optional): the average of the same launches bracketed by one event pair EACH --
+ * minus avg_us_out that is what an event pair adds to one short kernel, the correction for the sampled
+ * in-loop measurement of lom_match_align*. */
 int lom_profile_match(lom_map *m, const float *d_src_xyz, size_t n, size_t stride_bytes, const float t[3],
                       const float q_wxyz[4], float max_dist, int reps, double *avg_us_out,
-                      double *algorithmic_bytes_out, double *requested_bytes_out);
+                      double *algorithmic_bytes_out, double *requested_bytes_out, double *pair_avg_us_out);
+/* Roofline probe for the insert chain: lom_map_add_points_device bracketed by one HIP event pair on the handle's
+ * stream (all kernels of the insert, no host wait in between); microseconds from the first kernel to the last. */
+int lom_profile_insert(lom_map *m, const float *d_xyz, const float *d_nrm, size_t n, size_t stride_bytes,
+                       double *total_us_out);
 /* make the handle's stream wait for a hipEvent_t recorded elsewhere */
 int lom_map_wait_event(lom_map *m, void *hip_event);
 /* run the handle's work on a caller-owned hipStream_t (NULL = handle's own stream) */

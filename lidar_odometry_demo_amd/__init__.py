@@ -180,14 +180,22 @@ class VoxelGrid:
         return c[0]
 
     def profileMatch(self, d_src_ptr, n, transform, max_correspondence_distance=0.3, reps=20, stride_bytes=12):
-        """(average k_match launch duration [us], algorithmic bytes per launch, bytes the kernel requests
-        per launch) over a back-to-back train."""
-        us, by, rq = C.c_double(), C.c_double(), C.c_double()
+        """(average k_match launch duration [us] over a back-to-back train under one event pair, algorithmic
+        bytes per launch, bytes the kernel requests per launch, average of the same launches with one event
+        pair each [us])."""
+        us, by, rq, pr = C.c_double(), C.c_double(), C.c_double(), C.c_double()
         capi.check(capi.lib().lom_profile_match(
             self._h, d_src_ptr, int(n), int(stride_bytes), capi.f3(transform.translation),
             capi.f4(transform.rotation), float(max_correspondence_distance), int(reps), C.byref(us), C.byref(by),
-            C.byref(rq)), self._h)
-        return us.value, by.value, rq.value
+            C.byref(rq), C.byref(pr)), self._h)
+        return us.value, by.value, rq.value, pr.value
+
+    def profileInsert(self, d_xyz_ptr, d_nrm_ptr, n, stride_bytes=12):
+        """addCloud of device-resident points, all kernels of the insert under one HIP event pair: microseconds."""
+        us = C.c_double()
+        capi.check(capi.lib().lom_profile_insert(self._h, d_xyz_ptr, d_nrm_ptr, int(n), int(stride_bytes), C.byref(us)),
+                   self._h)
+        return us.value
 
     def setProfiling(self, period):
         """HIP event pairs around the correspondence launches of every `period`-th align (True = 1, False = 0)."""

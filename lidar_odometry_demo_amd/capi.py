@@ -50,6 +50,7 @@ class AlignStats(C.Structure):
         ("last_step_norm", C.c_double), ("match_kernel_ms", C.c_double),
         ("algorithmic_bytes", C.c_double), ("host_launch_ms", C.c_double), ("host_wait_ms", C.c_double),
         ("profiled_launches", C.c_int64), ("host_fallback", C.c_int32), ("reserved", C.c_int32),
+        ("lm_kernel_ms", C.c_double), ("lm_profiled_launches", C.c_int64),
     ]
 
     def asdict(self):
@@ -104,7 +105,7 @@ EXPORTED = [
     "lom_map_add_points_device", "lom_map_add_points_device_nowait", "lom_map_status", "lom_map_radius_cleanup", "lom_map_size", "lom_map_point_count",
     "lom_map_export", "lom_voxel_downsample", "lom_voxel_downsample_device", "lom_upload_points",
     "lom_transform_points_device", "lom_map_get_stream", "lom_match_find_pairs", "lom_match_align", "lom_match_align_device", "lom_match_align_repeat", "lom_debug_match_stamps", "lom_debug_eval_sums", "lom_debug_lm_trace",
-    "lom_map_set_profiling", "lom_profile_match", "lom_map_set_stream", "lom_comm_unique_id", "lom_comm_init",
+    "lom_map_set_profiling", "lom_profile_match", "lom_profile_insert", "lom_map_set_stream", "lom_comm_unique_id", "lom_comm_init",
     "lom_comm_finalize", "lom_comm_host_id", "lom_host_comm_create", "lom_host_comm_allreduce",
     "lom_host_comm_destroy", "lom_host_comm_allgather", "lom_comm_attach_host", "lom_comm_attach_p2p", "lom_align_with_hooks", "lom_point_time_normalize", "lom_transform_non_rigid",
     "lom_range_filter", "lom_cloud_classify", "lom_odometry_default_params", "lom_odometry_create",
@@ -200,7 +201,8 @@ def lib():
                                      C.POINTER(AlignStats)]
     L.lom_map_set_profiling.argtypes = [vp, C.c_int]
     L.lom_map_set_stream.argtypes = [vp, vp]
-    L.lom_profile_match.argtypes = [vp, vp, C.c_size_t, C.c_size_t, fp, fp, C.c_float, C.c_int, dp, dp, dp]
+    L.lom_profile_match.argtypes = [vp, vp, C.c_size_t, C.c_size_t, fp, fp, C.c_float, C.c_int, dp, dp, dp, dp]
+    L.lom_profile_insert.argtypes = [vp, vp, vp, C.c_size_t, C.c_size_t, dp]
     L.lom_comm_unique_id.argtypes = [C.c_char_p]
     L.lom_comm_init.argtypes = [vp, C.c_int, C.c_int, C.c_char_p]
     L.lom_comm_finalize.argtypes = [vp]

@@ -1584,14 +1584,14 @@ static int launch_match(ScanCtx &c, const float t[3], const float q[4], float ma
     if (c.n) {
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (m->profiling) {
-            // one event pair per launch, read back once at the end of the align
-            while (m->prof_events.size() < (size_t)(c.prof_used + 1) * 2) {
+            // three events per (k_match, k_lm) pair -- before, between, behind --, read back once at the end of the align
+            while (m->prof_events.size() < (size_t)(c.prof_used + 1) * 3) {
                 hipEvent_t e;
                 LOM_HIP(m, hipEventCreate(&e));
                 m->prof_events.push_back(e);
             }
-            e0 = m->prof_events[(size_t)c.prof_used * 2];
-            e1 = m->prof_events[(size_t)c.prof_used * 2 + 1];
+            e0 = m->prof_events[(size_t)c.prof_used * 3];
+            e1 = m->prof_events[(size_t)c.prof_used * 3 + 1];
             c.prof_used++;
             LOM_HIP(m, hipEventRecord(e0, m->stream));
         }
@@ -1877,6 +1877,7 @@ static int align_chained(lom_map *m, const char *d_src, size_t n, size_t stride,
         dbg = (unsigned long long *)m->dbg_stamps.p;
         LOM_HIP(m, hipMemsetAsync(dbg, 0, 40 * 8, m->stream));
     }
+    int lm_events = 0;
     auto launch_pair = [&]() -> int {
         const int i = launched;
         int r = launch_match(c, guess_t, guess_q, 0.3f, false, i > 0);
@@ -1890,6 +1891,10 @@ static int align_chained(lom_map *m, const char *d_src, size_t n, size_t stride,
                            reinterpret_cast<AlignReport *>(m->d_report), seq0 + (unsigned long long)i + 1,
                            server_timeout_ticks(), dbg, px, (d_trace && i == trace_outer) ? d_trace : (double *)nullptr);
         LOM_HIP(m, hipGetLastError());
+        if (m->profiling && c.prof_used) {
+            LOM_HIP(m, hipEventRecord(m->prof_events[(size_t)(c.prof_used - 1) * 3 + 2], m->stream));
+            lm_events++;
+        }
         c.launch_s += now_s() - t_l;
         launched++;
         return LOM_OK;
@@ -1951,12 +1956,18 @@ static int align_chained(lom_map *m, const char *d_src, size_t n, size_t stride,
     for (int a = 0; a < 4; a++) out_q[a] = pq[a];
     if (m->profiling && c.prof_used) {
         LOM_HIP(m, hipStreamSynchronize(m->stream));
-        for (int i = 0; i < c.prof_used; i++) {
+        // kernels enqueued beyond the end of the loop return at once: only the executed iterations count
+        const int executed = std::min(c.prof_used, (int)rp->outer_done);
+        for (int i = 0; i < executed; i++) {
             float ms = 0.f;
-            if (hipEventElapsedTime(&ms, m->prof_events[(size_t)i * 2], m->prof_events[(size_t)i * 2 + 1]) == hipSuccess)
+            if (hipEventElapsedTime(&ms, m->prof_events[(size_t)i * 3], m->prof_events[(size_t)i * 3 + 1]) == hipSuccess)
                 st.match_kernel_ms += ms;
+            if (i < lm_events &&
+                hipEventElapsedTime(&ms, m->prof_events[(size_t)i * 3 + 1], m->prof_events[(size_t)i * 3 + 2]) == hipSuccess)
+                st.lm_kernel_ms += ms;
         }
-        st.profiled_launches = c.prof_used;
+        st.profiled_launches = executed;
+        st.lm_profiled_launches = std::min(executed, lm_events);
     }
     st.host_launch_ms = c.launch_s * 1e3;
     st.host_wait_ms = c.wait_s * 1e3;
@@ -2031,7 +2042,7 @@ static int align_device(lom_map *m, const char *d_src, size_t n, size_t stride, 
         LOM_HIP(m, hipStreamSynchronize(m->stream));
         for (int i = 0; i < c.prof_used; i++) {
             float ms = 0.f;
-            if (hipEventElapsedTime(&ms, m->prof_events[(size_t)i * 2], m->prof_events[(size_t)i * 2 + 1]) == hipSuccess)
+            if (hipEventElapsedTime(&ms, m->prof_events[(size_t)i * 3], m->prof_events[(size_t)i * 3 + 1]) == hipSuccess)
                 st.match_kernel_ms += ms;
         }
         st.profiled_launches = c.prof_used;
@@ -2187,7 +2198,8 @@ int lom_comm_attach_p2p(lom_map *m, lom_host_comm *hc)
 }
 
 int lom_profile_match(lom_map *m, const float *d_src, size_t n, size_t stride, const float t[3], const float q[4],
-                      float max_dist, int reps, double *avg_us_out, double *bytes_out, double *requested_bytes_out)
+                      float max_dist, int reps, double *avg_us_out, double *bytes_out, double *requested_bytes_out,
+                      double *pair_avg_us_out)
 {
     if (!m || !d_src || !n || !t || !q || reps < 1 || !avg_us_out || stride < 12 || (stride & 3)) return LOM_ERR_ARG;
     if (n >= 0x7FFFFFFFull) return LOM_ERR_ARG;
@@ -2204,6 +2216,24 @@ int lom_profile_match(lom_map *m, const float *d_src, size_t n, size_t stride, c
     if (rc == LOM_OK) rc = hipEventRecord(e0, m->stream) == hipSuccess ? LOM_OK : LOM_ERR_HIP;
     for (int i = 0; rc == LOM_OK && i < reps; i++) rc = launch_match(c, t, q, max_dist, false);
     if (rc == LOM_OK) rc = hipEventRecord(e1, m->stream) == hipSuccess ? LOM_OK : LOM_ERR_HIP;
+    // the same launches with one event pair EACH (what the sampled in-loop measurement of lom_match_align* does):
+    // the difference to the train above is what an event pair adds to a single short kernel
+    double pair_ms = 0.0;
+    if (rc == LOM_OK && pair_avg_us_out) {
+        m->profiling = true;
+        c.prof_used = 0;
+        const int pr = std::min(reps, 32);
+        for (int i = 0; rc == LOM_OK && i < pr; i++) rc = launch_match(c, t, q, max_dist, false);
+        m->profiling = false;
+        if (rc == LOM_OK && hipStreamSynchronize(m->stream) != hipSuccess) rc = LOM_ERR_HIP;
+        for (int i = 0; rc == LOM_OK && i < c.prof_used; i++) {
+            float ms1 = 0.f;
+            if (hipEventElapsedTime(&ms1, m->prof_events[(size_t)i * 3], m->prof_events[(size_t)i * 3 + 1]) == hipSuccess)
+                pair_ms += ms1;
+        }
+        *pair_avg_us_out = c.prof_used ? pair_ms * 1e3 / c.prof_used : 0.0;
+        c.prof_used = 0;
+    }
     double sums[LOM_NSUMS];
     const double qd[4] = {q[0], q[1], q[2], q[3]}, td[3] = {t[0], t[1], t[2]};
     if (rc == LOM_OK) rc = launch_eval(c, qd, td, true, sums);  // folds the counters of the last launch
@@ -2352,6 +2382,8 @@ int lom_match_align_repeat(lom_map *m, const float *d_src, size_t n, size_t stri
         acc.host_wait_ms += st.host_wait_ms;
         acc.profiled_launches += st.profiled_launches;
         acc.host_fallback += st.host_fallback;
+        acc.lm_kernel_ms += st.lm_kernel_ms;
+        acc.lm_profiled_launches += st.lm_profiled_launches;
     }
     if (total) *total = acc;
     return LOM_OK;

@@ -1198,6 +1198,34 @@ int lom_map_add_points_device_nowait(lom_map *m, const float *d_xyz, const float
     return add_points_device(m, (const char *)d_xyz, (const char *)d_nrm, n, stride, false, false);
 }
 
+int lom_profile_insert(lom_map *m, const float *d_xyz, const float *d_nrm, size_t n, size_t stride, double *total_us_out)
+{
+    if (!m || !d_xyz || !n || !total_us_out || stride < 12 || (stride & 3)) return LOM_ERR_ARG;
+    LOM_HIP(m, hipSetDevice(m->device));
+    // capacity and scratch first, so that the bracket holds the insert's kernels only
+    int rc = refresh_nvox(m);
+    if (rc != LOM_OK) return rc;
+    const uint64_t worst = (uint64_t)m->n_vox + n;
+    if ((uint64_t)m->cap < 2 * worst && (rc = rehash(m, next_pow2(4 * worst))) != LOM_OK) return rc;
+    if (worst > m->slab_cap && (rc = ensure_slabs(m, worst + worst / 2)) != LOM_OK) return rc;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    LOM_HIP(m, hipEventCreate(&e0));
+    LOM_HIP(m, hipEventCreate(&e1));
+    LOM_HIP(m, hipStreamSynchronize(m->stream));
+    hipError_t e = hipEventRecord(e0, m->stream);
+    rc = add_points_device(m, (const char *)d_xyz, (const char *)d_nrm, n, stride, false, false);
+    if (e == hipSuccess) e = hipEventRecord(e1, m->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(m->stream);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc != LOM_OK) return rc;
+    if (e != hipSuccess) return set_error(m, LOM_ERR_HIP, "lom_profile_insert", e);
+    *total_us_out = (double)ms * 1e3;
+    return map_status(m);
+}
+
 int lom_map_status(lom_map *m)
 {
     if (!m) return LOM_ERR_ARG;

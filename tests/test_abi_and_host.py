@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol(lom):
     L = lom.capi.lib()
     for name in declared:
         assert hasattr(L, name), name
-    assert L.lom_abi_version() == 1
+    assert L.lom_abi_version() == 2
 
 
 def test_no_gpu_fails_loudly(lom):

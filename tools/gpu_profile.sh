@@ -1,0 +1,36 @@
+#!/bin/bash
+# Runs on the GPU box (through gpurun): the bench lines and the rocprofv3 evidence that goes into profiles/.
+#   tools/gpu_profile.sh <tag>      -> gpurun_out/<tag>/...
+# rocprofv3 runs from /tmp (its own temp files), the program itself after `--`, counters in separate passes.
+set -u
+TAG=${1:-prof}
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+run() { echo "== $*" >> "$OUT/log.txt"; timeout -k 10 "$@" >> "$OUT/log.txt" 2>&1; echo "rc=$?" >> "$OUT/log.txt"; }
+
+# 1. bench lines (default = C2 with the CPU baseline; C3, C4, C5 without)
+timeout -k 10 300 python3 "$ROOT/bench.py" > "$OUT/bench_default_line.json" 2> "$OUT/bench_default.err"; echo "default rc=$?"
+for c in C3 C4 C5; do
+  timeout -k 10 300 python3 "$ROOT/bench.py" --config $c --no-cpu-baseline > "$OUT/bench_${c}_line.json" 2> "$OUT/bench_$c.err"; echo "$c rc=$?"
+done
+# 2. kernel stats of the same commands
+run 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_default" -o kt -- python3 "$ROOT/bench.py" --no-cpu-baseline
+run 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_C5" -o kt -- python3 "$ROOT/bench.py" --config C5 --no-cpu-baseline --steps 200
+run 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_C3" -o kt -- python3 "$ROOT/bench.py" --config C3 --no-cpu-baseline --steps 50
+# 3. counters, separate passes (short runs: every dispatch is serialised under --pmc)
+B="python3 $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline"
+run 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o p -- $B
+run 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o p -- $B
+run 400 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --output-format csv -d "$OUT/pmc_sq" -o p -- $B
+run 400 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum TCP_TCC_ATOMIC_WITH_RET_REQ_sum --output-format csv -d "$OUT/pmc_tcc" -o p -- $B
+# 4. phase stamps of k_lm
+timeout -k 10 120 python3 "$ROOT/tools/lm_debug.py" > "$OUT/lm_stamps.txt" 2>&1; echo "lm_debug rc=$?"
+# summaries
+for k in k_match k_lm k_ins_claim2 k_ins_place2 k_ins_scatter2 k_ins_assign k_ins_heads; do
+  for d in pmc_fetch pmc_write pmc_sq pmc_tcc; do
+    python3 "$ROOT/tools/pmc_summary.py" "$OUT/$d" $k >> "$OUT/pmc_summary_$k.txt" 2>/dev/null
+  done
+done
+find "$OUT" -name "*kernel_stats.csv" | head
