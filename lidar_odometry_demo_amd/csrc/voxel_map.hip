@@ -211,8 +211,16 @@ __device__ inline uint32_t claim_slot(Slot *table, uint32_t mask, uint32_t shift
 {
     uint32_t h = hash_key(key, shift) & mask;
     for (;;) {
-        const unsigned long long prev = atomicCAS(&table[h].key, kEmptyKey, key);
-        if (prev == kEmptyKey || prev == key) return h;
+        // Look before the CAS: a slot that already shows this key needs no atomic (most points of a frame fall
+        // into voxels the map already has, and an atomic is a round trip to the memory side).  A stale view
+        // -- the slot still looks empty, or shows another key that is itself final -- only costs the CAS
+        // (keys never change once set) or moves on to the next slot exactly as the CAS would.
+        const unsigned long long seen = __hip_atomic_load(&table[h].key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (seen == key) return h;
+        if (seen == kEmptyKey) {
+            const unsigned long long prev = atomicCAS(&table[h].key, kEmptyKey, key);
+            if (prev == kEmptyKey || prev == key) return h;
+        }
         h = (h + 1) & mask;
     }
 }
@@ -234,6 +242,28 @@ __global__ void k_rebuild(Slot *table, uint32_t mask, uint32_t shift, const unsi
 __device__ inline const float *point_at(const char *base, size_t i, size_t stride)
 {
     return reinterpret_cast<const float *>(base + i * stride);
+}
+
+// one 12-byte point as ONE memory instruction (4-byte aligned is enough for global dwordx3): the compiler
+// does not know the alignment and would issue three dword accesses -- on scattered slab writes that is
+// three partial-line transactions per point instead of one
+typedef float f32x3 __attribute__((ext_vector_type(3)));
+__device__ __forceinline__ f32x3 load3(const float *p)
+{
+    f32x3 v;
+    asm volatile("global_load_dwordx3 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ void load3x2(const float *p, const float *q, f32x3 &a, f32x3 &b)  // both in flight together
+{
+    asm volatile("global_load_dwordx3 %0, %2, off\n\tglobal_load_dwordx3 %1, %3, off\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(a), "=&v"(b)
+                 : "v"(p), "v"(q)
+                 : "memory");
+}
+__device__ __forceinline__ void store3(float *p, f32x3 v)
+{
+    asm volatile("global_store_dwordx3 %0, %1, off" : : "v"(p), "v"(v) : "memory");
 }
 
 // per point: low word = 1 if it is the first point of a voxel seen for the first time (creation
@@ -543,20 +573,13 @@ __global__ __launch_bounds__(kThreads) void k_ins_place2(Slot *table, uint32_t n
             for (uint32_t j = 0; j < m && rank < room; j++) rank += it[j] < i;
             if (rank < room) {  // voxel_grid.h:86,89-90: append while size() < max_points_, in input order
                 const size_t dst = ((size_t)slab * K + old + rank) * 3;
-                const float *p = point_at(xyz, i, stride);
-                pts[dst + 0] = p[0];
-                pts[dst + 1] = p[1];
-                pts[dst + 2] = p[2];
-                if (nrm) {
-                    const float *q = point_at(nrm, i, stride);
-                    nrm_out[dst + 0] = q[0];
-                    nrm_out[dst + 1] = q[1];
-                    nrm_out[dst + 2] = q[2];
-                } else {  // voxel_grid.h:103,107
-                    nrm_out[dst + 0] = 0.f;
-                    nrm_out[dst + 1] = 0.f;
-                    nrm_out[dst + 2] = 0.f;
-                }
+                f32x3 pv, nv = {0.f, 0.f, 0.f};  // voxel_grid.h:103,107: no normals -> (0, 0, 0)
+                if (nrm)
+                    load3x2(point_at(xyz, i, stride), point_at(nrm, i, stride), pv, nv);
+                else
+                    pv = load3(point_at(xyz, i, stride));
+                store3(pts + dst, pv);
+                store3(nrm_out + dst, nv);
             }
         }
         if (is_head) {
@@ -834,7 +857,7 @@ static int map_status(lom_map *m)
 // sync_status: wait for the insert's verdict (LOM_ERR_RANGE when a point's index is out of range; such a
 // call inserts nothing).  Without it the call only enqueues; lom_map_status() reports later.
 static int add_points_device(lom_map *m, const char *d_xyz, const char *d_nrm, size_t n, size_t stride,
-                             bool validated_on_host, bool sync_status)
+                             bool validated_on_host, bool sync_status, bool allow_shrink = true)
 {
     if (n == 0) return LOM_OK;
     if (n >= 0x7FFFFFFFull) return set_error(m, LOM_ERR_ARG, "too many points in one call");
@@ -911,7 +934,7 @@ static int add_points_device(lom_map *m, const char *d_xyz, const char *d_nrm, s
     // keep the table dense enough to stay cache-resident: load factor in (1/16, 1/2] (measured on C2/C3:
     // 2 slots per voxel costs the search 5-10 %, 4..16 are equal within noise).  Only a batch that made the
     // table grow far beyond its content (a bulk insert into few voxels) is worth the look at the host.
-    if (N > kOnePassMax && (uint64_t)m->cap >= 16ull * std::max<uint32_t>(m->min_cap, 1u)) {
+    if (allow_shrink && N > kOnePassMax && (uint64_t)m->cap >= 16ull * std::max<uint32_t>(m->min_cap, 1u)) {
         if ((rc = refresh_nvox(m)) != LOM_OK) return rc;
         const uint32_t target = std::max(m->min_cap, next_pow2(4ull * m->n_vox));
         if (m->cap > 4 * target) {
@@ -1213,7 +1236,7 @@ int lom_profile_insert(lom_map *m, const float *d_xyz, const float *d_nrm, size_
     LOM_HIP(m, hipEventCreate(&e1));
     LOM_HIP(m, hipStreamSynchronize(m->stream));
     hipError_t e = hipEventRecord(e0, m->stream);
-    rc = add_points_device(m, (const char *)d_xyz, (const char *)d_nrm, n, stride, false, false);
+    rc = add_points_device(m, (const char *)d_xyz, (const char *)d_nrm, n, stride, false, false, false);
     if (e == hipSuccess) e = hipEventRecord(e1, m->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(m->stream);
     float ms = 0.f;
@@ -1223,7 +1246,11 @@ int lom_profile_insert(lom_map *m, const float *d_xyz, const float *d_nrm, size_
     if (rc != LOM_OK) return rc;
     if (e != hipSuccess) return set_error(m, LOM_ERR_HIP, "lom_profile_insert", e);
     *total_us_out = (double)ms * 1e3;
-    return map_status(m);
+    if ((rc = map_status(m)) != LOM_OK) return rc;
+    // what lom_map_add_points_device does after a bulk insert: keep the table's load factor in (1/16, 1/2]
+    const uint32_t target = std::max(m->min_cap, next_pow2(4ull * m->n_vox));
+    if (m->cap > 4 * target) return rehash(m, target);
+    return LOM_OK;
 }
 
 int lom_map_status(lom_map *m)
