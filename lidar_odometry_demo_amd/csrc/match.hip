@@ -39,6 +39,7 @@ namespace lom {
 constexpr int kMatchThreads = 256;             // 4 waves
 constexpr int kMatchG = 16;                    // lanes per query: four queries per wave
 constexpr int kGroupsPerBlock = kMatchThreads / kMatchG;
+constexpr int kMatchMinWaves = 7;              // waves per SIMD the register budget is held to (72 VGPRs)
 constexpr int kEvalThreads = 512;
 
 // what k_match leaves behind for the evaluations of one outer iteration: source point,
@@ -124,6 +125,12 @@ __device__ __forceinline__ unsigned long long row_min_step(unsigned long long k)
     const unsigned long long o =
         ((unsigned long long)row_dpp<kCtrl>((uint32_t)(k >> 32)) << 32) | row_dpp<kCtrl>((uint32_t)k);
     return o < k ? o : k;
+}
+// lane kLane (0..15) of the row, to every lane of the row (ds_swizzle bit mode: and 0x10, or kLane)
+template <int kLane>
+__device__ __forceinline__ uint32_t row_lane(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x10 | (kLane << 5));
 }
 // lane 15 of the row, to every lane of the row (ds_swizzle bit mode: and 0x10, or 0x0F)
 __device__ __forceinline__ uint32_t row_last(uint32_t v) { return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x1F0); }
@@ -221,40 +228,83 @@ __global__ __launch_bounds__(kMatchThreads, kMinWaves) void k_match(MapView map,
     __shared__ uint32_t s_pref[kGroups][32];  // inclusive prefix of scanned counts, scan order; padded with total
     __shared__ uint32_t s_base[kGroups][32];  // slab * K - exclusive prefix: point index = s_base[b] + c
     __shared__ uint32_t s_cnt[kGroups][4];
+    __shared__ double s_pose[12];             // [component][R row (3), t]: what the component lanes multiply with
+    __shared__ float s_gap[kGroups][12];      // per query [axis][to voxel i-1, 0, to voxel i+1]: squared pruning gaps
     const int gl = threadIdx.x % G;
     const int grp = threadIdx.x / G;
     const uint32_t groups_total = gridDim.x * kGroups;
     // per-group counters live in LDS (one ds_add per counter and query by the writing lane):
     // four fewer live registers keep the kernel at 64 VGPRs without spilling
     if (gl < 4) s_cnt[grp][gl] = 0u;
+    if (threadIdx.x < 12) {
+        const int c = threadIdx.x >> 2, k = threadIdx.x & 3;
+        double v = P.t[0];
+#pragma unroll
+        for (int cc = 0; cc < 3; cc++)
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++)
+                if (c == cc && k == kk) v = kk < 3 ? P.R[cc * 3 + kk] : P.t[cc];
+        s_pose[threadIdx.x] = v;
+    }
+    if (gl < 3) s_gap[grp][gl * 3 + 1] = 0.f;  // the centre column of the gap table never changes
+    __syncthreads();
     const float prune_sq = P.max_sq * 1.0001f;
-    int nb_dx[kSets], nb_dy[kSets], nb_dz[kSets];  // neighbour offsets of this lane, scan order ix, iy, iz
+    // Work that is the same for the 16 lanes of a query is split over them instead of repeated by each: lanes
+    // 0, 1, 2 of a row prepare the x, y, z component (f64 transform, f32 cast, truncating index, the two
+    // pruning gaps of that axis) and hand the results to the row -- values through ds_swizzle broadcasts, the
+    // gap table through 12 LDS words.  Lanes 3..15 repeat component z (same instruction stream, results unused).
+    const int comp = gl < 2 ? gl : 2;
+    const double *my_pose = s_pose + comp * 4;
+    // this lane's two neighbours (scan order ix, iy, iz): key and hash of a neighbour follow from the centre's
+    // by ADDING a lane constant -- pack_key is a sum of shifted fields, and the Fibonacci hash multiplies by a
+    // constant modulo 2^64, so hash(key0 + d) = (key0 * phi + d * phi) >> shift.  One 64-bit multiply per query
+    // instead of two, no per-neighbour packing.
+    constexpr unsigned long long kPhi = 0x9E3779B97F4A7C15ull;
+    unsigned long long dkey[kSets], dprod[kSets];
+    const float *gap_x[kSets], *gap_y[kSets], *gap_z[kSets];
 #pragma unroll
     for (int s = 0; s < kSets; s++) {
         const int b = gl + s * G;
-        nb_dx[s] = b / 9 - 1;
-        nb_dy[s] = (b / 3) % 3 - 1;
-        nb_dz[s] = b % 3 - 1;
+        const int dx = b / 9 - 1, dy = (b / 3) % 3 - 1, dz = b % 3 - 1;
+        dkey[s] = (unsigned long long)(((long long)dx << 42) + ((long long)dy << 21) + (long long)dz);
+        dprod[s] = dkey[s] * kPhi;
+        gap_x[s] = &s_gap[grp][0 + (b < 27 ? dx + 1 : 1)];
+        gap_y[s] = &s_gap[grp][3 + (b < 27 ? dy + 1 : 1)];
+        gap_z[s] = &s_gap[grp][6 + (b < 27 ? dz + 1 : 1)];
     }
 
     for (uint32_t q = blockIdx.x * kGroups + grp; q < n; q += groups_total) {
         const float *sp = reinterpret_cast<const float *>(src + (size_t)q * stride);
         const float s0 = sp[0], s1 = sp[1], s2 = sp[2];
         const double p0 = (double)s0, p1 = (double)s1, p2 = (double)s2;
-        // voxel_grid.h:220-223: R*p + t in f64 (Eigen order a0 + (a1 + a2)), cast to f32
-        const float qx = (float)((P.R[0] * p0 + (P.R[1] * p1 + P.R[2] * p2)) + P.t[0]);
-        const float qy = (float)((P.R[3] * p0 + (P.R[4] * p1 + P.R[5] * p2)) + P.t[1]);
-        const float qz = (float)((P.R[6] * p0 + (P.R[7] * p1 + P.R[8] * p2)) + P.t[2]);
-        int ix = 0, iy = 0, iz = 0;
-        const bool inr = voxel_index_fast(qx, map.voxel_size, map.inv_voxel_size, ix) &&
-                         voxel_index_fast(qy, map.voxel_size, map.inv_voxel_size, iy) &&
-                         voxel_index_fast(qz, map.voxel_size, map.inv_voxel_size, iz);
-        float gmx, gpx, gmy, gpy, gmz, gpz;
-        axis_gaps(qx, ix, map.voxel_size, gmx, gpx);
-        axis_gaps(qy, iy, map.voxel_size, gmy, gpy);
-        axis_gaps(qz, iz, map.voxel_size, gmz, gpz);
+        // voxel_grid.h:220-223: R*p + t in f64 (Eigen order a0 + (a1 + a2)), cast to f32 -- this lane's component
+        const float qc = (float)((my_pose[0] * p0 + (my_pose[1] * p1 + my_pose[2] * p2)) + my_pose[3]);
+        int ic = 0;
+        const bool okc = voxel_index_fast(qc, map.voxel_size, map.inv_voxel_size, ic);
+        float gm2, gp2;
+        axis_gaps(qc, ic, map.voxel_size, gm2, gp2);
+        if (gl < 3) {
+            s_gap[grp][gl * 3 + 0] = gm2;
+            s_gap[grp][gl * 3 + 2] = gp2;
+        }
+        const int icc = okc ? ic : (int)0x80000000;  // out of range / not finite
+        const float qx = __uint_as_float(row_lane<0>(__float_as_uint(qc)));
+        const float qy = __uint_as_float(row_lane<1>(__float_as_uint(qc)));
+        const float qz = __uint_as_float(row_lane<2>(__float_as_uint(qc)));
+        const int ix = (int)row_lane<0>((uint32_t)icc), iy = (int)row_lane<1>((uint32_t)icc),
+                  iz = (int)row_lane<2>((uint32_t)icc);
+        const bool inr = ix != (int)0x80000000 && iy != (int)0x80000000 && iz != (int)0x80000000;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         LOM_STAMP(1);  // source point loaded and transformed
         // ---- probe: both sets' first slots in flight together ----
+        // stored indices lie in (-2^20, 2^20): a centre at least two voxels inside has all 27 neighbours in range
+        const uint32_t kInner = (uint32_t)(2 * kIdxBias - 3);
+        const bool safe = (uint32_t)(ix + (kIdxBias - 2)) < kInner && (uint32_t)(iy + (kIdxBias - 2)) < kInner &&
+                          (uint32_t)(iz + (kIdxBias - 2)) < kInner;
+        const unsigned long long key0 = inr ? pack_key(ix, iy, iz) : 0ull;
+        const unsigned long long prod0 = key0 * kPhi;
         unsigned long long key[kSets];
         uint32_t h[kSets];
         bool act[kSets];
@@ -262,20 +312,15 @@ __global__ __launch_bounds__(kMatchThreads, kMinWaves) void k_match(MapView map,
 #pragma unroll
         for (int s = 0; s < kSets; s++) {
             const int b = gl + s * G;
-            int dx = nb_dx[s], dy = nb_dy[s], dz = nb_dz[s];
-            // keep the lane-constant comparisons below inside the loop: hoisted, their twelve
-            // lane masks do not fit the scalar registers and get spilled lane by lane
-            asm volatile("" : "+v"(dx), "+v"(dy), "+v"(dz));
-            const int nx = ix + dx, ny = iy + dy, nz = iz + dz;
-            // stored indices lie in (-2^20, 2^20); anything outside cannot exist
-            act[s] = inr && b < 27 && nx > -kIdxBias && nx < kIdxBias && ny > -kIdxBias && ny < kIdxBias &&
-                     nz > -kIdxBias && nz < kIdxBias;
-            key[s] = act[s] ? pack_key(nx, ny, nz) : 0ull;
-            h[s] = act[s] ? (hash_key(key[s], map.shift) & map.mask) : 0u;
-            const float sx = dx < 0 ? gmx : (dx > 0 ? gpx : 0.f);
-            const float sy = dy < 0 ? gmy : (dy > 0 ? gpy : 0.f);
-            const float sz = dz < 0 ? gmz : (dz > 0 ? gpz : 0.f);
-            lower[s] = sx + (sy + sz);
+            act[s] = inr && b < 27;
+            if (act[s] && !safe) {  // the outermost index layers: neighbours beyond the range cannot exist
+                const int nx = ix + (b / 9 - 1), ny = iy + ((b / 3) % 3 - 1), nz = iz + (b % 3 - 1);
+                act[s] = nx > -kIdxBias && nx < kIdxBias && ny > -kIdxBias && ny < kIdxBias && nz > -kIdxBias &&
+                         nz < kIdxBias;
+            }
+            key[s] = act[s] ? key0 + dkey[s] : 0ull;
+            h[s] = act[s] ? ((uint32_t)((prod0 + dprod[s]) >> map.shift) & map.mask) : 0u;
+            lower[s] = *gap_x[s] + (*gap_y[s] + *gap_z[s]);
         }
         u32x4 raw[kSets];
         load_slots2(map.table + h[0], map.table + h[1], raw[0], raw[1]);
@@ -304,19 +349,32 @@ __global__ __launch_bounds__(kMatchThreads, kMinWaves) void k_match(MapView map,
         }
         LOM_STAMP(2);  // 27 slots probed
         // ---- group-wide prefix over the neighbours in scan order ----
-        uint32_t tot = 0, run = 0;
-#pragma unroll
-        for (int s = 0; s < kSets; s++) {
-            const uint32_t inc = row_scan_inclusive(scan_cnt[s]);
-            // occupied voxels (<= 27) above bit 26, stored points (<= 27 K, K <= 2^20) below
-            tot += row_sum(cnt[s] | (cnt[s] ? (1u << 26) : 0u));
-            const int b = gl + s * G;
-            s_pref[grp][b] = (b < 27) ? run + inc : 0xFFFFFFFFu;
-            s_base[grp][b] = slab[s] * map.K - (run + inc - scan_cnt[s]);
-            run += row_last(inc);
-        }
+        // occupied voxels (<= 27) above bit 26, stored points (<= 27 K, K < 2^16) below: one row sum for both sets
+        const uint32_t tot = row_sum((cnt[0] + cnt[1]) | (((cnt[0] ? 1u : 0u) + (cnt[1] ? 1u : 0u)) << 26));
         const uint32_t n_cand = tot & ((1u << 26) - 1u), n_occ = tot >> 26;
-        const uint32_t T = run;
+        uint32_t T;
+        if (map.K <= 2048u) {
+            // both sets' counts in one register (16 voxels x K < 2^16 each): ONE row scan, one broadcast
+            const uint32_t inc = row_scan_inclusive(scan_cnt[0] | (scan_cnt[1] << 16));
+            const uint32_t last = row_last(inc);
+            const uint32_t tot0 = last & 0xFFFFu, inc0 = inc & 0xFFFFu, inc1 = tot0 + (inc >> 16);
+            s_pref[grp][gl] = inc0;
+            s_pref[grp][gl + G] = (gl + G < 27) ? inc1 : 0xFFFFFFFFu;
+            s_base[grp][gl] = slab[0] * map.K - (inc0 - scan_cnt[0]);
+            s_base[grp][gl + G] = slab[1] * map.K - (inc1 - scan_cnt[1]);
+            T = tot0 + (last >> 16);
+        } else {
+            uint32_t run = 0;
+#pragma unroll
+            for (int s = 0; s < kSets; s++) {
+                const uint32_t inc = row_scan_inclusive(scan_cnt[s]);
+                const int b = gl + s * G;
+                s_pref[grp][b] = (b < 27) ? run + inc : 0xFFFFFFFFu;
+                s_base[grp][b] = slab[s] * map.K - (run + inc - scan_cnt[s]);
+                run += row_last(inc);
+            }
+            T = run;
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1522,7 +1580,7 @@ static void pose_args(const float t[3], const float q[4], float max_dist, PoseAr
     P.max_sq = max_dist * max_dist;  // voxel_grid.h:215
 }
 
-constexpr uint32_t kMaxMatchBlocks = 256u * 8u;
+constexpr uint32_t kMaxMatchBlocks = 256u * (uint32_t)kMatchMinWaves;  // one resident round: kMatchMinWaves workgroups of 4 waves per CU
 static uint32_t match_grid(uint32_t n)
 {
     const uint32_t need = (n + kGroupsPerBlock - 1) / kGroupsPerBlock;
@@ -1597,14 +1655,17 @@ static int launch_match(ScanCtx &c, const float t[3], const float q[4], float ma
         }
         // <lanes per query, candidates per lane and trip, min waves per SIMD>: measured on C2 / C3
         // (tools/ab_match.py): <16,1,8> 9.2 / 37.3 us, <16,2,1> 8.9 / 41.0, <16,4,1> 10.0 / 43.5,
-        // <16,2,8> and <16,4,8> spill and lose; 8 lanes per query 12.3 / 44.1, 32 lanes 10.1 / 44.5
+        // <16,2,8> and <16,4,8> spill and lose; 8 lanes per query 12.3 / 44.1, 32 lanes 10.1 / 44.5.
+        // Round 2 (query preparation split over the row's lanes, -15 % VALU instructions): 70 VGPRs, so 7 waves
+        // per SIMD and a grid capped at one resident round of that; held to 64 VGPRs it spills 4 and loses
+        // (C2 / C3 in the loop: 8.5 / 33.3 us at 7 waves, 9.3 / 36.5 at 8)
         if (chained)
-            hipLaunchKernelGGL((k_match<kMatchG, 1, 8, false, true>), dim3(c.match_blocks), dim3(kMatchThreads), 0,
+            hipLaunchKernelGGL((k_match<kMatchG, 1, kMatchMinWaves, false, true>), dim3(c.match_blocks), dim3(kMatchThreads), 0,
                                m->stream, view_of(m), c.d_src, c.stride, c.n, P, (int32_t *)m->scan_idx.p,
                                (MatchRec *)m->scan_on.p, (QStat *)nullptr, d_block_counters(m),
                                (unsigned long long *)nullptr, (const AlignState *)m->align_state.p);
         else
-            hipLaunchKernelGGL((k_match<kMatchG, 1, 8>), dim3(c.match_blocks), dim3(kMatchThreads), 0, m->stream,
+            hipLaunchKernelGGL((k_match<kMatchG, 1, kMatchMinWaves>), dim3(c.match_blocks), dim3(kMatchThreads), 0, m->stream,
                                view_of(m), c.d_src, c.stride, c.n, P, (int32_t *)m->scan_idx.p,
                                (MatchRec *)m->scan_on.p, stats ? (QStat *)m->scan_stats.p : (QStat *)nullptr,
                                d_block_counters(m), (unsigned long long *)nullptr, (const AlignState *)nullptr);
@@ -2341,7 +2402,7 @@ int lom_debug_match_stamps(lom_map *m, const float *d_src, size_t n, size_t stri
     PoseArgs P;
     pose_args(t, q, max_dist, P);
     for (int rep = 0; rep < 3; rep++)  // the last launch's stamps are kept (warm caches, like an align)
-        hipLaunchKernelGGL((k_match<kMatchG, 1, 8, true>), dim3(nb), dim3(kMatchThreads), 0, m->stream, view_of(m),
+        hipLaunchKernelGGL((k_match<kMatchG, 1, kMatchMinWaves, true>), dim3(nb), dim3(kMatchThreads), 0, m->stream, view_of(m),
                            (const char *)d_src, stride, (uint32_t)n, P, (int32_t *)m->scan_idx.p,
                            (MatchRec *)m->scan_on.p, (QStat *)nullptr, d_block_counters(m), d_st);
     hipError_t e = hipMemcpyAsync(stamps_out, d_st, (size_t)nb * 64, hipMemcpyDeviceToHost, m->stream);

@@ -244,27 +244,14 @@ __device__ inline const float *point_at(const char *base, size_t i, size_t strid
     return reinterpret_cast<const float *>(base + i * stride);
 }
 
-// one 12-byte point as ONE memory instruction (4-byte aligned is enough for global dwordx3): the compiler
-// does not know the alignment and would issue three dword accesses -- on scattered slab writes that is
-// three partial-line transactions per point instead of one
-typedef float f32x3 __attribute__((ext_vector_type(3)));
-__device__ __forceinline__ f32x3 load3(const float *p)
-{
-    f32x3 v;
-    asm volatile("global_load_dwordx3 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
-    return v;
-}
-__device__ __forceinline__ void load3x2(const float *p, const float *q, f32x3 &a, f32x3 &b)  // both in flight together
-{
-    asm volatile("global_load_dwordx3 %0, %2, off\n\tglobal_load_dwordx3 %1, %3, off\n\ts_waitcnt vmcnt(0)"
-                 : "=&v"(a), "=&v"(b)
-                 : "v"(p), "v"(q)
-                 : "memory");
-}
-__device__ __forceinline__ void store3(float *p, f32x3 v)
-{
-    asm volatile("global_store_dwordx3 %0, %1, off" : : "v"(p), "v"(v) : "memory");
-}
+// one 12-byte point as ONE memory instruction: a packed struct tells the compiler that the three floats are
+// contiguous and 4-byte aligned, and it issues global_load / global_store_dwordx3 -- on the scattered slab
+// writes that is one partial-line transaction per point instead of three
+struct __attribute__((packed, aligned(4))) Point3 {
+    float x, y, z;
+};
+__device__ __forceinline__ Point3 load3(const float *p) { return *reinterpret_cast<const Point3 *>(p); }
+__device__ __forceinline__ void store3(float *p, Point3 v) { *reinterpret_cast<Point3 *>(p) = v; }
 
 // per point: low word = 1 if it is the first point of a voxel seen for the first time (creation
 // order = order of first appearance, voxel_grid.h:83-87), high word = size of the voxel's bucket
@@ -573,11 +560,9 @@ __global__ __launch_bounds__(kThreads) void k_ins_place2(Slot *table, uint32_t n
             for (uint32_t j = 0; j < m && rank < room; j++) rank += it[j] < i;
             if (rank < room) {  // voxel_grid.h:86,89-90: append while size() < max_points_, in input order
                 const size_t dst = ((size_t)slab * K + old + rank) * 3;
-                f32x3 pv, nv = {0.f, 0.f, 0.f};  // voxel_grid.h:103,107: no normals -> (0, 0, 0)
-                if (nrm)
-                    load3x2(point_at(xyz, i, stride), point_at(nrm, i, stride), pv, nv);
-                else
-                    pv = load3(point_at(xyz, i, stride));
+                const Point3 pv = load3(point_at(xyz, i, stride));
+                Point3 nv = {0.f, 0.f, 0.f};  // voxel_grid.h:103,107: no normals -> (0, 0, 0)
+                if (nrm) nv = load3(point_at(nrm, i, stride));
                 store3(pts + dst, pv);
                 store3(nrm_out + dst, nv);
             }
