@@ -400,6 +400,15 @@ typedef struct {
 int64_t lom_pcd_read(const char *path, float *xyz_out, float *nrm_out, size_t cap, lom_pcd_info *info_or_null);
 const char *lom_pcd_last_error(void);
 
+/* ---- normal estimation helper: pcl::NormalEstimation, setRadiusSearch(r), viewpoint (0,0,0) (test/test.cpp:196-205) */
+/* For every point: covariance of all points within `radius` (itself included), eigenvector of the smallest
+ * eigenvalue, flipped towards the origin; NaN where fewer than 3 neighbours exist (test.cpp:219-221 drops those
+ * points).  The one plane / covariance accumulation in the reference's data flow; outside the align path, which
+ * uses the normals it is given.  Host input and output (packed 12-byte normals; optionally the neighbour counts);
+ * returns the number of points with a normal. */
+int64_t lom_estimate_normals(const float *xyz, size_t n, size_t stride_bytes, float radius, int device, float *nrm_out,
+                             uint32_t *neighbours_out_or_null);
+
 /* LidarOdometry::Params, src/lidar_odometry.h:23-48 */
 typedef struct {
     float lidar_min_range, lidar_max_range;

@@ -15,7 +15,7 @@ from . import capi
 from .capi import LomError  # noqa: F401
 
 __all__ = ["Pose3D", "VoxelGrid", "CloudMatcher", "LidarOdometry", "transform_points", "pointTimeNormalize",
-           "transformNonRigid", "rangeFilter", "classify", "loadPCDFile", "FrontEnd", "LomError", "capi"]
+           "transformNonRigid", "rangeFilter", "classify", "loadPCDFile", "estimateNormals", "FrontEnd", "LomError", "capi"]
 
 
 class Pose3D:
@@ -317,6 +317,17 @@ def classify(points):
     grid = (C.c_size_t * 2)()
     n = capi.lib().lom_cloud_classify(a.ctypes.data, len(a), xyz.ctypes.data, nrm.ctypes.data, C.byref(nu), grid)
     return xyz[:n].copy(), nrm[:n].copy(), int(nu.value), (int(grid[0]), int(grid[1]))
+
+
+def estimateNormals(xyz, radius, device=0, with_counts=False):
+    """pcl::NormalEstimation with setRadiusSearch(radius), viewpoint (0, 0, 0) (test/test.cpp:196-205) on the
+    device: (n, 3) float32 normals, NaN where fewer than 3 neighbours exist."""
+    xyz = capi.xyz_array(xyz)
+    nrm = np.empty_like(xyz)
+    cnt = np.empty(len(xyz), np.uint32) if with_counts else None
+    capi.check(capi.lib().lom_estimate_normals(xyz.ctypes.data, len(xyz), 12, float(radius), int(device), nrm.ctypes.data,
+                                               cnt.ctypes.data if with_counts else None))
+    return (nrm, cnt) if with_counts else nrm
 
 
 class FrontEnd:

@@ -1,0 +1,64 @@
+"""Normal-estimation helper on the device (csrc/normals.hip) = pcl::NormalEstimation with setRadiusSearch(0.25)
+as the reference's matcher test uses it (test/test.cpp:196-224), against the numpy restatement in
+tests/scenes.estimate_normals_radius (which produced the committed fixture normals), and the whole
+MatchingTest protocol with device-estimated normals.  Outside the align path."""
+import numpy as np
+import pytest
+
+from tests import scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def test_normals_match_the_restatement_on_the_fixture(lom, fixture_cloud):
+    xyz, xyzn = fixture_cloud
+    sub = xyz[::3].copy()                                   # ~20k points keep the numpy side in seconds
+    ref = scenes.estimate_normals_radius(sub, 0.25)
+    got, cnt = lom.estimateNormals(sub, 0.25, with_counts=True)
+    nan_ref, nan_got = np.isnan(ref).any(axis=1), np.isnan(got).any(axis=1)
+    # the two sides decide "within the radius" on differently rounded distances: a point exactly on the sphere may differ
+    assert (nan_ref != nan_got).sum() <= 3
+    ok = ~nan_ref & ~nan_got
+    assert ok.sum() > 0.5 * len(sub)                        # every third point only: sparser neighbourhoods
+    dots = np.abs((ref[ok].astype(np.float64) * got[ok].astype(np.float64)).sum(axis=1))
+    # planes with a clear smallest eigenvalue agree to f32 precision; nearly isotropic neighbourhoods (3-4 points,
+    # lines) have no stable normal on either side
+    assert np.mean(dots > 1 - 1e-6) > 0.97, np.mean(dots > 1 - 1e-6)
+    assert np.allclose(np.linalg.norm(got[ok], axis=1), 1.0, atol=1e-5)
+    # flipped towards the viewpoint (0, 0, 0)
+    assert ((-sub[ok].astype(np.float64) * got[ok].astype(np.float64)).sum(axis=1) >= -1e-9).all()
+    assert cnt[ok].min() >= 3
+
+
+def test_plane_and_degenerate_inputs(lom):
+    rng = np.random.default_rng(2)
+    xy = rng.uniform(-2, 2, (3000, 2))
+    plane = np.c_[xy, 0.3 * xy[:, 0] + 5.0].astype(np.float32)          # z = 0.3 x + 5
+    n = lom.estimateNormals(plane, 0.25)
+    want = np.array([-0.3, 0.0, 1.0]) / np.hypot(0.3, 1.0)
+    good = ~np.isnan(n).any(axis=1)
+    assert good.mean() > 0.95
+    d = np.abs(n[good].astype(np.float64) @ want)
+    assert (d > 1 - 1e-4).all()
+    # towards the origin: the plane lies above it, so the normals point down
+    assert (n[good][:, 2] < 0).all()
+    lonely = np.array([[0, 0, 0], [10, 0, 0], [10.1, 0, 0], [20, 0, 0]], np.float32)
+    out = lom.estimateNormals(lonely, 0.25)
+    assert np.isnan(out).all()                                           # 1 or 2 neighbours: no normal
+    # a crowded voxel (more points within one radius-sized voxel than the first cap of the internal map)
+    blob = (rng.normal(0, 0.02, (500, 3)) + np.array([3, 3, 3])).astype(np.float32)
+    nb, cnt = lom.estimateNormals(blob, 0.25, with_counts=True)
+    assert not np.isnan(nb).any() and cnt.min() > 400
+
+
+def test_matching_test_protocol_with_device_normals(lom, fixture_cloud):
+    """test/test.cpp:191-264 end to end through the product: normals from the device helper instead of the
+    committed ones, then VoxelGrid(0.25, 20) + align for the 7 guesses, reference tolerances."""
+    xyz, _ = fixture_cloud
+    nrm = lom.estimateNormals(xyz, 0.25)
+    keep = ~np.isnan(nrm).any(axis=1)                                    # :219-221
+    xyzn = np.c_[xyz[keep], nrm[keep]].astype(np.float32)
+    assert keep.sum() > 0.9 * len(xyz)
+    res = scenes.run_matching_test(lom, xyz, xyzn)
+    for c in res["cases"]:
+        assert c["err_t_norm"] < 0.05 and c["rot_err"] < 0.01            # test.cpp:261-262
