@@ -300,6 +300,7 @@ __global__ __launch_bounds__(kThreads) void k_fe_curv(const lom_point_xyzirt *__
     org[c] = make_float4(x, y, z, inten);
 }
 
+template <int kItems>  // cells per thread: 1 while a frame's cells fit one resident grid of 65536 threads, else kFeItems
 __global__ __launch_bounds__(kThreads) void k_fe_planar(const float4 *__restrict__ org, uint32_t *win, uint32_t cell_cap,
                                                         FrameConst F, float *__restrict__ out_xyz,
                                                         float *__restrict__ out_nrm, Granule *agg, uint32_t seq,
@@ -309,14 +310,14 @@ __global__ __launch_bounds__(kThreads) void k_fe_planar(const float4 *__restrict
     const uint32_t H = words[2], W = words[3];
     const bool overflow = (unsigned long long)H * W > cell_cap;
     const uint32_t total = overflow ? 0u : H * W;
-    const uint32_t base = (blockIdx.x * kThreads + threadIdx.x) * kFeItems;
+    const uint32_t base = (blockIdx.x * kThreads + threadIdx.x) * kItems;
     const float flat = 0.05f;
     const double flat10 = (double)flat * 10.0;  // :121 flatness_threshold * 10.0
-    bool keep[kFeItems];
-    float px[kFeItems], py[kFeItems], pz[kFeItems], nx[kFeItems], ny[kFeItems], nz[kFeItems];
+    bool keep[kItems];
+    float px[kItems], py[kItems], pz[kItems], nx[kItems], ny[kItems], nz[kItems];
     unsigned long long mine = 0;
 #pragma unroll
-    for (int k = 0; k < kFeItems; k++) {
+    for (int k = 0; k < kItems; k++) {
         const uint32_t c = base + k;
         keep[k] = false;
         px[k] = py[k] = pz[k] = nx[k] = ny[k] = nz[k] = 0.f;
@@ -368,7 +369,7 @@ __global__ __launch_bounds__(kThreads) void k_fe_planar(const float4 *__restrict
     const unsigned long long before = grid_prefix64(tot, agg, seq, words + 5, s_w);
     uint32_t at = (uint32_t)(before + excl);  // low word: filtered points before this thread
 #pragma unroll
-    for (int k = 0; k < kFeItems; k++) {
+    for (int k = 0; k < kItems; k++) {
         if (!keep[k]) continue;
         float *o = out_xyz + (size_t)at * 3, *no = out_nrm + (size_t)at * 3;
         o[0] = px[k], o[1] = py[k], o[2] = pz[k];
@@ -575,8 +576,12 @@ int lom_frontend_process(lom_frontend *f, const lom_point_xyzirt *pts, size_t n,
                        cells_bound, seq, f->d_words);
     hipLaunchKernelGGL(k_fe_curv, dim3(blocks_for(cells_bound)), dim3(kThreads), 0, f->stream, f->d_desk, f->d_win,
                        f->d_words, cells_bound, f->d_org);
-    hipLaunchKernelGGL(k_fe_planar, dim3(blocks_for((cells_bound + kFeItems - 1) / kFeItems)), dim3(kThreads), 0, f->stream,
-                       f->d_org, f->d_win, cells_bound, F, f->d_xyz, f->d_nrm, fe_agg(f), seq, f->d_words);
+    if (cells_bound <= kOnePassMax)
+        hipLaunchKernelGGL(k_fe_planar<1>, dim3(blocks_for(cells_bound)), dim3(kThreads), 0, f->stream, f->d_org, f->d_win,
+                           cells_bound, F, f->d_xyz, f->d_nrm, fe_agg(f), seq, f->d_words);
+    else
+        hipLaunchKernelGGL(k_fe_planar<kFeItems>, dim3(blocks_for((cells_bound + kFeItems - 1) / kFeItems)), dim3(kThreads), 0,
+                           f->stream, f->d_org, f->d_win, cells_bound, F, f->d_xyz, f->d_nrm, fe_agg(f), seq, f->d_words);
     FE_HIP(f, hipGetLastError());
     FE_HIP(f, hipEventRecord(f->done_ev, f->stream));
     return LOM_OK;

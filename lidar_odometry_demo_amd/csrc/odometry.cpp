@@ -493,7 +493,11 @@ private:
 struct lom_odometry {
     lom_odometry_params cfg;
     lom_map *keyframe = nullptr;       // keyframe_           lidar_odometry.h:82
-    lom_map *update_ds = nullptr;      // keyframe_downsampler lidar_odometry.cpp:37 (reused per frame)
+    // keyframe_downsampler lidar_odometry.cpp:37: two workspaces, alternating per frame -- its output feeds the
+    // keyframe update of the frame, which runs on the keyframe's stream beside the NEXT frame's stages
+    lom_map *update_ds2[2] = {nullptr, nullptr};
+    lom_map *update_ds = nullptr;      // the one of the current frame
+    int parity = 0;
     lom_map *matching_ds = nullptr;    // matching_downsampler lidar_odometry.cpp:46 (reused per frame)
     lom_pose previous, current;        // lidar_odometry.h:84-85
     lom_odometry_frame_stats last{};
@@ -572,13 +576,17 @@ int lom_odometry_create(const lom_odometry_params *params, int device, lom_odome
     o->previous = o->current;
     int rc = lom_map_create(params->keyframe_voxel_size, params->keyframe_max_points_cnt, 1 << 16, device,
                             &o->keyframe);  // :18-19
-    if (rc == LOM_OK) rc = lom_map_create(params->keyframe_update_voxel_size, 1, 1 << 15, device, &o->update_ds);
+    if (rc == LOM_OK) rc = lom_map_create(params->keyframe_update_voxel_size, 1, 1 << 15, device, &o->update_ds2[0]);
+    if (rc == LOM_OK) rc = lom_map_create(params->keyframe_update_voxel_size, 1, 1 << 15, device, &o->update_ds2[1]);
+    o->update_ds = o->update_ds2[0];
     if (rc == LOM_OK) rc = lom_map_create(params->keyframe_matching_voxel_size, 1, 1 << 14, device, &o->matching_ds);
-    // one stream for the three handles: a frame stays in HBM from the upload of the filtered cloud to
-    // the keyframe update, each step consuming the previous one's device buffers in stream order
-    if (rc == LOM_OK) rc = lom_map_set_stream(o->update_ds, lom_map_get_stream(o->keyframe));
-    if (rc == LOM_OK) rc = lom_map_set_stream(o->matching_ds, lom_map_get_stream(o->keyframe));
+    // Two streams: the keyframe's (align, keyframe update) and the front end's (upload, front-end kernels, both
+    // down-samplers).  The stages of frame k+1 run beside the keyframe update of frame k; the host reads the
+    // stage results back (a synchronisation with the front end's stream) before it launches the align.
     if (rc == LOM_OK && !getenv("LOM_HOST_FRONTEND")) rc = lom_frontend_create(device, nullptr, &o->frontend);
+    void *stage_stream = o->frontend ? lom_frontend_stream(o->frontend) : (o->keyframe ? lom_map_get_stream(o->keyframe) : nullptr);
+    for (lom_map *h : {o->update_ds2[0], o->update_ds2[1], o->matching_ds})
+        if (rc == LOM_OK) rc = lom_map_set_stream(h, stage_stream);
     if (rc != LOM_OK) {
         lom_odometry_destroy(o);
         return rc;
@@ -592,9 +600,11 @@ void lom_odometry_destroy(lom_odometry *o)
     if (!o) return;
     (void)o->settle();
     o->deferred.reset();
-    lom_frontend_destroy(o->frontend);  // the front end and the down-samplers run on the keyframe handle's stream: they go first
-    lom_map_destroy(o->update_ds);
+    // the down-samplers run on the front end's stream (or the keyframe's): they go before the owner of that stream
+    lom_map_destroy(o->update_ds2[0]);
+    lom_map_destroy(o->update_ds2[1]);
     lom_map_destroy(o->matching_ds);
+    lom_frontend_destroy(o->frontend);
     lom_map_destroy(o->keyframe);
     delete o;
 }
@@ -727,14 +737,12 @@ int stages_on_device(lom_odometry *o, const lom_point_xyzirt *pts, size_t n, con
     o->temp_points = n;  // :31 temp_cloud_ = deskewed_input_cloud (fetched from HBM on demand)
     o->temp_on_device = true;
     tm.lap("front end enq.");
-    if ((rc = o->settle()) != LOM_OK) return rc;  // as in stages_on_host
     const float *d_fx = nullptr, *d_fn = nullptr;
     const uint32_t *d_fe = nullptr, *d_nd = nullptr, *d_nm = nullptr;
     uint32_t bound = 0;
     lom_frontend_results(o->frontend, &d_fx, &d_fn, &d_fe, &bound);
-    // the front end ran on its own stream, beside the previous frame's keyframe update; the handles' stream
-    // takes over from here
-    if ((rc = lom_map_wait_event(o->keyframe, lom_frontend_done_event(o->frontend))) != LOM_OK) return fail_map(o, rc, o->keyframe);
+    // front end and down-samplers share a stream of their own: all of this runs beside the previous frame's
+    // keyframe update (whose input is the OTHER update workspace)
     if ((rc = lom_voxel_downsample_device_nowait(o->update_ds, o->cfg.keyframe_update_voxel_size, d_fx, d_fn, bound, d_fe + 1,
                                                  12, &in.d_down, &in.d_down_n, &d_nd)) != LOM_OK)
         return fail_map(o, rc, o->update_ds);
@@ -761,8 +769,12 @@ int stages_on_device(lom_odometry *o, const lom_point_xyzirt *pts, size_t n, con
         ptrs[k++] = m_range;  // 8
         ptrs[k++] = m_grid;   // 9
     }
-    if ((rc = lom_map_read_device_words(o->keyframe, ptrs, k, got)) != LOM_OK) return fail_map(o, rc, o->keyframe);
+    if ((rc = lom_map_read_device_words(o->update_ds, ptrs, k, got)) != LOM_OK) return fail_map(o, rc, o->update_ds);
     tm.lap("stages (device)");
+    // the previous frame's keyframe update must be through before this frame touches the keyframe handle.  Its
+    // failure is reported here, by the call after the one it belongs to; poses / keyframe stay as they were.
+    if ((rc = o->settle()) != LOM_OK) return rc;
+    tm.lap("settle");
     const uint32_t fe_seq = lom_frontend_sequence(o->frontend);
     if (got[3] == fe_seq || got[6] == seq_u || (d_nm && got[9] == seq_m)) {
         o->error = "a workgroup timed out waiting for the others of its grid";
@@ -800,6 +812,8 @@ int lom_odometry_process_cloud(lom_odometry *o, const lom_point_xyzirt *pts, siz
         lom_pose_identity(&ident);
         FrameInputs in;
         int rc = 1;
+        o->parity ^= 1;
+        o->update_ds = o->update_ds2[o->parity];
         if (o->frontend) rc = stages_on_device(o, pts, n, rel_inv, ident, cur, in, tm);
         if (rc == 1) {
             in = FrameInputs();
