@@ -898,9 +898,9 @@ __device__ __forceinline__ void reduce_and_exchange(const double acc[28], double
 // lane issuing ~1500 f64 instructions costs ~4 us per step on a 64-wide SIMD.  Here lane r < 6
 // owns row r of the 6x6 system; values another row needs travel by v_readlane (uniform
 // broadcasts), so a step is ~400 instructions.  Differences from the serial code are at rounding
-// level only: the 6x6 system is factored as L D L^T with reciprocals from v_rcp_f64 + two Newton
-// steps (lm_core.hpp: Cholesky with the correctly rounded library sqrt and division).  All 64 lanes run the code (uniform control
-// flow); lanes >= 6 compute unused values and never store.
+// level only: the 6x6 system is solved by Gauss-Jordan elimination on the lanes' rows with reciprocals from
+// v_rcp_f64 + two Newton steps (lm_core.hpp: Cholesky with the correctly rounded library sqrt and division).
+// All 64 lanes run the code (uniform control flow); lanes >= 6 compute unused values and never store.
 __device__ __forceinline__ double lane_bcast(double v, int k)
 {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), k);
@@ -1148,42 +1148,30 @@ __device__ __forceinline__ int lmw_propose(LmState &S, int lane)
         double M[6];
 #pragma unroll
         for (int j = 0; j < 6; j++) M[j] = (r == j) ? As[j] + diag_r * inv_radius : As[j];
-        // M = L D L^T, column by column (positive pivots <=> the Cholesky factor of lm_core.hpp
-        // exists): lane r ends with l_rk in M[k] for k < r and d_r in M[r]; Lt[j] of lane k = l_jk.
-        // Unit triangles: the substitutions below carry no scaling in their dependent chains.
-        double invd[6], Lt[6] = {0, 0, 0, 0, 0, 0};
+        // Gauss-Jordan on the augmented rows [M_r | gs_r], lane r owns row r: per pivot one reciprocal, the pivot
+        // row travels by v_readlane, and every lane updates its whole row with INDEPENDENT multiply-adds -- no
+        // triangular substitutions afterwards (their 12 dependent broadcast-multiply-add steps were as long as
+        // the factorisation).  Same elimination order as the L D L^T it replaces: the pivots are its D, so
+        // "all pivots positive" is still "the Cholesky factor of lm_core.hpp exists".
+        double rhs = gs_r;
         bool ok = true;
 #pragma unroll
         for (int k = 0; k < 6; k++) {
-            const double d = lane_bcast(M[k], k);
-            if (!(d > 0.0)) ok = false;
-            const double id = fast_rcp(d);
-            invd[k] = id;
-            const double Lrk = M[k] * id;  // l_rk for r > k
+            double piv[6];
 #pragma unroll
-            for (int j = k + 1; j < 6; j++) {
-                const double Cjk = lane_bcast(M[k], j);  // M[j][k], not yet scaled
-                M[j] -= Lrk * Cjk;
-                Lt[j] = (r == k) ? Cjk * id : Lt[j];
-            }
-            M[k] = (r == k) ? d : Lrk;
+            for (int j = k; j < 6; j++) piv[j] = lane_bcast(M[j], k);
+            const double prhs = lane_bcast(rhs, k);
+            if (!(piv[k] > 0.0)) ok = false;
+            const double f = (r == k) ? 0.0 : M[k] * fast_rcp(piv[k]);
+#pragma unroll
+            for (int j = k; j < 6; j++) M[j] -= f * piv[j];
+            rhs -= f * prhs;
         }
         double y[6];
         if (ok) {
-            double s_r = gs_r, zv = 0.0;
+            const double y_r = rhs * fast_rcp(lmw_pick(M, r));
 #pragma unroll
-            for (int m = 0; m < 6; m++) {  // L z = gs
-                const double zm = lane_bcast(s_r, m);
-                s_r -= M[m] * zm;
-                zv = (r == m) ? zm : zv;
-            }
-            double t_r = zv * lmw_pick(invd, r);  // D w = z
-#pragma unroll
-            for (int m = 5; m >= 0; m--) {  // L^T y = w
-                const double ym = lane_bcast(t_r, m);
-                t_r -= Lt[m] * ym;
-                y[m] = ym;
-            }
+            for (int m = 0; m < 6; m++) y[m] = lane_bcast(y_r, m);
 #pragma unroll
             for (int i = 0; i < 6; i++)
                 if (!lm_finite(y[i])) ok = false;
