@@ -133,7 +133,7 @@ int64_t lom_voxel_downsample_device(lom_map *workspace, float voxel_size, const 
                                     size_t n, size_t stride_bytes, const float **d_xyz_out,
                                     const float **d_nrm_out);
 /* the same, enqueued only: the input size may live on the device (*d_n, with n_bound its upper bound known
- * to the host, <= 65536 then; d_n == NULL: n_bound points), and the number of voxels is left in a device word
+ * to the host, <= 262144 then; d_n == NULL: n_bound points), and the number of voxels is left in a device word
  * (*d_count_out) for the kernels that consume the result; lom_map_status() reports a point out of range. */
 int lom_voxel_downsample_device_nowait(lom_map *workspace, float voxel_size, const float *d_xyz, const float *d_nrm,
                                        size_t n_bound, const uint32_t *d_n, size_t stride_bytes,

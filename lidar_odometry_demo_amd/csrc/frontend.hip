@@ -545,7 +545,8 @@ int lom_frontend_process(lom_frontend *f, const lom_point_xyzirt *pts, size_t n,
                          float min_range, float max_range)
 {
     if (!f || (n && !pts) || !start || !end) return LOM_ERR_ARG;
-    if (n >= (size_t)kFeItems * kOnePassMax / 3) return fe_fail(f, LOM_ERR_ARG, "frame too large for the device front end");
+    // the organised cloud is scanned by one grid of at most kFeItems * 65536 cells, sized n + n / 2 + 4096
+    if (n + n / 2 + 4096 > (size_t)kFeItems * kOnePassMax) return fe_fail(f, LOM_ERR_ARG, "frame too large for the device front end");
     FE_HIP(f, hipSetDevice(f->device));
     f->error.clear();
     int rc = fe_reserve(f, std::max<size_t>(n, 1));

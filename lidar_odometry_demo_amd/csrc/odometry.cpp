@@ -719,6 +719,9 @@ int stages_on_device(lom_odometry *o, const lom_point_xyzirt *pts, size_t n, con
                      lom_odometry_frame_stats &cur, FrameInputs &in, StageTimer &tm)
 {
     int rc;
+    // front end and down-samplers take frames of up to ~170k points (their in-kernel scans cover 262144 cells /
+    // points); larger ones go through the host stages
+    if (n > 170000) return 1;
     // the frame goes into the front end's pinned buffer by the worker pool (one pass over ~1 MB), then to HBM
     lom_point_xyzirt *stage = nullptr;
     if ((rc = lom_frontend_stage(o->frontend, n, &stage)) != LOM_OK) {
@@ -780,7 +783,9 @@ int stages_on_device(lom_odometry *o, const lom_point_xyzirt *pts, size_t n, con
         o->error = "a workgroup timed out waiting for the others of its grid";
         return LOM_ERR_HIP;
     }
-    if (got[2] == fe_seq) return 1;  // an azimuth on a bin boundary, or an organised cloud beyond the buffers
+    // an azimuth on a bin boundary, or an organised cloud beyond the buffers (LOM_TEST_FORCE_HOST_REDO: tests take
+    // this path on every frame)
+    if (got[2] == fe_seq || getenv("LOM_TEST_FORCE_HOST_REDO")) return 1;
     if (got[5] == seq_u || (d_nm && got[8] == seq_m)) {
         o->error = "coordinate / voxel_size out of range or not finite";
         return LOM_ERR_RANGE;

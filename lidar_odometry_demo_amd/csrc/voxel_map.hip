@@ -407,25 +407,39 @@ __global__ void k_ds_write(uint32_t n, const uint32_t *flag, const uint32_t *ran
 // k_ds_claim (above) leaves pt_slot[] and head[]; this kernel keeps the first point of every voxel in
 // order of first appearance and puts the workspace back to rest: the head point of a voxel frees its
 // table slot and its head word, so neither a table re-initialisation nor a memset follows.
+template <int kItems>  // consecutive points per thread: 1 up to 65536 points, 4 up to 262144
 __global__ __launch_bounds__(kThreads) void k_ds_emit(Slot *table, uint32_t n, const uint32_t *n_dev,
                                                       const uint32_t *__restrict__ pt_slot, uint32_t *head, const char *xyz,
                                                       const char *nrm, size_t stride, float *out_xyz, float *out_nrm,
                                                       Granule *agg, uint32_t seq, uint32_t *words)
 {
     __shared__ unsigned long long s_w[8];
-    const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
+    const uint32_t base = (blockIdx.x * kThreads + threadIdx.x) * kItems;
     if (n_dev) n = min(n, *n_dev);
-    uint32_t h = kInvalidSlot;
-    bool keep = false;
-    if (i < n) {
-        h = pt_slot[i];
-        keep = h != kInvalidSlot && head[h] == i;
+    uint32_t h[kItems];
+    bool keep[kItems];
+    uint32_t mine = 0;
+#pragma unroll
+    for (int k = 0; k < kItems; k++) {
+        const uint32_t i = base + k;
+        h[k] = kInvalidSlot;
+        keep[k] = false;
+        if (i < n) {
+            h[k] = pt_slot[i];
+            keep[k] = h[k] != kInvalidSlot && head[h[k]] == i;
+        }
+        mine += keep[k] ? 1u : 0u;
     }
     unsigned long long total;
-    const unsigned long long excl = block_scan64(keep ? 1ull : 0ull, s_w, total);
+    const unsigned long long excl = block_scan64(mine, s_w, total);
     const unsigned long long before = grid_prefix64(total, agg, seq, words + 7, s_w);
-    if (keep) {
-        const size_t d = (size_t)(before + excl) * 3;
+    uint32_t at = (uint32_t)(before + excl);
+#pragma unroll
+    for (int k = 0; k < kItems; k++) {
+        if (!keep[k]) continue;
+        const uint32_t i = base + k;
+        const size_t d = (size_t)at * 3;
+        at++;
         const float *p = point_at(xyz, i, stride);
         out_xyz[d] = p[0];
         out_xyz[d + 1] = p[1];
@@ -444,8 +458,8 @@ __global__ __launch_bounds__(kThreads) void k_ds_emit(Slot *table, uint32_t n, c
         e.key = kEmptyKey;
         e.count = 0;
         e.slab = kNoSlab;
-        table[h] = e;
-        head[h] = 0xFFFFFFFFu;
+        table[h[k]] = e;
+        head[h[k]] = 0xFFFFFFFFu;
     }
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) words[4] = (uint32_t)(before + total);  // voxels kept
 }
@@ -1377,7 +1391,7 @@ static int downsample_core(lom_map *m, float voxel_size, const char *dx, const c
     if ((uint64_t)m->cap < 2ull * N) {
         if ((rc = rehash(m, next_pow2(4ull * N))) != LOM_OK) return rc;
     }
-    const bool one_pass = N <= kOnePassMax;
+    const bool one_pass = N <= 4 * kOnePassMax;
     if ((rc = ensure(m, m->scr[S_PT_SLOT], (size_t)N * 4)) != LOM_OK) return rc;
     if ((rc = ensure_rest(m, m->scr[S_DS_HEAD], (size_t)m->cap * 4, 0xFF)) != LOM_OK) return rc;
     if ((rc = ensure(m, m->scr[S_ITEMS], (size_t)N * 12)) != LOM_OK) return rc;     // compacted xyz
@@ -1387,12 +1401,16 @@ static int downsample_core(lom_map *m, float voxel_size, const char *dx, const c
     const uint32_t seq = ++m->call_seq;
     const MapView v = view_of(m);
     const dim3 g(blocks_for(N)), b(kThreads);
-    if (n_dev && !one_pass) return set_error(m, LOM_ERR_ARG, "device-side point count: at most 65536 points");
+    if (n_dev && !one_pass) return set_error(m, LOM_ERR_ARG, "device-side point count: at most 262144 points");
     hipLaunchKernelGGL(k_ds_claim, g, b, 0, m->stream, m->d_table, v.mask, v.shift, dx, stride, N, n_dev, voxel_size,
                        pt_slot, head, seq, d_word(m, 5));
     if (one_pass) {
-        hipLaunchKernelGGL(k_ds_emit, g, b, 0, m->stream, m->d_table, N, n_dev, pt_slot, head, dx, dn, stride, oxyz, onrm,
-                           d_agg(m), seq, d_word(m, 0));
+        if (N <= kOnePassMax)
+            hipLaunchKernelGGL(k_ds_emit<1>, g, b, 0, m->stream, m->d_table, N, n_dev, pt_slot, head, dx, dn, stride, oxyz,
+                               onrm, d_agg(m), seq, d_word(m, 0));
+        else
+            hipLaunchKernelGGL(k_ds_emit<4>, dim3(blocks_for((N + 3) / 4)), b, 0, m->stream, m->d_table, N, n_dev, pt_slot,
+                               head, dx, dn, stride, oxyz, onrm, d_agg(m), seq, d_word(m, 0));
         LOM_HIP(m, hipGetLastError());
     } else {
         if ((rc = ensure(m, m->scr[S_FLAG], (size_t)N * 4)) != LOM_OK) return rc;

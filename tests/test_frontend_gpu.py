@@ -102,3 +102,18 @@ def test_device_sinf_equals_libm(lom):
     got = fe.sinf(x)
     want = np.array([libm.sinf(float(v)) for v in x], np.float32)
     assert got.tobytes() == want.tobytes()
+
+
+def test_frontend_64_beam_frame(lom, oracle):
+    """A 64-beam x 2048 frame (~130k points): the organised cloud needs several cells per thread of the in-kernel
+    scan (k_fe_planar<4>); still bit-equal to the oracle's chain."""
+    fe = lom.FrontEnd()
+    frame = synth.make_sequence_frame(4, n_beams=64, n_az=2048)
+    assert len(frame) > 100_000
+    start, end = POSES[1]
+    desk, n_planar, fx, fn, grid = _oracle_chain(oracle, frame, start, end, 4.0, 80.0)
+    got = fe.process(frame, lom.Pose3D(*start), lom.Pose3D(*end), 4.0, 80.0)
+    assert not got["redo_on_host"]
+    assert got["deskewed"].tobytes() == desk.tobytes()
+    assert got["grid"] == grid and got["planar_points"] == n_planar
+    assert got["xyz"].tobytes() == fx.tobytes() and got["normals"].tobytes() == fn.tobytes()

@@ -669,3 +669,35 @@ def test_c4_full_size_single_rank(lom, oracle, c4_case):
     n = len(c["scan"])
     parts = [m.debugEvalSums(g, np.ascontiguousarray(c["scan"][n * r // 8: n * (r + 1) // 8]), pose) for r in range(8)]
     assert_sums_close(np.sum(parts, axis=0), m.debugEvalSums(g, c["scan"], pose), "C4 ranges")
+
+
+def test_deferred_insert_verdict(lom):
+    """lom_map_add_points_device_nowait only enqueues; lom_map_status reports a point out of range afterwards, and
+    such a call has inserted nothing (its voxels' keys may stay claimed without payload: invisible to every query)."""
+    import ctypes as C
+
+    import torch
+
+    L = lom.capi.lib()
+    g = lom.VoxelGrid(0.5, 20)
+    good = torch.from_numpy(np.array([[0.1, 0.1, 0.1], [1.1, 0.1, 0.1], [0.2, 0.1, 0.1]], np.float32)).to("cuda:0")
+    bad = torch.from_numpy(np.array([[5.1, 0.1, 0.1], [1e9, 0.0, 0.0], [7.2, 0.1, 0.1]], np.float32)).to("cuda:0")
+    torch.cuda.synchronize()
+    lom.capi.check(L.lom_map_add_points_device_nowait(g.handle, good.data_ptr(), None, 3, 12), g.handle)
+    assert L.lom_map_status(g.handle) == 0
+    assert g.size() == 2 and g.pointCount() == 3
+    assert L.lom_map_add_points_device_nowait(g.handle, bad.data_ptr(), None, 3, 12) == 0        # enqueued
+    assert L.lom_map_status(g.handle) == lom.capi.ERR_RANGE                                     # the verdict, later
+    assert g.size() == 2 and g.pointCount() == 3                                                 # nothing inserted
+    assert L.lom_map_status(g.handle) == 0                                                       # reported once
+    c = g.findMatchingPairs(np.array([[5.1, 0.1, 0.1], [0.1, 0.1, 0.1]], np.float32), lom.Pose3D(), 0.3)
+    assert c["index"][0] == -1 and c["index"][1] >= 0
+    lom.capi.check(L.lom_map_add_points_device_nowait(g.handle, good.data_ptr(), None, 3, 12), g.handle)
+    assert L.lom_map_status(g.handle) == 0 and g.pointCount() == 6
+    # a later insert INTO a voxel whose key an aborted call left behind works like into a new voxel
+    ok2 = torch.from_numpy(np.array([[5.1, 0.1, 0.1]], np.float32)).to("cuda:0")
+    torch.cuda.synchronize()
+    lom.capi.check(L.lom_map_add_points_device(g.handle, ok2.data_ptr(), None, 1, 12), g.handle)
+    assert g.size() == 3 and g.pointCount() == 7
+    xyz, _ = g.getCloud()
+    assert tuple(xyz[-1]) == (np.float32(5.1), np.float32(0.1), np.float32(0.1))

@@ -220,3 +220,45 @@ def test_device_stages_equal_host_stages(lom, monkeypatch):
         if k in (0, 7):
             assert dev.getTempCloud().tobytes() == host.getTempCloud().tobytes()
     assert dev.getFullKeyFrameCloud().tobytes() == host.getFullKeyFrameCloud().tobytes()
+
+
+@pytest.mark.gpu
+def test_frame_handed_back_by_the_device_front_end(lom, monkeypatch):
+    """A frame the device front end cannot decide bit-exactly (an azimuth on a bin boundary: ~1e-11 per point) is
+    redone by the host stages after the device stages have already run.  Forced on every frame here: same
+    results as the pure device path, and the stats say which path a frame took."""
+    boxes = synth.make_boxes()
+    dev = lom.LidarOdometry()
+    redo = lom.LidarOdometry()
+    for k in range(8):
+        f = synth.make_sequence_frame(k, boxes=boxes)
+        dev.processCloud(f)
+        monkeypatch.setenv("LOM_TEST_FORCE_HOST_REDO", "1")
+        redo.processCloud(f)
+        monkeypatch.delenv("LOM_TEST_FORCE_HOST_REDO")
+        assert dev.stats["host_stages"] == 0 and redo.stats["host_stages"] == 1
+        for key in ("planar_points", "filtered_points", "update_points", "matching_points", "outer_iterations", "keyframe_voxels"):
+            assert dev.stats[key] == redo.stats[key], (k, key)
+        a, b = dev.getCurrentPose(), redo.getCurrentPose()
+        assert a.translation.tobytes() == b.translation.tobytes() and a.rotation.tobytes() == b.rotation.tobytes()
+        assert dev.getTempCloud().tobytes() == redo.getTempCloud().tobytes()
+
+
+@pytest.mark.gpu
+def test_lidar_odometry_64_beam_frames_on_the_device_path(lom, oracle):
+    """64-beam frames (~130k points) stay on the device path (multi-item in-kernel scans of the front end and the
+    down-samplers) and follow the oracle: counts equal, poses within the bar."""
+    boxes = synth.make_boxes()
+    g, o = lom.LidarOdometry(), oracle.LidarOdometry(nthreads=8)
+    for k in range(4):
+        f = synth.make_sequence_frame(k, n_beams=64, n_az=2048, boxes=boxes)
+        g.processCloud(f)
+        o.processCloud(f)
+        gs, os_ = g.stats, o.stats
+        assert gs["host_stages"] == 0
+        for key in ("planar_points", "filtered_points", "update_points", "matching_points", "outer_iterations",
+                    "keyframe_voxels"):
+            assert gs[key] == os_[key], (k, key, gs, os_)
+        pg, po = g.getCurrentPose(), o.getCurrentPose()
+        dt, dr = scenes.pose_delta(pg.translation, pg.rotation, po.translation, po.rotation)
+        assert dt < 1e-4 and dr < 1e-4, (k, dt, dr)
