@@ -751,6 +751,25 @@ __device__ __forceinline__ void xword_store(XWord *dst, double v, unsigned long 
     __hip_atomic_store(&dst->check, seq ^ b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// a' + b' after v_permlane{32,16}_swap(a, b): lanes of the lower half (of the wave / of each pair of rows) end with
+// a[lane] + a[partner], lanes of the upper half with b[partner] + b[lane] -- two values folded by one addition
+// (lane mapping verified on the device: tools/microbench/permlane_swap.hip)
+template <int kWidth>
+__device__ __forceinline__ double swap_add(double a, double b)
+{
+    unsigned int alo = (unsigned int)__double2loint(a), ahi = (unsigned int)__double2hiint(a);
+    unsigned int blo = (unsigned int)__double2loint(b), bhi = (unsigned int)__double2hiint(b);
+    if constexpr (kWidth == 32) {
+        const auto lo = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
+        const auto hi = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
+        return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+    } else {
+        const auto lo = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
+        const auto hi = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
+        return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+    }
+}
+
 // k_lm's evaluation epilogue: workgroup reduction of the 28 per-lane sums through LDS in a fixed
 // order, every row total published straight from the lane that holds it (plus the workgroup's
 // slice of k_match's counters), then all workgroups' words gathered and added in workgroup order
@@ -772,14 +791,29 @@ __device__ __forceinline__ void reduce_and_exchange(const double acc[28], double
     RX_STAMP(0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     XWord *mine = set + (size_t)blockIdx.x * kRecWords;
-    // first level in registers: the four lanes of a quad add up (two DPP steps per value), so the
-    // LDS rows are a quarter as long (LDS bandwidth was the bulk of this phase)
+    // Wave level, all in registers, as a reduce-scatter: v_permlane32_swap exchanges the upper half of one
+    // register with the lower half of another, so ONE add folds two values at once -- the lower 32 lanes keep
+    // value k, the upper 32 value k + 14 (28 -> 14 values per lane); v_permlane16_swap does the same between
+    // the 16-lane rows (14 -> 7: row r now holds values k + 7 r); four DPP butterflies finish the 7 values
+    // inside each row.  147 instructions instead of the 168 of a quad pre-sum plus an LDS pass over 28 x 128
+    // doubles, and what goes through LDS is 28 doubles per wave.  The order of the additions is fixed.
+    double s1[14];
 #pragma unroll
-    for (int k = 0; k < 28; k++) {
-        double v = acc[k];
+    for (int k = 0; k < 14; k++) s1[k] = swap_add<32>(acc[k], acc[k + 14]);
+    double s2[7];
+#pragma unroll
+    for (int k = 0; k < 7; k++) {
+        double v = swap_add<16>(s1[k], s1[k + 7]);
         v += dpp_f64<kDppXor1>(v);
         v += dpp_f64<kDppXor2>(v);
-        if ((tid & 3) == 0) s_acc[k * kAccStride + (tid >> 2)] = v;
+        v += dpp_f64<kDppHalfMirror>(v);
+        v += dpp_f64<kDppMirror>(v);
+        s2[k] = v;
+    }
+    if ((lane & 15) == 0) {  // the first lane of row r holds the wave's totals of values 7 r .. 7 r + 6
+        double *dst = s_acc + wave * 32 + 7 * (lane >> 4);
+#pragma unroll
+        for (int k = 0; k < 7; k++) dst[k] = s2[k];
     }
     if (wave == 7) {  // the last wave carries no row of the reduction below (28 rows x 16 lanes = 448)
         unsigned long long c0 = 0, c1 = 0, c2 = 0;
@@ -803,21 +837,12 @@ __device__ __forceinline__ void reduce_and_exchange(const double acc[28], double
         if (lane < 3) xword_store(mine + 28 + lane, (double)(lane == 0 ? c0 : (lane == 1 ? c1 : c2)), seq);
     }
     __syncthreads();
-    // thread (k = tid / 16, j = tid % 16) adds row k's quad sums j, j+16, ... in order
-    {
-        const int k = tid >> 4, j = tid & 15;
+    if (tid < 28) {  // the eight waves' totals, in wave order
         double v = 0.0;
-        if (k < 28) {
-            const double *row = s_acc + k * kAccStride + j;
 #pragma unroll
-            for (int i = 0; i < kEvalThreads / 64; i++) v += row[i * 16];
-        }
-        v += dpp_f64<kDppXor1>(v);  // the 16 lanes of a row: DPP butterflies, no LDS crossbar
-        v += dpp_f64<kDppXor2>(v);
-        v += dpp_f64<kDppHalfMirror>(v);
-        v += dpp_f64<kDppMirror>(v);
+        for (int w = 0; w < kEvalThreads / 64; w++) v += s_acc[w * 32 + tid];
         RX_STAMP(1);
-        if (j == 0 && k < 28) xword_store(mine + k, v, seq);
+        xword_store(mine + tid, v, seq);
     }
     RX_STAMP(2);
     // gather: thread (g = tid / 32, k = tid % 32) takes word k of workgroups 4g .. 4g+3
@@ -830,7 +855,8 @@ __device__ __forceinline__ void reduce_and_exchange(const double acc[28], double
         // Let the words land before the first poll: a poll that comes too early is a wasted memory
         // round trip (and 52 workgroups x 512 lanes of them load the memory side).  Measured on C2:
         // no head start 0.1724 ms per align, s_sleep 8 / 12 / 16 / 20 / 24 -> 0.1668 / 0.1657 / 0.1645 /
-        // 0.1650 / 0.1650.
+        // 0.1650 / 0.1650; again after the round-2 reduction: 4 / 8 / 12 / 16 / 24 -> 0.1580 / 0.1562 / 0.1545 /
+        // 0.1539 / 0.1548.
         __builtin_amdgcn_s_sleep(16);
         const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
         for (;;) {
