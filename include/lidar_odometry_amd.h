@@ -400,6 +400,44 @@ typedef struct {
 int64_t lom_pcd_read(const char *path, float *xyz_out, float *nrm_out, size_t cap, lom_pcd_info *info_or_null);
 const char *lom_pcd_last_error(void);
 
+/* ---- message payloads: pcl::fromROSMsg / pcl::toROSMsg of the node (src/lidar_odometry_node.cpp:47-48,61,71) ---- */
+/* sensor_msgs/msg/PointField datatypes */
+enum {
+    LOM_PF_INT8 = 1, LOM_PF_UINT8 = 2, LOM_PF_INT16 = 3, LOM_PF_UINT16 = 4,
+    LOM_PF_INT32 = 5, LOM_PF_UINT32 = 6, LOM_PF_FLOAT32 = 7, LOM_PF_FLOAT64 = 8
+};
+typedef struct {
+    const char *name;
+    uint32_t offset;
+    uint8_t datatype;
+    uint32_t count;
+} lom_pc2_field;
+/* the members of a sensor_msgs/msg/PointCloud2 the conversion reads; nothing is copied or kept */
+typedef struct {
+    uint32_t height, width;
+    const lom_pc2_field *fields;
+    uint32_t n_fields;
+    uint8_t is_bigendian;
+    uint32_t point_step, row_step;
+    const uint8_t *data;
+    size_t data_bytes;
+} lom_pc2_view;
+/* fromROSMsg into PointCloud<lidar_point::PointXYZIRT>: x y z intensity (FLOAT32), ring (UINT16), time (FLOAT32)
+ * located by name, datatype and count as PCL's FieldMatches does; a field without a match stays zero and sets
+ * bit k of *missing_mask (k in the order above).  Returns width * height (writes at most cap records; out may be
+ * NULL with cap 0), negative = lom_status with lom_pointcloud2_last_error().  `out` may be the pinned buffer of
+ * lom_frontend_stage(). */
+int64_t lom_pointcloud2_unpack(const lom_pc2_view *msg, lom_point_xyzirt *out, size_t cap, uint32_t *missing_mask_or_null);
+/* toROSMsg: field table and point_step of an outgoing cloud (height 1, width n, row_step n * point_step, little
+ * endian); LOM_PC2_XYZ for the keyframe clouds, LOM_PC2_XYZIRT for the deskewed cloud, whose records are
+ * lom_point_xyzirt as they are.  Returns the number of fields. */
+enum { LOM_PC2_XYZ = 0, LOM_PC2_XYZIRT = 1 };
+int lom_pointcloud2_layout(int kind, lom_pc2_field fields_out[6], uint32_t *point_step_out);
+/* payload of a PointCloud<pcl::PointXYZ> message from xyz triples (stride 0 = packed): 16-byte records
+ * {x, y, z, 1.0f}.  Returns the bytes needed / written. */
+int64_t lom_pointcloud2_pack_xyz(const float *xyz, size_t n, size_t stride_bytes, uint8_t *data_out, size_t cap_bytes);
+const char *lom_pointcloud2_last_error(void);
+
 /* ---- normal estimation helper: pcl::NormalEstimation, setRadiusSearch(r), viewpoint (0,0,0) (test/test.cpp:196-205) */
 /* For every point: covariance of all points within `radius` (itself included), eigenvector of the smallest
  * eigenvalue, flipped towards the origin; NaN where fewer than 3 neighbours exist (test.cpp:219-221 drops those

@@ -15,7 +15,7 @@ from . import capi
 from .capi import LomError  # noqa: F401
 
 __all__ = ["Pose3D", "VoxelGrid", "CloudMatcher", "LidarOdometry", "transform_points", "pointTimeNormalize",
-           "transformNonRigid", "rangeFilter", "classify", "loadPCDFile", "estimateNormals", "FrontEnd", "LomError", "capi"]
+           "transformNonRigid", "rangeFilter", "classify", "loadPCDFile", "fromROSMsg", "toROSMsg", "estimateNormals", "FrontEnd", "LomError", "capi"]
 
 
 class Pose3D:
@@ -388,6 +388,57 @@ def loadPCDFile(path, with_normals=False):
     if m < 0:
         raise LomError(int(m), capi.lib().lom_pcd_last_error().decode())
     return (xyz, nrm) if with_normals else xyz
+
+
+# sensor_msgs/msg/PointField datatypes
+PF_INT8, PF_UINT8, PF_INT16, PF_UINT16, PF_INT32, PF_UINT32, PF_FLOAT32, PF_FLOAT64 = range(1, 9)
+
+
+def fromROSMsg(data, fields, width, height=1, point_step=None, row_step=None, is_bigendian=False):
+    """pcl::fromROSMsg into PointCloud<PointXYZIRT> (src/lidar_odometry_node.cpp:47-48) on the members of a
+    sensor_msgs/PointCloud2: `data` the payload bytes, `fields` a list of (name, offset, datatype, count).
+    Returns (POINT_XYZIRT records, names of the point type's fields the message did not carry)."""
+    buf = np.frombuffer(bytes(data), np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data).view(np.uint8).ravel()
+    arr = (capi.Pc2Field * max(len(fields), 1))()
+    for i, (name, offset, datatype, count) in enumerate(fields):
+        arr[i] = capi.Pc2Field(name.encode(), offset, datatype, count)
+    if point_step is None:
+        raise ValueError("point_step is required")
+    view = capi.Pc2View(height, width, arr, len(fields), 1 if is_bigendian else 0, point_step,
+                        row_step if row_step is not None else width * point_step, buf.ctypes.data, buf.size)
+    missing = C.c_uint32(0)
+    n = capi.lib().lom_pointcloud2_unpack(C.byref(view), None, 0, C.byref(missing))
+    if n < 0:
+        raise LomError(int(n), capi.lib().lom_pointcloud2_last_error().decode())
+    out = np.empty(n, capi.POINT_XYZIRT)
+    m = capi.lib().lom_pointcloud2_unpack(C.byref(view), out.ctypes.data, n, None)
+    if m < 0:
+        raise LomError(int(m), capi.lib().lom_pointcloud2_last_error().decode())
+    names = ("x", "y", "z", "intensity", "ring", "time")
+    return out, [names[k] for k in range(6) if missing.value >> k & 1]
+
+
+def toROSMsg(cloud):
+    """pcl::toROSMsg (src/lidar_odometry_node.cpp:61,71): an (n, 3) float32 array becomes a PointCloud<PointXYZ>
+    message, POINT_XYZIRT records a PointCloud<PointXYZIRT> one.  Returns a dict of the PointCloud2 members."""
+    arr = (capi.Pc2Field * 6)()
+    step = C.c_uint32(0)
+    cloud = np.asarray(cloud)
+    if cloud.dtype == capi.POINT_XYZIRT:
+        nf = capi.lib().lom_pointcloud2_layout(1, arr, C.byref(step))
+        data = np.ascontiguousarray(cloud).tobytes()
+        n = len(cloud)
+    else:
+        xyz = np.ascontiguousarray(cloud, np.float32).reshape(-1, 3)
+        nf = capi.lib().lom_pointcloud2_layout(0, arr, C.byref(step))
+        n = len(xyz)
+        out = np.empty(16 * n, np.uint8)
+        w = capi.lib().lom_pointcloud2_pack_xyz(xyz.ctypes.data, n, 12, out.ctypes.data, out.size)
+        if w < 0:
+            raise LomError(int(w), capi.lib().lom_pointcloud2_last_error().decode())
+        data = out.tobytes()
+    return {"height": 1, "width": n, "fields": [(arr[i].name.decode(), arr[i].offset, arr[i].datatype, arr[i].count) for i in range(nf)],
+            "is_bigendian": False, "point_step": step.value, "row_step": step.value * n, "data": data, "is_dense": True}
 
 
 class LidarOdometry:

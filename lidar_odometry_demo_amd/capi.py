@@ -80,6 +80,16 @@ class OdometryFrameStats(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "pad"}
 
 
+class Pc2Field(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("offset", C.c_uint32), ("datatype", C.c_uint8), ("count", C.c_uint32)]
+
+
+class Pc2View(C.Structure):
+    _fields_ = [("height", C.c_uint32), ("width", C.c_uint32), ("fields", C.POINTER(Pc2Field)), ("n_fields", C.c_uint32),
+                ("is_bigendian", C.c_uint8), ("point_step", C.c_uint32), ("row_step", C.c_uint32),
+                ("data", C.c_void_p), ("data_bytes", C.c_size_t)]
+
+
 class PcdInfo(C.Structure):
     _fields_ = [("points", C.c_uint64), ("width", C.c_uint32), ("height", C.c_uint32), ("point_step", C.c_uint32),
                 ("has_normals", C.c_int32), ("data_kind", C.c_int32)]
@@ -113,6 +123,7 @@ EXPORTED = [
     "lom_odometry_keyframe", "lom_odometry_last_error", "lom_pcd_read", "lom_pcd_last_error", "lom_estimate_normals", "lom_frontend_create", "lom_frontend_destroy", "lom_frontend_last_error",
     "lom_frontend_process", "lom_frontend_results", "lom_frontend_wait", "lom_frontend_fetch", "lom_frontend_stream", "lom_frontend_stage", "lom_frontend_done_event", "lom_map_wait_event", "lom_frontend_sequence", "lom_map_status_words", "lom_debug_sinf",
     "lom_voxel_downsample_device_nowait", "lom_map_read_device_words",
+    "lom_pointcloud2_unpack", "lom_pointcloud2_layout", "lom_pointcloud2_pack_xyz", "lom_pointcloud2_last_error",
 ]
 
 _lib = None
@@ -261,6 +272,12 @@ def lib():
     L.lom_pcd_read.argtypes = [C.c_char_p, vp, vp, C.c_size_t, C.POINTER(PcdInfo)]
     L.lom_pcd_read.restype = C.c_int64
     L.lom_pcd_last_error.restype = C.c_char_p
+    L.lom_pointcloud2_unpack.argtypes = [C.POINTER(Pc2View), vp, C.c_size_t, C.POINTER(C.c_uint32)]
+    L.lom_pointcloud2_unpack.restype = C.c_int64
+    L.lom_pointcloud2_layout.argtypes = [C.c_int, C.POINTER(Pc2Field), C.POINTER(C.c_uint32)]
+    L.lom_pointcloud2_pack_xyz.argtypes = [vp, C.c_size_t, C.c_size_t, vp, C.c_size_t]
+    L.lom_pointcloud2_pack_xyz.restype = C.c_int64
+    L.lom_pointcloud2_last_error.restype = C.c_char_p
     _lib = L
     return L
 
