@@ -142,8 +142,13 @@ int lom_voxel_downsample_device_nowait(lom_map *workspace, float voxel_size, con
  * sequence number of the last call that failed (range / a grid time-out) and the sequence number of the
  * handle's last call -- a word equal to *seq means that call failed */
 int lom_map_status_words(lom_map *m, const uint32_t **d_range, const uint32_t **d_grid, uint32_t *seq);
-/* one synchronisation for up to 32 device words of any handle on this handle's stream */
+/* up to 32 device words of any handle, read behind everything enqueued so far on this handle's stream: one
+ * single-wave kernel that stores them into the handle's pinned block, no copy engine.  _begin enqueues it,
+ * _end waits for its words (one read in flight per handle; work enqueued between the two does not delay it);
+ * lom_map_read_device_words is both. */
 int lom_map_read_device_words(lom_map *m, const uint32_t *const *d_ptrs, int n, uint32_t *out);
+int lom_map_read_device_words_begin(lom_map *m, const uint32_t *const *d_ptrs, int n);
+int lom_map_read_device_words_end(lom_map *m, uint32_t *out);
 /* lom_transform_points on the device (same f32 arithmetic): packed 12-byte output in the handle's
  * staging buffers, valid until the next upload / host-input call on this handle. */
 int lom_transform_points_device(lom_map *m, const lom_pose *pose, const float *d_xyz, const float *d_nrm, size_t n,

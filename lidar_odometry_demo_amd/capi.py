@@ -122,7 +122,7 @@ EXPORTED = [
     "lom_odometry_destroy", "lom_odometry_process_cloud", "lom_odometry_get_pose", "lom_odometry_get_stats", "lom_odometry_get_temp_cloud", "lom_odometry_debug_set_state",
     "lom_odometry_keyframe", "lom_odometry_last_error", "lom_pcd_read", "lom_pcd_last_error", "lom_estimate_normals", "lom_frontend_create", "lom_frontend_destroy", "lom_frontend_last_error",
     "lom_frontend_process", "lom_frontend_results", "lom_frontend_wait", "lom_frontend_fetch", "lom_frontend_stream", "lom_frontend_stage", "lom_frontend_done_event", "lom_map_wait_event", "lom_frontend_sequence", "lom_map_status_words", "lom_debug_sinf",
-    "lom_voxel_downsample_device_nowait", "lom_map_read_device_words",
+    "lom_voxel_downsample_device_nowait", "lom_map_read_device_words", "lom_map_read_device_words_begin", "lom_map_read_device_words_end",
     "lom_pointcloud2_unpack", "lom_pointcloud2_layout", "lom_pointcloud2_pack_xyz", "lom_pointcloud2_last_error",
 ]
 
@@ -267,6 +267,8 @@ def lib():
     L.lom_voxel_downsample_device_nowait.argtypes = [vp, C.c_float, vp, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(vp),
                                                      C.POINTER(vp), C.POINTER(vp)]
     L.lom_map_read_device_words.argtypes = [vp, C.POINTER(vp), C.c_int, C.POINTER(C.c_uint32)]
+    L.lom_map_read_device_words_begin.argtypes = [vp, C.POINTER(vp), C.c_int]
+    L.lom_map_read_device_words_end.argtypes = [vp, C.POINTER(C.c_uint32)]
     L.lom_estimate_normals.argtypes = [vp, C.c_size_t, C.c_size_t, C.c_float, C.c_int, vp, vp]
     L.lom_estimate_normals.restype = C.c_int64
     L.lom_pcd_read.argtypes = [C.c_char_p, vp, vp, C.c_size_t, C.POINTER(PcdInfo)]

@@ -40,6 +40,7 @@ constexpr int kMatchThreads = 256;             // 4 waves
 constexpr int kMatchG = 16;                    // lanes per query: four queries per wave
 constexpr int kGroupsPerBlock = kMatchThreads / kMatchG;
 constexpr int kMatchMinWaves = 7;              // waves per SIMD the register budget is held to (72 VGPRs)
+constexpr uint32_t kMatchSmallMax = 16384;   // queries up to which k_match runs its four-loads-in-flight variant
 constexpr int kEvalThreads = 512;
 
 // what k_match leaves behind for the evaluations of one outer iteration: source point,
@@ -200,7 +201,7 @@ __global__ __launch_bounds__(kMatchThreads, kMinWaves) void k_match(MapView map,
                                                          unsigned long long *__restrict__ stamps = nullptr,
                                                          const AlignState *state = nullptr)
 {
-    static_assert(G == 16 && kU == 1, "one query per 16-lane DPP row");
+    static_assert(G == 16 && kU >= 1 && kU <= 4, "one query per 16-lane DPP row");
     struct {
         double R[9], t[3];
         float max_sq;
@@ -385,26 +386,41 @@ __global__ __launch_bounds__(kMatchThreads, kMinWaves) void k_match(MapView map,
         const uint32_t *pref = s_pref[grp];
         // lane l takes candidates l, l + 16, ... of the flattened sequence (scan order: strict
         // minimum per lane, first wins)
-        for (uint32_t c = gl; c < T; c += G) {
-            // smallest b with pref[b] > c
-            uint32_t b = 0;
-            b += (pref[b + 15] <= c) ? 16u : 0u;
-            b += (pref[b + 7] <= c) ? 8u : 0u;
-            b += (pref[b + 3] <= c) ? 4u : 0u;
-            b += (pref[b + 1] <= c) ? 2u : 0u;
-            b += (pref[b] <= c) ? 1u : 0u;
-            const uint32_t pi = s_base[grp][b] + c;
-            const float *vp = map.pts + (size_t)pi * 3;
-            const float ax = vp[0], ay = vp[1], az = vp[2];
-            const float dx = qx - ax, dy = qy - ay, dz = qz - az;
-            const float d2 = dx * dx + (dy * dy + dz * dz);  // voxel_grid.h:184 f32 squaredNorm
-            if (d2 < P.max_sq && d2 < best) {                // :186-187 strict
-                best = d2;
-                best_c = c;
-                best_idx = pi;
-                bpx = ax;
-                bpy = ay;
-                bpz = az;
+        // kU candidates per lane and trip: their loads are in flight together (a scan with few waves per SIMD --
+        // a small cloud -- is a chain of round trips otherwise); compared in ascending order, as one by one
+        for (uint32_t c0 = gl; c0 < T; c0 += G * kU) {
+            float ax[kU], ay[kU], az[kU];
+            uint32_t pi[kU];
+#pragma unroll
+            for (int u = 0; u < kU; u++) {
+                const uint32_t c = c0 + (uint32_t)(u * G);
+                const uint32_t cs = (kU == 1 || c < T) ? c : c0;  // beyond the end: re-read this lane's first (not compared)
+                // smallest b with pref[b] > cs
+                uint32_t b = 0;
+                b += (pref[b + 15] <= cs) ? 16u : 0u;
+                b += (pref[b + 7] <= cs) ? 8u : 0u;
+                b += (pref[b + 3] <= cs) ? 4u : 0u;
+                b += (pref[b + 1] <= cs) ? 2u : 0u;
+                b += (pref[b] <= cs) ? 1u : 0u;
+                pi[u] = s_base[grp][b] + cs;
+                const float *vp = map.pts + (size_t)pi[u] * 3;
+                ax[u] = vp[0];
+                ay[u] = vp[1];
+                az[u] = vp[2];
+            }
+#pragma unroll
+            for (int u = 0; u < kU; u++) {
+                const uint32_t c = c0 + (uint32_t)(u * G);
+                const float dx = qx - ax[u], dy = qy - ay[u], dz = qz - az[u];
+                const float d2 = dx * dx + (dy * dy + dz * dz);  // voxel_grid.h:184 f32 squaredNorm
+                if ((kU == 1 || c < T) && d2 < P.max_sq && d2 < best) {  // :186-187 strict
+                    best = d2;
+                    best_c = c;
+                    best_idx = pi[u];
+                    bpx = ax[u];
+                    bpy = ay[u];
+                    bpz = az[u];
+                }
             }
         }
         LOM_STAMP(4);  // candidates scanned
@@ -1672,17 +1688,26 @@ static int launch_match(ScanCtx &c, const float t[3], const float q[4], float ma
         // <16,2,8> and <16,4,8> spill and lose; 8 lanes per query 12.3 / 44.1, 32 lanes 10.1 / 44.5.
         // Round 2 (query preparation split over the row's lanes, -15 % VALU instructions): 70 VGPRs, so 7 waves
         // per SIMD and a grid capped at one resident round of that; held to 64 VGPRs it spills 4 and loses
-        // (C2 / C3 in the loop: 8.5 / 33.3 us at 7 waves, 9.3 / 36.5 at 8)
-        if (chained)
-            hipLaunchKernelGGL((k_match<kMatchG, 1, kMatchMinWaves, false, true>), dim3(c.match_blocks), dim3(kMatchThreads), 0,
-                               m->stream, view_of(m), c.d_src, c.stride, c.n, P, (int32_t *)m->scan_idx.p,
-                               (MatchRec *)m->scan_on.p, (QStat *)nullptr, d_block_counters(m),
-                               (unsigned long long *)nullptr, (const AlignState *)m->align_state.p);
+        // (C2 / C3 in the loop: 8.5 / 33.3 us at 7 waves, 9.3 / 36.5 at 8).  Four candidate loads in flight per lane
+        // (<16,4,4>, 74 VGPRs) on C2 / C3: 9.3 / 39.3 us -- it pays only where few waves share a SIMD (C5's 8k-point
+        // matching cloud: frame 0.329 -> 0.295 ms; eight in flight: the same).
+        // A small cloud leaves the SIMDs with two or three waves each: nothing hides a round trip, so each lane keeps
+        // four candidate loads in flight (<16,4,4>: 128-VGPR budget, one resident round up to 16384 queries).
+        auto launch = [&](auto kernel, QStat *st, const AlignState *as) {
+            hipLaunchKernelGGL(kernel, dim3(c.match_blocks), dim3(kMatchThreads), 0, m->stream, view_of(m), c.d_src, c.stride,
+                               c.n, P, (int32_t *)m->scan_idx.p, (MatchRec *)m->scan_on.p, st, d_block_counters(m),
+                               (unsigned long long *)nullptr, as);
+        };
+        const bool small = c.n <= kMatchSmallMax;
+        QStat *st = stats ? (QStat *)m->scan_stats.p : (QStat *)nullptr;
+        if (chained && small)
+            launch(k_match<kMatchG, 4, 4, false, true>, (QStat *)nullptr, (const AlignState *)m->align_state.p);
+        else if (chained)
+            launch(k_match<kMatchG, 1, kMatchMinWaves, false, true>, (QStat *)nullptr, (const AlignState *)m->align_state.p);
+        else if (small)
+            launch(k_match<kMatchG, 4, 4>, st, (const AlignState *)nullptr);
         else
-            hipLaunchKernelGGL((k_match<kMatchG, 1, kMatchMinWaves>), dim3(c.match_blocks), dim3(kMatchThreads), 0, m->stream,
-                               view_of(m), c.d_src, c.stride, c.n, P, (int32_t *)m->scan_idx.p,
-                               (MatchRec *)m->scan_on.p, stats ? (QStat *)m->scan_stats.p : (QStat *)nullptr,
-                               d_block_counters(m), (unsigned long long *)nullptr, (const AlignState *)nullptr);
+            launch(k_match<kMatchG, 1, kMatchMinWaves>, st, (const AlignState *)nullptr);
         LOM_HIP(m, hipGetLastError());
         if (m->profiling) LOM_HIP(m, hipEventRecord(e1, m->stream));
     }

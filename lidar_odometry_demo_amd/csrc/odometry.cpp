@@ -449,15 +449,22 @@ public:
     }
     void submit(std::function<int()> f)
     {
+        bool asleep;
         {
             std::lock_guard<std::mutex> g(m_);
             job_ = std::move(f);
             busy_ = true;
+            asleep = asleep_;
         }
-        cv_.notify_all();
+        running_.store(true, std::memory_order_release);
+        posted_.store(true, std::memory_order_release);
+        if (asleep) cv_.notify_all();
     }
     int join()  // status of the last job (LOM_OK if none is pending)
     {
+        // a job is a few tens of microseconds of enqueues and two looks at the device: watch for its end
+        // before going to sleep on it (a futex wake-up costs as much as the job)
+        for (int i = 0; i < kSpins && running_.load(std::memory_order_acquire); i++) __builtin_ia32_pause();
         std::unique_lock<std::mutex> g(m_);
         cv_.wait(g, [this] { return !busy_; });
         const int rc = rc_;
@@ -470,8 +477,16 @@ private:
     {
         std::unique_lock<std::mutex> g(m_);
         for (;;) {
+            // frames that follow each other closely find the worker awake: it watches for the next job for
+            // about half a millisecond before it sleeps on the condition variable (10 Hz input: asleep 99 %)
+            g.unlock();
+            for (int i = 0; i < kSpins && !posted_.load(std::memory_order_acquire); i++) __builtin_ia32_pause();
+            g.lock();
+            asleep_ = true;
             cv_.wait(g, [this] { return stop_ || (busy_ && job_); });
+            asleep_ = false;
             if (stop_) return;
+            posted_.store(false, std::memory_order_relaxed);
             std::function<int()> f = std::move(job_);
             job_ = nullptr;
             g.unlock();
@@ -479,13 +494,16 @@ private:
             g.lock();
             rc_ = rc;
             busy_ = false;
+            running_.store(false, std::memory_order_release);
             cv_.notify_all();
         }
     }
+    const int kSpins = getenv("LOM_HELPER_SPINS") ? atoi(getenv("LOM_HELPER_SPINS")) : 20000;  // x one `pause` (about 25 ns)
     std::mutex m_;
     std::condition_variable cv_;
     std::function<int()> job_;
-    bool busy_ = false, stop_ = false;
+    std::atomic<bool> posted_{false}, running_{false};  // a job waits for the worker / is not finished yet
+    bool busy_ = false, stop_ = false, asleep_ = false;
     int rc_ = LOM_OK;
     std::thread th_;
 };
@@ -663,6 +681,32 @@ struct FrameInputs {  // what the stages before the align leave in HBM for it an
     const float *d_down = nullptr, *d_down_n = nullptr;  // keyframe_downsampler.getCloud()            :37-38,42,69
     const float *d_match = nullptr;                      // matching_downsampler.getCloudWithoutNormals() :46-47,50
     int64_t nd = 0, nm = 0;
+    // device stages: the update cloud's size and verdict are still on their way (a read-back is enqueued on this
+    // workspace); collect_update() waits for them.  Returns LOM_OK / LOM_ERR_RANGE / LOM_ERR_HIP.
+    lom_map *pending_update = nullptr;
+    uint32_t pending_seq = 0;
+    int collect_update(const char **error_out)
+    {
+        if (!pending_update) return LOM_OK;
+        lom_map *m = pending_update;
+        pending_update = nullptr;
+        uint32_t w[3] = {0, 0, 0};
+        const int rc = lom_map_read_device_words_end(m, w);
+        if (rc != LOM_OK) {
+            if (error_out) *error_out = lom_last_error(m);
+            return rc;
+        }
+        if (w[2] == pending_seq) {
+            if (error_out) *error_out = "a workgroup timed out waiting for the others of its grid";
+            return LOM_ERR_HIP;
+        }
+        if (w[1] == pending_seq) {
+            if (error_out) *error_out = "coordinate / voxel_size out of range or not finite";
+            return LOM_ERR_RANGE;
+        }
+        nd = w[0];
+        return LOM_OK;
+    }
 };
 
 int fail_map(lom_odometry *o, int rc, lom_map *m)
@@ -745,55 +789,79 @@ int stages_on_device(lom_odometry *o, const lom_point_xyzirt *pts, size_t n, con
     uint32_t bound = 0;
     lom_frontend_results(o->frontend, &d_fx, &d_fn, &d_fe, &bound);
     // front end and down-samplers share a stream of their own: all of this runs beside the previous frame's
-    // keyframe update (whose input is the OTHER update workspace)
-    if ((rc = lom_voxel_downsample_device_nowait(o->update_ds, o->cfg.keyframe_update_voxel_size, d_fx, d_fn, bound, d_fe + 1,
-                                                 12, &in.d_down, &in.d_down_n, &d_nd)) != LOM_OK)
-        return fail_map(o, rc, o->update_ds);
-    if (o->keyframe_has_voxels &&
-        (rc = lom_voxel_downsample_device_nowait(o->matching_ds, o->cfg.keyframe_matching_voxel_size, d_fx, nullptr, bound,
-                                                 d_fe + 1, 12, &in.d_match, nullptr, &d_nm)) != LOM_OK)
-        return fail_map(o, rc, o->matching_ds);
-    // the one synchronisation before the align: counts and verdicts of everything enqueued above
+    // keyframe update (whose input is the OTHER update workspace).  Only the matching cloud is on the way to the
+    // align; the keyframe-update cloud is enqueued behind the read-back the align waits for, runs beside the
+    // align's first kernels, and its count and verdict are collected after the align (pending_update).
     const uint32_t *ptrs[12];
-    uint32_t seq_u = 0, seq_m = 0, got[12];
+    uint32_t seq_u = 0, seq_m = 0, got[12] = {0};
     const uint32_t *u_range = nullptr, *u_grid = nullptr, *m_range = nullptr, *m_grid = nullptr;
-    lom_map_status_words(o->update_ds, &u_range, &u_grid, &seq_u);
-    lom_map_status_words(o->matching_ds, &m_range, &m_grid, &seq_m);
     int k = 0;
     ptrs[k++] = d_fe;      // 0 planar
     ptrs[k++] = d_fe + 1;  // 1 filtered
     ptrs[k++] = d_fe + 4;  // 2 front end: redo on the host (sequence number of the frame)
     ptrs[k++] = d_fe + 5;  // 3 front end: grid error
-    ptrs[k++] = d_nd;      // 4
-    ptrs[k++] = u_range;   // 5
-    ptrs[k++] = u_grid;    // 6
-    if (d_nm) {
-        ptrs[k++] = d_nm;     // 7
-        ptrs[k++] = m_range;  // 8
-        ptrs[k++] = m_grid;   // 9
+    auto update_downsample = [&]() -> int {
+        const int r = lom_voxel_downsample_device_nowait(o->update_ds, o->cfg.keyframe_update_voxel_size, d_fx, d_fn, bound,
+                                                         d_fe + 1, 12, &in.d_down, &in.d_down_n, &d_nd);
+        if (r != LOM_OK) return fail_map(o, r, o->update_ds);
+        lom_map_status_words(o->update_ds, &u_range, &u_grid, &seq_u);
+        return LOM_OK;
+    };
+    lom_map *reader = o->update_ds;
+    if (o->keyframe_has_voxels) {
+        if ((rc = lom_voxel_downsample_device_nowait(o->matching_ds, o->cfg.keyframe_matching_voxel_size, d_fx, nullptr, bound,
+                                                     d_fe + 1, 12, &in.d_match, nullptr, &d_nm)) != LOM_OK)
+            return fail_map(o, rc, o->matching_ds);
+        lom_map_status_words(o->matching_ds, &m_range, &m_grid, &seq_m);
+        ptrs[k++] = d_nm;     // 4
+        ptrs[k++] = m_range;  // 5
+        ptrs[k++] = m_grid;   // 6
+        reader = o->matching_ds;
+        if ((rc = lom_map_read_device_words_begin(reader, ptrs, k)) != LOM_OK) return fail_map(o, rc, reader);
+        if ((rc = update_downsample()) != LOM_OK) return rc;
+        const uint32_t *late[3] = {d_nd, u_range, u_grid};
+        if ((rc = lom_map_read_device_words_begin(o->update_ds, late, 3)) != LOM_OK) return fail_map(o, rc, o->update_ds);
+        in.pending_update = o->update_ds;
+        in.pending_seq = seq_u;
+    } else {  // first frame: the keyframe is initialised from the update cloud, there is no align
+        if ((rc = update_downsample()) != LOM_OK) return rc;
+        ptrs[k++] = d_nd;     // 4
+        ptrs[k++] = u_range;  // 5
+        ptrs[k++] = u_grid;   // 6
+        if ((rc = lom_map_read_device_words_begin(reader, ptrs, k)) != LOM_OK) return fail_map(o, rc, reader);
     }
-    if ((rc = lom_map_read_device_words(o->update_ds, ptrs, k, got)) != LOM_OK) return fail_map(o, rc, o->update_ds);
+    // the one wait before the align: counts and verdicts of what it needs
+    if ((rc = lom_map_read_device_words_end(reader, got)) != LOM_OK) return fail_map(o, rc, reader);
     tm.lap("stages (device)");
     // the previous frame's keyframe update must be through before this frame touches the keyframe handle.  Its
     // failure is reported here, by the call after the one it belongs to; poses / keyframe stay as they were.
     if ((rc = o->settle()) != LOM_OK) return rc;
     tm.lap("settle");
     const uint32_t fe_seq = lom_frontend_sequence(o->frontend);
-    if (got[3] == fe_seq || got[6] == seq_u || (d_nm && got[9] == seq_m)) {
+    const uint32_t seq_ds = o->keyframe_has_voxels ? seq_m : seq_u;
+    if (got[3] == fe_seq || got[6] == seq_ds) {
+        (void)in.collect_update(nullptr);
         o->error = "a workgroup timed out waiting for the others of its grid";
         return LOM_ERR_HIP;
     }
     // an azimuth on a bin boundary, or an organised cloud beyond the buffers (LOM_TEST_FORCE_HOST_REDO: tests take
     // this path on every frame)
-    if (got[2] == fe_seq || getenv("LOM_TEST_FORCE_HOST_REDO")) return 1;
-    if (got[5] == seq_u || (d_nm && got[8] == seq_m)) {
+    if (got[2] == fe_seq || getenv("LOM_TEST_FORCE_HOST_REDO")) {
+        (void)in.collect_update(nullptr);
+        return 1;
+    }
+    if (got[5] == seq_ds) {
+        (void)in.collect_update(nullptr);
         o->error = "coordinate / voxel_size out of range or not finite";
         return LOM_ERR_RANGE;
     }
     cur.planar_points = got[0];
     cur.filtered_points = got[1];
-    in.nd = got[4];
-    in.nm = d_nm ? got[7] : 0;
+    if (o->keyframe_has_voxels) {
+        in.nm = got[4];
+    } else {
+        in.nd = got[4];
+    }
     return LOM_OK;
 }
 
@@ -826,13 +894,13 @@ int lom_odometry_process_cloud(lom_odometry *o, const lom_point_xyzirt *pts, siz
             cur.host_stages = 1;
         }
         if (rc != LOM_OK) return rc;
-        cur.update_points = in.nd;
         // :40 keyframe_.size() == 0 -- known on the host: the keyframe is empty until a frame has put voxels
         // into it (nd > 0 points always create at least one), and stays non-empty unless a cleanup empties it
         if (!o->keyframe_has_voxels) {  // :40-44 init keyframe
             if ((rc = lom_map_add_points_device(o->keyframe, in.d_down, in.d_down_n, (size_t)in.nd, 12)) != LOM_OK)
                 return fail_map(o, rc, o->keyframe);
             cur.initialised_keyframe = 1;
+            cur.update_points = in.nd;
             cur.keyframe_voxels = lom_map_size(o->keyframe);
             o->keyframe_has_voxels = cur.keyframe_voxels > 0;
             o->last = cur;
@@ -843,8 +911,19 @@ int lom_odometry_process_cloud(lom_odometry *o, const lom_point_xyzirt *pts, siz
         lom_pose_compose(&o->current, &relative, &guess);  // :51
         lom_align_stats ast;
         if ((rc = lom_match_align_device(o->keyframe, in.d_match, (size_t)in.nm, 12, guess.t, guess.q, result.t, result.q,
-                                         &ast)) != LOM_OK)  // :49-51
+                                         &ast)) != LOM_OK) {  // :49-51
+            (void)in.collect_update(nullptr);
             return fail_map(o, rc, o->keyframe);
+        }
+        {   // the update cloud was down-sampled beside the align: its size and verdict (long since on the host)
+            const char *why = nullptr;
+            const int rcu = in.collect_update(&why);
+            if (rcu != LOM_OK) {
+                o->error = why ? why : "keyframe-update down-sampling failed";
+                return rcu;
+            }
+        }
+        cur.update_points = in.nd;
         cur.outer_iterations = ast.outer_iterations;
         cur.queries = ast.queries;
         o->queries_total += ast.queries;

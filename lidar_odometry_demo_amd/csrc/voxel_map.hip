@@ -815,11 +815,75 @@ static int ensure_slabs(lom_map *m, uint64_t want)
     return LOM_OK;
 }
 
+// Device words -> host in ONE launch and no copy engine: a single wave stores {word, call tag} pairs as
+// 64-bit system-scope words into the handle's coherent pinned block; the host watches the tags.  (A
+// hipMemcpyAsync per word is a 4 us blit kernel each plus its enqueue: ten of them per frame of the streaming
+// path were 15 % of its kernel time.)  The stream is in order, so the words arriving also says that
+// everything enqueued before them is through.
+struct WordPtrs {
+    const uint32_t *p[32];
+};
+
+__global__ __launch_bounds__(64) void k_gather_words(WordPtrs w, int n, unsigned long long *host_out, uint32_t tag)
+{
+    const int i = (int)threadIdx.x;
+    if (i >= n) return;
+    const uint32_t v = __hip_atomic_load(w.p[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(host_out + i, (unsigned long long)v | ((unsigned long long)tag << 32), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+constexpr size_t kWordsOffset = 512;  // of h_report / d_report: [0, 256) AlignReport, [512, 768) these words
+
+int gather_words_begin(lom_map *m, const uint32_t *const *ptrs, int n)
+{
+    m->words_pending = 0;
+    if (n <= 0) return LOM_OK;
+    WordPtrs w;
+    for (int i = 0; i < 32; i++) w.p[i] = i < n ? ptrs[i] : nullptr;
+    if (++m->words_tag == 0) m->words_tag = 1;  // the block starts zeroed: 0 is "nothing yet"
+    hipLaunchKernelGGL(k_gather_words, dim3(1), dim3(64), 0, m->stream, w, n,
+                       reinterpret_cast<unsigned long long *>((char *)m->d_report + kWordsOffset), m->words_tag);
+    LOM_HIP(m, hipGetLastError());
+    m->words_pending = n;
+    return LOM_OK;
+}
+
+int gather_words_end(lom_map *m, uint32_t *out)
+{
+    const int n = m->words_pending;
+    const uint32_t tag = m->words_tag;
+    m->words_pending = 0;
+    volatile unsigned long long *hw = reinterpret_cast<volatile unsigned long long *>((char *)m->h_report + kWordsOffset);
+    uint64_t spins = 0;
+    for (int i = 0; i < n; i++) {
+        while ((uint32_t)(hw[i] >> 32) != tag) {
+            __builtin_ia32_pause();
+            if ((++spins & 0x3FFF) != 0) continue;
+            const hipError_t e = hipStreamQuery(m->stream);
+            if (e == hipSuccess) {
+                if ((uint32_t)(hw[i] >> 32) == tag) break;
+                return set_error(m, LOM_ERR_HIP, "device words did not arrive");
+            }
+            if (e != hipErrorNotReady) return set_error(m, LOM_ERR_HIP, "stream failed while reading device words", e);
+        }
+        out[i] = (uint32_t)hw[i];
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    return LOM_OK;
+}
+
+int gather_words(lom_map *m, const uint32_t *const *ptrs, int n, uint32_t *out)
+{
+    const int rc = gather_words_begin(m, ptrs, n);
+    return rc != LOM_OK ? rc : gather_words_end(m, out);
+}
+
 int read_words(lom_map *m, int first, int n)
 {
-    LOM_HIP(m, hipMemcpyAsync(m->h_flags, d_word(m, first), (size_t)n * 4, hipMemcpyDeviceToHost, m->stream));
-    LOM_HIP(m, hipStreamSynchronize(m->stream));
-    return LOM_OK;
+    const uint32_t *ptrs[32];
+    for (int i = 0; i < n; i++) ptrs[i] = d_word(m, first + i);
+    return gather_words(m, ptrs, n, m->h_flags);
 }
 
 // grow-only scratch that is kept at rest (every byte == fill) between calls: a fresh allocation is
@@ -1079,7 +1143,7 @@ int lom_map_create(float voxel_size, size_t max_points, size_t capacity_hint, in
         (e = hipHostGetDevicePointer((void **)&m->d_mail, m->h_mail, 0)) != hipSuccess ||
         (e = hipHostMalloc(&m->h_cmd, 256, hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess ||
         (e = hipHostGetDevicePointer(&m->d_cmd, m->h_cmd, 0)) != hipSuccess ||
-        (e = hipHostMalloc(&m->h_report, 256, hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess ||
+        (e = hipHostMalloc(&m->h_report, 1024, hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess ||
         (e = hipHostGetDevicePointer(&m->d_report, m->h_report, 0)) != hipSuccess) {
         set_error(nullptr, LOM_ERR_HIP, "handle setup", e);
         lom_map_destroy(m);
@@ -1088,7 +1152,7 @@ int lom_map_create(float voxel_size, size_t max_points, size_t capacity_hint, in
     m->stream = m->own_stream;
     std::memset(m->h_mail, 0, 64 * 32 * sizeof(double));
     std::memset(m->h_cmd, 0, 256);
-    std::memset(m->h_report, 0, 256);
+    std::memset(m->h_report, 0, 1024);
     m->min_cap = next_pow2(4ull * std::max<size_t>(capacity_hint, 256));
     // status / counter words (256 bytes) + the block aggregates of the single-pass kernels (256 x 2 granules)
     int rc = ensure(m, m->scr[S_MISC], 256 + 256 * 2 * sizeof(Granule));
@@ -1525,10 +1589,24 @@ int lom_map_read_device_words(lom_map *m, const uint32_t *const *d_ptrs, int n, 
     if (!m || !d_ptrs || !out || n < 0 || n > 32) return LOM_ERR_ARG;
     LOM_HIP(m, hipSetDevice(m->device));
     for (int i = 0; i < n; i++)
-        LOM_HIP(m, hipMemcpyAsync(m->h_flags + i, d_ptrs[i], 4, hipMemcpyDeviceToHost, m->stream));
-    LOM_HIP(m, hipStreamSynchronize(m->stream));
-    for (int i = 0; i < n; i++) out[i] = m->h_flags[i];
-    return LOM_OK;
+        if (!d_ptrs[i]) return LOM_ERR_ARG;
+    return gather_words(m, d_ptrs, n, out);
+}
+
+int lom_map_read_device_words_begin(lom_map *m, const uint32_t *const *d_ptrs, int n)
+{
+    if (!m || !d_ptrs || n < 0 || n > 32) return LOM_ERR_ARG;
+    LOM_HIP(m, hipSetDevice(m->device));
+    for (int i = 0; i < n; i++)
+        if (!d_ptrs[i]) return LOM_ERR_ARG;
+    return gather_words_begin(m, d_ptrs, n);
+}
+
+int lom_map_read_device_words_end(lom_map *m, uint32_t *out)
+{
+    if (!m || !out) return LOM_ERR_ARG;
+    LOM_HIP(m, hipSetDevice(m->device));
+    return gather_words_end(m, out);
 }
 
 int lom_upload_points(lom_map *m, const float *xyz, const float *nrm, size_t n, size_t stride, const float **d_xyz_out,
