@@ -226,8 +226,9 @@ __global__ __launch_bounds__(kMatchThreads, kMinWaves) void k_match(MapView map,
     LOM_STAMP(0);
     constexpr int kGroups = kMatchThreads / G;
     constexpr int kSets = 2;                  // neighbours b = gl (set 0) and 16 + gl (set 1) < 27
-    __shared__ uint32_t s_pref[kGroups][32];  // inclusive prefix of scanned counts, scan order; padded with total
-    __shared__ uint32_t s_base[kGroups][32];  // slab * K - exclusive prefix: point index = s_base[b] + c
+    // per neighbour b in scan order: .x inclusive prefix of the scanned counts (entries >= 27: never reached),
+    // .y slab * K - exclusive prefix, so that candidate c of the flattened sequence is point .y + c
+    __shared__ uint2 s_pb[kGroups][32];
     __shared__ uint32_t s_cnt[kGroups][4];
     __shared__ double s_pose[12];             // [component][R row (3), t]: what the component lanes multiply with
     __shared__ float s_gap[kGroups][12];      // per query [axis][to voxel i-1, 0, to voxel i+1]: squared pruning gaps
@@ -359,10 +360,8 @@ __global__ __launch_bounds__(kMatchThreads, kMinWaves) void k_match(MapView map,
             const uint32_t inc = row_scan_inclusive(scan_cnt[0] | (scan_cnt[1] << 16));
             const uint32_t last = row_last(inc);
             const uint32_t tot0 = last & 0xFFFFu, inc0 = inc & 0xFFFFu, inc1 = tot0 + (inc >> 16);
-            s_pref[grp][gl] = inc0;
-            s_pref[grp][gl + G] = (gl + G < 27) ? inc1 : 0xFFFFFFFFu;
-            s_base[grp][gl] = slab[0] * map.K - (inc0 - scan_cnt[0]);
-            s_base[grp][gl + G] = slab[1] * map.K - (inc1 - scan_cnt[1]);
+            s_pb[grp][gl] = make_uint2(inc0, slab[0] * map.K - (inc0 - scan_cnt[0]));
+            s_pb[grp][gl + G] = make_uint2((gl + G < 27) ? inc1 : 0xFFFFFFFFu, slab[1] * map.K - (inc1 - scan_cnt[1]));
             T = tot0 + (last >> 16);
         } else {
             uint32_t run = 0;
@@ -370,8 +369,7 @@ __global__ __launch_bounds__(kMatchThreads, kMinWaves) void k_match(MapView map,
             for (int s = 0; s < kSets; s++) {
                 const uint32_t inc = row_scan_inclusive(scan_cnt[s]);
                 const int b = gl + s * G;
-                s_pref[grp][b] = (b < 27) ? run + inc : 0xFFFFFFFFu;
-                s_base[grp][b] = slab[s] * map.K - (run + inc - scan_cnt[s]);
+                s_pb[grp][b] = make_uint2((b < 27) ? run + inc : 0xFFFFFFFFu, slab[s] * map.K - (run + inc - scan_cnt[s]));
                 run += row_last(inc);
             }
             T = run;
@@ -383,7 +381,11 @@ __global__ __launch_bounds__(kMatchThreads, kMinWaves) void k_match(MapView map,
         LOM_STAMP(3);  // prefix in LDS
         float best = INFINITY, bpx = 0.f, bpy = 0.f, bpz = 0.f;
         uint32_t best_c = 0xFFFFFFFFu, best_idx = 0;
-        const uint32_t *pref = s_pref[grp];
+        // Binary search of a candidate's voxel: the first two of its five levels compare with three values read once
+        // per query, the last reads the entry and its successor's base together -- three dependent LDS round trips
+        // per candidate instead of six.
+        const uint2 *pb = s_pb[grp];
+        const uint32_t p7 = pb[7].x, p15 = pb[15].x, p23 = pb[23].x;
         // lane l takes candidates l, l + 16, ... of the flattened sequence (scan order: strict
         // minimum per lane, first wins)
         // kU candidates per lane and trip: their loads are in flight together (a scan with few waves per SIMD --
@@ -395,14 +397,14 @@ __global__ __launch_bounds__(kMatchThreads, kMinWaves) void k_match(MapView map,
             for (int u = 0; u < kU; u++) {
                 const uint32_t c = c0 + (uint32_t)(u * G);
                 const uint32_t cs = (kU == 1 || c < T) ? c : c0;  // beyond the end: re-read this lane's first (not compared)
-                // smallest b with pref[b] > cs
-                uint32_t b = 0;
-                b += (pref[b + 15] <= cs) ? 16u : 0u;
-                b += (pref[b + 7] <= cs) ? 8u : 0u;
-                b += (pref[b + 3] <= cs) ? 4u : 0u;
-                b += (pref[b + 1] <= cs) ? 2u : 0u;
-                b += (pref[b] <= cs) ? 1u : 0u;
-                pi[u] = s_base[grp][b] + cs;
+                // smallest b with prefix[b] > cs
+                uint32_t b = (p15 <= cs) ? 16u : 0u;
+                b += ((b ? p23 : p7) <= cs) ? 8u : 0u;
+                b += (pb[b + 3].x <= cs) ? 4u : 0u;
+                b += (pb[b + 1].x <= cs) ? 2u : 0u;
+                const uint2 e = pb[b];
+                const uint32_t next_base = pb[b + 1].y;
+                pi[u] = ((e.x <= cs) ? next_base : e.y) + cs;
                 const float *vp = map.pts + (size_t)pi[u] * 3;
                 ax[u] = vp[0];
                 ay[u] = vp[1];
@@ -1690,7 +1692,9 @@ static int launch_match(ScanCtx &c, const float t[3], const float q[4], float ma
         // per SIMD and a grid capped at one resident round of that; held to 64 VGPRs it spills 4 and loses
         // (C2 / C3 in the loop: 8.5 / 33.3 us at 7 waves, 9.3 / 36.5 at 8).  Four candidate loads in flight per lane
         // (<16,4,4>, 74 VGPRs) on C2 / C3: 9.3 / 39.3 us -- it pays only where few waves share a SIMD (C5's 8k-point
-        // matching cloud: frame 0.329 -> 0.295 ms; eight in flight: the same).
+        // matching cloud: frame 0.329 -> 0.295 ms; eight in flight: the same).  With the candidate search at three
+        // LDS round trips instead of six (C2 / C3 / C4 8.3 / 33.9 / 58.1 -> 7.7 / 31.0 / 54.3 us, 68 VGPRs) two loads
+        // in flight fit the 7-wave budget (66 VGPRs): C2 the same, C3 31.6 -> 30.3 us.
         // A small cloud leaves the SIMDs with two or three waves each: nothing hides a round trip, so each lane keeps
         // four candidate loads in flight (<16,4,4>: 128-VGPR budget, one resident round up to 16384 queries).
         auto launch = [&](auto kernel, QStat *st, const AlignState *as) {
@@ -1703,11 +1707,11 @@ static int launch_match(ScanCtx &c, const float t[3], const float q[4], float ma
         if (chained && small)
             launch(k_match<kMatchG, 4, 4, false, true>, (QStat *)nullptr, (const AlignState *)m->align_state.p);
         else if (chained)
-            launch(k_match<kMatchG, 1, kMatchMinWaves, false, true>, (QStat *)nullptr, (const AlignState *)m->align_state.p);
+            launch(k_match<kMatchG, 2, kMatchMinWaves, false, true>, (QStat *)nullptr, (const AlignState *)m->align_state.p);
         else if (small)
             launch(k_match<kMatchG, 4, 4>, st, (const AlignState *)nullptr);
         else
-            launch(k_match<kMatchG, 1, kMatchMinWaves>, st, (const AlignState *)nullptr);
+            launch(k_match<kMatchG, 2, kMatchMinWaves>, st, (const AlignState *)nullptr);
         LOM_HIP(m, hipGetLastError());
         if (m->profiling) LOM_HIP(m, hipEventRecord(e1, m->stream));
     }
