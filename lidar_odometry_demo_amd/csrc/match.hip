@@ -794,7 +794,8 @@ __device__ __forceinline__ double swap_add(double a, double b)
 // into s_tot[0..30] -- bitwise the same on every workgroup.  Only the first wave may read s_tot
 // afterwards (no workgroup barrier behind the final sum); the caller's next __syncthreads()
 // releases s_acc / s_part for the following evaluation.
-//   s_acc: dynamic LDS, 28 rows of kAccStride doubles;  s_part: kEvalThreads doubles.
+//   s_acc: 32 doubles per wave;  s_part: kT doubles (kT = threads of the workgroup).
+template <int kT>
 __device__ __forceinline__ void reduce_and_exchange(const double acc[28], double *s_acc, double *s_part,
                                                     const uint32_t *__restrict__ block_counters,
                                                     uint32_t n_match_blocks, XWord *set, uint32_t nb,
@@ -833,7 +834,7 @@ __device__ __forceinline__ void reduce_and_exchange(const double acc[28], double
 #pragma unroll
         for (int k = 0; k < 7; k++) dst[k] = s2[k];
     }
-    if (wave == 7) {  // the last wave carries no row of the reduction below (28 rows x 16 lanes = 448)
+    if (wave == kT / 64 - 1) {  // the workgroup's slice of k_match's counters
         unsigned long long c0 = 0, c1 = 0, c2 = 0;
         if (n_match_blocks) {
             const uint32_t chunk = (n_match_blocks + gridDim.x - 1) / gridDim.x;
@@ -858,18 +859,22 @@ __device__ __forceinline__ void reduce_and_exchange(const double acc[28], double
     if (tid < 28) {  // the eight waves' totals, in wave order
         double v = 0.0;
 #pragma unroll
-        for (int w = 0; w < kEvalThreads / 64; w++) v += s_acc[w * 32 + tid];
+        for (int w = 0; w < kT / 64; w++) v += s_acc[w * 32 + tid];
         RX_STAMP(1);
         xword_store(mine + tid, v, seq);
     }
     RX_STAMP(2);
-    // gather: thread (g = tid / 32, k = tid % 32) takes word k of workgroups 4g .. 4g+3
+    // gather: thread (g = tid / 32, k = tid % 32) takes word k of workgroups kPer g .. kPer g + kPer - 1
     {
+        constexpr int kPer = (int)kMaxLmBlocks / (kT / 32);
         const int k = tid & 31, g = tid >> 5;
-        unsigned long long vb[4] = {0, 0, 0, 0};
-        bool ok[4];
+        unsigned long long vb[kPer];
+        bool ok[kPer];
 #pragma unroll
-        for (int u = 0; u < 4; u++) ok[u] = (k >= 31) || ((uint32_t)(g * 4 + u) >= nb);
+        for (int u = 0; u < kPer; u++) {
+            vb[u] = 0;
+            ok[u] = (k >= 31) || ((uint32_t)(g * kPer + u) >= nb);
+        }
         // Let the words land before the first poll: a poll that comes too early is a wasted memory
         // round trip (and 52 workgroups x 512 lanes of them load the memory side).  Measured on C2:
         // no head start 0.1724 ms per align, s_sleep 8 / 12 / 16 / 20 / 24 -> 0.1668 / 0.1657 / 0.1645 /
@@ -878,18 +883,18 @@ __device__ __forceinline__ void reduce_and_exchange(const double acc[28], double
         __builtin_amdgcn_s_sleep(16);
         const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
         for (;;) {
-            unsigned long long cb[4];
+            unsigned long long cb[kPer];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
+            for (int u = 0; u < kPer; u++) {
                 if (!ok[u]) {
-                    const XWord *w = set + (size_t)(g * 4 + u) * kRecWords + k;
+                    const XWord *w = set + (size_t)(g * kPer + u) * kRecWords + k;
                     vb[u] = __hip_atomic_load(&w->bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     cb[u] = __hip_atomic_load(&w->check, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
             bool all = true;
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
+            for (int u = 0; u < kPer; u++) {
                 if (!ok[u]) ok[u] = (cb[u] ^ vb[u]) == seq;
                 all = all && ok[u];
             }
@@ -902,16 +907,16 @@ __device__ __forceinline__ void reduce_and_exchange(const double acc[28], double
         }
         double part = 0.0;
 #pragma unroll
-        for (int u = 0; u < 4; u++) part += __longlong_as_double((long long)vb[u]);  // absent workgroups add +0.0
+        for (int u = 0; u < kPer; u++) part += __longlong_as_double((long long)vb[u]);  // absent workgroups add +0.0
         s_part[tid] = part;
     }
     RX_STAMP(3);
     __syncthreads();
-    if (tid < 64) {  // the first wave adds the 16 partial sums in order and keeps the totals to itself
+    if (tid < 64) {  // the first wave adds the kT / 32 partial sums in order and keeps the totals to itself
         if (tid < 31) {
             double v = 0.0;
 #pragma unroll
-            for (int g = 0; g < kEvalThreads / 32; g++) v += s_part[g * 32 + tid];
+            for (int g = 0; g < kT / 32; g++) v += s_part[g * 32 + tid];
             s_tot[tid] = v;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1406,7 +1411,8 @@ __device__ __forceinline__ void accumulate_all(const MatchRec *__restrict__ rec,
     }
 }
 
-__global__ __launch_bounds__(kEvalThreads) void k_lm(const MatchRec *__restrict__ rec, uint32_t n, AlignState *state,
+template <int kT>
+__global__ __launch_bounds__(kT) void k_lm(const MatchRec *__restrict__ rec, uint32_t n, AlignState *state,
                                                      LmInit init, int first_outer,
                                                      const uint32_t *__restrict__ block_counters,
                                                      uint32_t n_match_blocks, XWord *xrec,
@@ -1416,9 +1422,9 @@ __global__ __launch_bounds__(kEvalThreads) void k_lm(const MatchRec *__restrict_
                                                      unsigned long long *dbg_stamps, P2pArgs px,
                                                      double *dbg_trace)
 {
-    extern __shared__ __attribute__((aligned(16))) double s_acc[];
+    __shared__ double s_acc[(kT / 64) * 32];  // the waves' totals of one evaluation
     __shared__ double s_tot[kRecWords];
-    __shared__ double s_part[kEvalThreads];
+    __shared__ double s_part[kT];
     __shared__ double s_x[7];
     __shared__ LmState s_lm;
     __shared__ int s_action, s_failed;
@@ -1463,7 +1469,7 @@ __global__ __launch_bounds__(kEvalThreads) void k_lm(const MatchRec *__restrict_
         LM_STAMP(1);
         seq++;
         XWord *set = xrec + (size_t)(seq & 1) * kMaxLmBlocks * kRecWords;
-        reduce_and_exchange(acc, s_acc, s_part, block_counters, counters_from, set, nb, seq, timeout_ticks,
+        reduce_and_exchange<kT>(acc, s_acc, s_part, block_counters, counters_from, set, nb, seq, timeout_ticks,
                             s_tot, &s_failed, (dbg_stamps && first_outer && ev == 1) ? dbg_stamps + 32 : nullptr);
         counters_from = 0;
         if (px.nranks > 1 && wave == 0 && !s_failed) {
@@ -1738,8 +1744,6 @@ static int eval_kernel_attrs(lom_map *m)
                                    (int)kEvalLdsBytes));
     LOM_HIP(m, hipFuncSetAttribute(reinterpret_cast<const void *>(k_eval_server),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEvalLdsBytes));
-    LOM_HIP(m, hipFuncSetAttribute(reinterpret_cast<const void *>(k_lm), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)kEvalLdsBytes));
     m->eval_attr_set = true;
     return LOM_OK;
 }
@@ -1924,17 +1928,28 @@ void p2p_detach(lom_map *m)
 constexpr int kDeviceLoopGaveUp = 100;
 
 // k_lm's workgroups wait for each other inside the kernel, so all of them must be resident at once:
-// the grid never exceeds what the occupancy query admits on this device
-static int lm_block_limit(lom_map *m, uint32_t *out)
+// the grid never exceeds what the occupancy query admits on this device.
+// Workgroup size: 512 threads, or 256 for clouds that 64 such workgroups cover (one point per lane either way):
+// the wave-level reduction is bound by the CU's f64 issue rate, and four waves -- one per SIMD -- are through it
+// in half the time of eight; the final sum adds 8 partial sums instead of 16.
+constexpr uint32_t kLmSmallThreads = 256;
+static bool lm_small(uint32_t n) { return n <= kMaxLmBlocks * kLmSmallThreads; }
+
+static int lm_block_limit(lom_map *m, bool small, uint32_t *out)
 {
-    if (!m->lm_max_blocks) {
+    uint32_t &cached = small ? m->lm_max_blocks_small : m->lm_max_blocks;
+    if (!cached) {
         int per_cu = 0, cus = 0;
-        LOM_HIP(m, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(k_lm),
-                                                                kEvalThreads, kEvalLdsBytes));
+        if (small)
+            LOM_HIP(m, hipOccupancyMaxActiveBlocksPerMultiprocessor(
+                           &per_cu, reinterpret_cast<const void *>(k_lm<(int)kLmSmallThreads>), (int)kLmSmallThreads, 0));
+        else
+            LOM_HIP(m, hipOccupancyMaxActiveBlocksPerMultiprocessor(
+                           &per_cu, reinterpret_cast<const void *>(k_lm<kEvalThreads>), kEvalThreads, 0));
         LOM_HIP(m, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, m->device));
-        m->lm_max_blocks = (uint32_t)std::max(1, per_cu * cus);
+        cached = (uint32_t)std::max(1, per_cu * cus);
     }
-    *out = m->lm_max_blocks;
+    *out = cached;
     return LOM_OK;
 }
 
@@ -1962,8 +1977,11 @@ static int align_chained(lom_map *m, const char *d_src, size_t n, size_t stride,
     for (int a = 0; a < 3; a++) init.prior_b[a] = (double)guess_t[a];  // :153
     init.max_sq = 0.3f * 0.3f;                                          // :139, voxel_grid.h:215
     uint32_t nb_limit = 0;
-    if ((rc = lm_block_limit(m, &nb_limit)) != LOM_OK) return rc;
-    const uint32_t nb = std::min(std::min(eval_grid(std::max<uint32_t>(c.n, 1u)), kMaxLmBlocks), nb_limit);
+    const bool small = lm_small(c.n);
+    const uint32_t lm_threads = small ? kLmSmallThreads : (uint32_t)kEvalThreads;
+    if ((rc = lm_block_limit(m, small, &nb_limit)) != LOM_OK) return rc;
+    const uint32_t nb =
+        std::min(std::min(std::max(1u, (c.n + lm_threads - 1) / lm_threads), kMaxLmBlocks), nb_limit);
     double *d_trace = nullptr;  // lom_debug_lm_trace: k_lm of outer iteration `trace_outer` records its evaluations
     if (trace_out) {
         if ((rc = ensure(m, m->dbg_trace, 201 * 8)) != LOM_OK) return rc;
@@ -1989,11 +2007,18 @@ static int align_chained(lom_map *m, const char *d_src, size_t n, size_t stride,
         const double t_l = now_s();
         m->lm_seq += 8;  // a solve spends at most 5 evaluations
         px.set_base = (int)((m->lm_launches++ & 1ull) * 2ull);  // same launch count on every rank
-        hipLaunchKernelGGL(k_lm, dim3(nb), dim3(kEvalThreads), kEvalLdsBytes, m->stream,
-                           (const MatchRec *)m->scan_on.p, c.n, (AlignState *)m->align_state.p, init, i == 0 ? 1 : 0,
-                           (const uint32_t *)d_block_counters(m), c.match_blocks, (XWord *)m->xrec.p, m->lm_seq,
-                           reinterpret_cast<AlignReport *>(m->d_report), seq0 + (unsigned long long)i + 1,
-                           server_timeout_ticks(), dbg, px, (d_trace && i == trace_outer) ? d_trace : (double *)nullptr);
+        auto launch = [&](auto kernel) {
+            hipLaunchKernelGGL(kernel, dim3(nb), dim3(lm_threads), 0, m->stream, (const MatchRec *)m->scan_on.p, c.n,
+                               (AlignState *)m->align_state.p, init, i == 0 ? 1 : 0,
+                               (const uint32_t *)d_block_counters(m), c.match_blocks, (XWord *)m->xrec.p, m->lm_seq,
+                               reinterpret_cast<AlignReport *>(m->d_report), seq0 + (unsigned long long)i + 1,
+                               server_timeout_ticks(), dbg, px,
+                               (d_trace && i == trace_outer) ? d_trace : (double *)nullptr);
+        };
+        if (small)
+            launch(k_lm<(int)kLmSmallThreads>);
+        else
+            launch(k_lm<kEvalThreads>);
         LOM_HIP(m, hipGetLastError());
         if (m->profiling && c.prof_used) {
             LOM_HIP(m, hipEventRecord(m->prof_events[(size_t)(c.prof_used - 1) * 3 + 2], m->stream));
