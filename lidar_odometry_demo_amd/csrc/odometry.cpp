@@ -498,7 +498,7 @@ private:
             cv_.notify_all();
         }
     }
-    const int kSpins = getenv("LOM_HELPER_SPINS") ? atoi(getenv("LOM_HELPER_SPINS")) : 20000;  // x one `pause` (about 25 ns)
+    static constexpr int kSpins = 20000;  // x one `pause` (about 25 ns)
     std::mutex m_;
     std::condition_variable cv_;
     std::function<int()> job_;
