@@ -5,6 +5,8 @@
 //   Pose3D        reference src/pose_3d.h:10-59
 //   VoxelGrid     reference src/voxel_grid.h:17-257
 //   CloudMatcher  reference src/cloud_matcher.h:13-17
+//   CloudTransformer, CloudClassifier, utils::pointTimeNormalize, utils::rangeFilter  reference src/utils/*.h
+//   LidarOdometry reference src/lidar_odometry.h:20-85
 // so that reference src/lidar_odometry.cpp compiles against it with a type
 // alias or two.  No Eigen / PCL / Ceres / robin_map needed:
 // the point structs below have the memory layout of pcl::PointXYZ (16 bytes)
@@ -293,6 +295,16 @@ struct CloudTransformer {
                              &out->points.data()->x, nullptr, sizeof(PointXYZ));
         return out;
     }
+    // transformNonRigid (cloud_transform.h:15-40): the deskew, on the host (lom::LidarOdometry runs it on the device)
+    static PointCloud<lom_point_xyzirt>::Ptr transformNonRigid(const PointCloud<lom_point_xyzirt> &input,
+                                                              const Pose3D &start_pose, const Pose3D &end_pose)
+    {
+        auto out = std::make_shared<PointCloud<lom_point_xyzirt>>();
+        out->points.resize(input.points.size());
+        const lom_pose s = start_pose.c(), e = end_pose.c();
+        lom_transform_non_rigid(input.points.data(), input.points.size(), &s, &e, out->points.data());
+        return out;
+    }
     static PointCloud<PointNormal>::Ptr transformWithNormals(const PointCloud<PointNormal> &input, const Pose3D &pose)
     {
         auto out = std::make_shared<PointCloud<PointNormal>>();
@@ -303,6 +315,76 @@ struct CloudTransformer {
                              sizeof(PointNormal), &out->points.data()->x, &out->points.data()->normal_x,
                              sizeof(PointNormal));
         return out;
+    }
+};
+
+// ---- the stages processCloud runs before the align (src/lidar_odometry.cpp:25-35), host functions of the library
+// with the reference's names: a caller that keeps the reference's own orchestration but not PCL uses these;
+// lom::LidarOdometry below runs the same stages on the device.
+using PointXYZIRT = lom_point_xyzirt;  // lidar_point::PointXYZIRT (src/lidar_point_type.h:13-31), same 32-byte layout
+
+namespace utils {
+// utils::pointTimeNormalize (src/utils/point_time_normalize.h:15-39)
+inline PointCloud<PointXYZIRT>::Ptr pointTimeNormalize(const PointCloud<PointXYZIRT> &input)
+{
+    auto out = std::make_shared<PointCloud<PointXYZIRT>>();
+    out->points.resize(input.points.size());
+    lom_point_time_normalize(input.points.data(), input.points.size(), out->points.data());
+    return out;
+}
+// utils::rangeFilter (src/utils/range_filter.h:13-28) for the two point types the reference's data flow holds
+inline PointCloud<PointNormal>::Ptr rangeFilter(const PointCloud<PointNormal> &input, float min_range, float max_range)
+{
+    const size_t n = input.points.size();
+    std::vector<float> xyz(3 * n + 3), nrm(3 * n + 3), fx(3 * n + 3), fn(3 * n + 3);
+    for (size_t i = 0; i < n; i++) {
+        const PointNormal &p = input.points[i];
+        xyz[3 * i] = p.x, xyz[3 * i + 1] = p.y, xyz[3 * i + 2] = p.z;
+        nrm[3 * i] = p.normal_x, nrm[3 * i + 1] = p.normal_y, nrm[3 * i + 2] = p.normal_z;
+    }
+    const size_t m = lom_range_filter(xyz.data(), nrm.data(), n, min_range, max_range, fx.data(), fn.data());
+    auto out = std::make_shared<PointCloud<PointNormal>>();
+    out->points.resize(m);
+    for (size_t i = 0; i < m; i++) {
+        PointNormal &p = out->points[i];
+        p.x = fx[3 * i], p.y = fx[3 * i + 1], p.z = fx[3 * i + 2];
+        p.normal_x = fn[3 * i], p.normal_y = fn[3 * i + 1], p.normal_z = fn[3 * i + 2];
+    }
+    return out;
+}
+inline PointCloud<PointXYZ>::Ptr rangeFilter(const PointCloud<PointXYZ> &input, float min_range, float max_range)
+{
+    const size_t n = input.points.size();
+    std::vector<float> xyz(3 * n + 3), fx(3 * n + 3);
+    for (size_t i = 0; i < n; i++) xyz[3 * i] = input.points[i].x, xyz[3 * i + 1] = input.points[i].y, xyz[3 * i + 2] = input.points[i].z;
+    const size_t m = lom_range_filter(xyz.data(), nullptr, n, min_range, max_range, fx.data(), nullptr);
+    auto out = std::make_shared<PointCloud<PointXYZ>>();
+    out->points.reserve(m);
+    for (size_t i = 0; i < m; i++) out->points.emplace_back(fx[3 * i], fx[3 * i + 1], fx[3 * i + 2]);
+    return out;
+}
+}  // namespace utils
+
+// CloudClassifier::classify (src/utils/cloud_classifier.h:19-168): {planar points with normals, unclassified points}.
+// The second cloud is returned with the reference's SIZE only (default points): its one caller drops it
+// (src/lidar_odometry.cpp:33), and the library does not build it.
+struct CloudClassifier {
+    static std::pair<PointCloud<PointNormal>::Ptr, PointCloud<PointXYZIRT>::Ptr> classify(const PointCloud<PointXYZIRT> &input)
+    {
+        const size_t n = input.points.size();
+        std::vector<float> xyz(3 * n + 3), nrm(3 * n + 3);
+        size_t unclassified = 0;
+        const size_t m = lom_cloud_classify(input.points.data(), n, xyz.data(), nrm.data(), &unclassified, nullptr);
+        auto planar = std::make_shared<PointCloud<PointNormal>>();
+        planar->points.resize(m);
+        for (size_t i = 0; i < m; i++) {
+            PointNormal &p = planar->points[i];
+            p.x = xyz[3 * i], p.y = xyz[3 * i + 1], p.z = xyz[3 * i + 2];
+            p.normal_x = nrm[3 * i], p.normal_y = nrm[3 * i + 1], p.normal_z = nrm[3 * i + 2];
+        }
+        auto rest = std::make_shared<PointCloud<PointXYZIRT>>();
+        rest->points.resize(unclassified);
+        return {planar, rest};
     }
 };
 

@@ -207,6 +207,110 @@ static void LidarOdometry_RoomSequence()
     EXPECT(sparse->size() > 1000 && full->size() >= sparse->size());
 }
 
+// The reference's own orchestration (src/lidar_odometry.cpp:22-77), written with the mirror's classes exactly as the
+// reference writes it with PCL / Eigen ones -- what a maintainer who keeps lidar_odometry.cpp compiles.  Its poses must
+// equal lom::LidarOdometry's (which runs the same stages on the device) frame by frame.
+struct ReferenceStyleOdometry {
+    LidarOdometry::Params config_;
+    VoxelGrid keyframe_;
+    Pose3D previous_transform_, current_transform_;
+    explicit ReferenceStyleOdometry(const LidarOdometry::Params &c)
+        : config_(c), keyframe_(c.keyframe_voxel_size, c.keyframe_max_points_cnt)
+    {
+    }
+    void processCloud(const LidarOdometry::CloudType &input_cloud)
+    {
+        auto time_normalized_cloud = utils::pointTimeNormalize(input_cloud);                                       // :25
+        const auto relative_transform = previous_transform_.relativeTo(current_transform_);                         // :27
+        previous_transform_ = current_transform_;                                                                   // :28
+        auto deskewed_input_cloud =
+            CloudTransformer::transformNonRigid(*time_normalized_cloud, relative_transform.inverse(), Pose3D());  // :30
+        auto [planar_cloud, unclassified_cloud] = CloudClassifier::classify(*deskewed_input_cloud);                // :33
+        auto filtered_planar_cloud =
+            utils::rangeFilter(*planar_cloud, config_.lidar_min_range, config_.lidar_max_range);                   // :35
+        VoxelGrid keyframe_downsampler(config_.keyframe_update_voxel_size, 1);                                      // :37
+        keyframe_downsampler.addCloud(*filtered_planar_cloud);                                                      // :38
+        if (keyframe_.size() == 0) {                                                                                // :40
+            keyframe_.addCloud(*keyframe_downsampler.getCloud());                                                   // :42
+            return;
+        }
+        VoxelGrid matching_downsampler(config_.keyframe_matching_voxel_size, 1);                                    // :46
+        PointCloud<PointXYZ> filtered_xyz;
+        for (const auto &p : filtered_planar_cloud->points) filtered_xyz.points.emplace_back(p.x, p.y, p.z);
+        matching_downsampler.addCloudWithoutNormals(filtered_xyz);                                                  // :47
+        CloudMatcher matcher;                                                                                       // :49
+        const auto guess = current_transform_.compose(relative_transform);                                          // :51
+        auto result = matcher.align(keyframe_, *matching_downsampler.getCloudWithoutNormals(), guess);              // :50
+        current_transform_ = result;  // (the divergence guard of :53-63 never fires in this sequence)             // :65
+        keyframe_.radiusCleanup(current_transform_.translation, config_.keyframe_cleanup_range);                    // :67
+        auto update_cloud = CloudTransformer::transformWithNormals(*keyframe_downsampler.getCloud(), current_transform_);  // :69
+        keyframe_.addCloud(*update_cloud);                                                                          // :70
+    }
+};
+
+static LidarOdometry::CloudType room_frame(float sx)
+{
+    const float half[2] = {24.f, 17.f};
+    const float zlo = -2.f, zhi = 7.f;
+    LidarOdometry::CloudType cloud;
+    for (int ring = 0; ring < 16; ring++) {
+        const float el = (-15.f + 2.f * (float)ring) * 3.14159265358979f / 180.f;
+        for (int a = 0; a < 900; a++) {
+            const float az = (float)a * (2.f * 3.14159265358979f / 900.f);
+            const float d[3] = {std::cos(el) * std::cos(az), -std::cos(el) * std::sin(az), std::sin(el)};
+            float t = 1e9f;
+            if (d[0] > 1e-6f) t = std::fmin(t, (half[0] - sx) / d[0]);
+            if (d[0] < -1e-6f) t = std::fmin(t, (-half[0] - sx) / d[0]);
+            if (d[1] > 1e-6f) t = std::fmin(t, half[1] / d[1]);
+            if (d[1] < -1e-6f) t = std::fmin(t, -half[1] / d[1]);
+            if (d[2] > 1e-6f) t = std::fmin(t, zhi / d[2]);
+            if (d[2] < -1e-6f) t = std::fmin(t, zlo / d[2]);
+            lom_point_xyzirt p{};
+            p.x = t * d[0];
+            p.y = t * d[1];
+            p.z = t * d[2];
+            p.intensity = 1.f;
+            p.ring = (uint16_t)ring;
+            p.time = (float)a / 900.f * 0.1f;
+            cloud.points.push_back(p);
+        }
+    }
+    return cloud;
+}
+
+static void ReferenceOrchestration_EqualsLidarOdometry()
+{
+    LidarOdometry::Params params;
+    LidarOdometry odometry(params);
+    ReferenceStyleOdometry by_hand(params);
+    for (int f = 0; f < 5; f++) {
+        const auto cloud = room_frame(0.1f * (float)f);
+        // the stages on their own: sizes and value ranges
+        auto normalized = utils::pointTimeNormalize(cloud);
+        EXPECT(normalized->size() == cloud.size());
+        float tmin = 1e9f, tmax = -1e9f;
+        for (const auto &p : normalized->points) tmin = std::fmin(tmin, p.time), tmax = std::fmax(tmax, p.time);
+        EXPECT(tmin == 0.f && tmax == 1.f);
+        auto [planar, rest] = CloudClassifier::classify(*normalized);
+        EXPECT(planar->size() > 2000 && planar->size() + rest->size() <= 16 * 900);
+        for (size_t i = 0; i < planar->size(); i += 97) {
+            const auto &p = planar->points[i];
+            const float nn = p.normal_x * p.normal_x + p.normal_y * p.normal_y + p.normal_z * p.normal_z;
+            EXPECT(std::fabs(nn - 1.f) < 1e-4f);
+        }
+        auto near = utils::rangeFilter(*planar, 0.f, 10.f);
+        EXPECT(near->size() > 0 && near->size() < planar->size());
+        for (const auto &p : near->points) EXPECT(p.x * p.x + p.y * p.y + p.z * p.z <= 100.f);
+        // the two orchestrations
+        odometry.processCloud(cloud);
+        by_hand.processCloud(cloud);
+        const Pose3D a = odometry.getCurrentPose(), b = by_hand.current_transform_;
+        for (int k = 0; k < 3; k++) EXPECT(a.translation.v[k] == b.translation.v[k]);
+        for (int k = 0; k < 4; k++) EXPECT(a.rotation.q[k] == b.rotation.q[k]);
+    }
+    EXPECT((size_t)odometry.lastFrameStats().keyframe_voxels == by_hand.keyframe_.size());
+}
+
 int main()
 {
     try {
@@ -216,6 +320,7 @@ int main()
         CloudTransformer_RigidTransform();
         CloudMatcher_MatchingTest();
         LidarOdometry_RoomSequence();
+        ReferenceOrchestration_EqualsLidarOdometry();
     } catch (const lom::Error &e) {
         std::printf("lom::Error %d: %s\n", e.code, e.what());
         return 2;
