@@ -835,7 +835,10 @@ int stages_on_device(lom_odometry *o, const lom_point_xyzirt *pts, size_t n, con
     tm.lap("stages (device)");
     // the previous frame's keyframe update must be through before this frame touches the keyframe handle.  Its
     // failure is reported here, by the call after the one it belongs to; poses / keyframe stay as they were.
-    if ((rc = o->settle()) != LOM_OK) return rc;
+    if ((rc = o->settle()) != LOM_OK) {
+        (void)in.collect_update(nullptr);
+        return rc;
+    }
     tm.lap("settle");
     const uint32_t fe_seq = lom_frontend_sequence(o->frontend);
     const uint32_t seq_ds = o->keyframe_has_voxels ? seq_m : seq_u;
