@@ -200,6 +200,25 @@ def test_lm_trace_synth(lom, oracle):
     assert trace == []
 
 
+def test_lm_trace_c2_size(lom, oracle):
+    """The same, evaluation by evaluation, on a C2-sized cloud (26.6k points: 512-thread workgroups of the
+    device-resident solve and the two-loads-in-flight search; the cases above run the 256-thread / four-loads
+    variants that clouds of up to 16,384 points take)."""
+    c = scenes.synth_case(16, 1800, 200_000)
+    assert len(c["scan"]) > 16384
+    g, og = lom.VoxelGrid(0.5, 20), oracle.VoxelGrid(0.5, 20)
+    g.addCloud(c["map_xyz"], c["map_nrm"])
+    og.addCloud(c["map_xyz"], c["map_nrm"])
+    guess = lom.Pose3D((0.05, -0.04, 0.02), scenes.angle_axis_q(0.0175, (0, 0, 1)))
+    om = oracle.CloudMatcher(nthreads=8)
+    ref = om.align(og, c["scan"], oracle.Pose3D(guess.translation, guess.rotation))
+    for outer in (0, 2, om.stats["outer_iterations"] - 1):
+        pose, st, ne = _trace_vs_oracle(lom, oracle, g, og, c["scan"], guess, outer, "C2-size")
+    _assert_lm_numbers(st, om.stats)
+    dt, dr = scenes.pose_delta(pose.translation, pose.rotation, ref.translation, ref.rotation)
+    assert dt < 1e-4 and dr < 1e-4
+
+
 def _assert_lm_numbers(st, ost):
     """Recorded iterations, evaluated points, last step norm and final cost of the whole align against
     the oracle's Ceres restatement."""
