@@ -516,7 +516,8 @@ struct EvalCmd {  // pinned host memory, written by the host only
 constexpr unsigned int kCmdEval = 1, kCmdStop = 2;
 constexpr int kPublishPlain = 0, kPublishHost = 1, kPublishDevice = 2;
 constexpr int kPairsAhead = 5;  // (k_match, k_lm) pairs enqueued before the host looks at a report
-constexpr uint32_t kMaxLmBlocks = 64;  // workgroups of k_lm (one lane of a wave watches each record)
+constexpr uint32_t kMaxLmBlocks = 64;    // workgroups of k_lm (one lane of a wave watches each record)
+constexpr uint32_t kMaxLmBlocksBig = 128;  // ... of its variant for large clouds; also the size of an exchange set
 
 // cloud_matcher.cpp:48-102 for one correspondence, accumulated into the 28 sums
 __device__ __forceinline__ void accumulate_point(const float4 ra, const float4 rb, const float4 rc,
@@ -795,7 +796,7 @@ __device__ __forceinline__ double swap_add(double a, double b)
 // afterwards (no workgroup barrier behind the final sum); the caller's next __syncthreads()
 // releases s_acc / s_part for the following evaluation.
 //   s_acc: 32 doubles per wave;  s_part: kT doubles (kT = threads of the workgroup).
-template <int kT>
+template <int kT, int kBlocks>
 __device__ __forceinline__ void reduce_and_exchange(const double acc[28], double *s_acc, double *s_part,
                                                     const uint32_t *__restrict__ block_counters,
                                                     uint32_t n_match_blocks, XWord *set, uint32_t nb,
@@ -866,7 +867,7 @@ __device__ __forceinline__ void reduce_and_exchange(const double acc[28], double
     RX_STAMP(2);
     // gather: thread (g = tid / 32, k = tid % 32) takes word k of workgroups kPer g .. kPer g + kPer - 1
     {
-        constexpr int kPer = (int)kMaxLmBlocks / (kT / 32);
+        constexpr int kPer = kBlocks / (kT / 32);
         const int k = tid & 31, g = tid >> 5;
         unsigned long long vb[kPer];
         bool ok[kPer];
@@ -1411,7 +1412,7 @@ __device__ __forceinline__ void accumulate_all(const MatchRec *__restrict__ rec,
     }
 }
 
-template <int kT>
+template <int kT, int kBlocks = (int)kMaxLmBlocks>
 __global__ __launch_bounds__(kT) void k_lm(const MatchRec *__restrict__ rec, uint32_t n, AlignState *state,
                                                      LmInit init, int first_outer,
                                                      const uint32_t *__restrict__ block_counters,
@@ -1468,8 +1469,8 @@ __global__ __launch_bounds__(kT) void k_lm(const MatchRec *__restrict__ rec, uin
         accumulate_all(rec, n, first, step, ra, rb, rc, s_x, acc);
         LM_STAMP(1);
         seq++;
-        XWord *set = xrec + (size_t)(seq & 1) * kMaxLmBlocks * kRecWords;
-        reduce_and_exchange<kT>(acc, s_acc, s_part, block_counters, counters_from, set, nb, seq, timeout_ticks,
+        XWord *set = xrec + (size_t)(seq & 1) * kMaxLmBlocksBig * kRecWords;
+        reduce_and_exchange<kT, kBlocks>(acc, s_acc, s_part, block_counters, counters_from, set, nb, seq, timeout_ticks,
                             s_tot, &s_failed, (dbg_stamps && first_outer && ev == 1) ? dbg_stamps + 32 : nullptr);
         counters_from = 0;
         if (px.nranks > 1 && wave == 0 && !s_failed) {
@@ -1932,20 +1933,30 @@ constexpr int kDeviceLoopGaveUp = 100;
 // Workgroup size: 512 threads, or 256 for clouds that 64 such workgroups cover (one point per lane either way):
 // the wave-level reduction is bound by the CU's f64 issue rate, and four waves -- one per SIMD -- are through it
 // in half the time of eight; the final sum adds 8 partial sums instead of 16.
+// Clouds beyond what 64 workgroups of 512 cover with two points per lane (C3, C4 on one GPU) take up to 128 workgroups:
+// the accumulation halves, the gather reads twice as many records (on C2-sized clouds that trade loses).
 constexpr uint32_t kLmSmallThreads = 256;
-static bool lm_small(uint32_t n) { return n <= kMaxLmBlocks * kLmSmallThreads; }
-
-static int lm_block_limit(lom_map *m, bool small, uint32_t *out)
+enum LmShape { kLmSmall = 0, kLmMid = 1, kLmBig = 2 };
+static LmShape lm_shape(uint32_t n)
 {
-    uint32_t &cached = small ? m->lm_max_blocks_small : m->lm_max_blocks;
+    if (n <= kMaxLmBlocks * kLmSmallThreads) return kLmSmall;
+    return n <= 2u * kMaxLmBlocks * (uint32_t)kEvalThreads ? kLmMid : kLmBig;
+}
+
+static int lm_block_limit(lom_map *m, LmShape shape, uint32_t *out)
+{
+    uint32_t &cached = m->lm_max_blocks[shape];
     if (!cached) {
         int per_cu = 0, cus = 0;
-        if (small)
+        if (shape == kLmSmall)
             LOM_HIP(m, hipOccupancyMaxActiveBlocksPerMultiprocessor(
                            &per_cu, reinterpret_cast<const void *>(k_lm<(int)kLmSmallThreads>), (int)kLmSmallThreads, 0));
-        else
+        else if (shape == kLmMid)
             LOM_HIP(m, hipOccupancyMaxActiveBlocksPerMultiprocessor(
                            &per_cu, reinterpret_cast<const void *>(k_lm<kEvalThreads>), kEvalThreads, 0));
+        else
+            LOM_HIP(m, hipOccupancyMaxActiveBlocksPerMultiprocessor(
+                           &per_cu, reinterpret_cast<const void *>(k_lm<kEvalThreads, (int)kMaxLmBlocksBig>), kEvalThreads, 0));
         LOM_HIP(m, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, m->device));
         cached = (uint32_t)std::max(1, per_cu * cus);
     }
@@ -1965,7 +1976,7 @@ static int align_chained(lom_map *m, const char *d_src, size_t n, size_t stride,
     if (rc != LOM_OK) return rc;
     if ((rc = ensure(m, m->align_state, sizeof(AlignState))) != LOM_OK) return rc;
     if (!m->xrec.p) {
-        const size_t bytes = (size_t)2 * kMaxLmBlocks * kRecWords * sizeof(XWord);
+        const size_t bytes = (size_t)2 * kMaxLmBlocksBig * kRecWords * sizeof(XWord);
         if ((rc = ensure(m, m->xrec, bytes)) != LOM_OK) return rc;
         LOM_HIP(m, hipMemsetAsync(m->xrec.p, 0, bytes, m->stream));
     }
@@ -1977,11 +1988,14 @@ static int align_chained(lom_map *m, const char *d_src, size_t n, size_t stride,
     for (int a = 0; a < 3; a++) init.prior_b[a] = (double)guess_t[a];  // :153
     init.max_sq = 0.3f * 0.3f;                                          // :139, voxel_grid.h:215
     uint32_t nb_limit = 0;
-    const bool small = lm_small(c.n);
-    const uint32_t lm_threads = small ? kLmSmallThreads : (uint32_t)kEvalThreads;
-    if ((rc = lm_block_limit(m, small, &nb_limit)) != LOM_OK) return rc;
-    const uint32_t nb =
-        std::min(std::min(std::max(1u, (c.n + lm_threads - 1) / lm_threads), kMaxLmBlocks), nb_limit);
+    // ranks of one node keep to 64 workgroups each: a shard is an eighth of the cloud, and ranks that share a GPU
+    // (tests, rehearsals) must all be resident together
+    const LmShape shape = m->p2p ? std::min(lm_shape(c.n), kLmMid) : lm_shape(c.n);
+    const uint32_t lm_threads = shape == kLmSmall ? kLmSmallThreads : (uint32_t)kEvalThreads;
+    if ((rc = lm_block_limit(m, shape, &nb_limit)) != LOM_OK) return rc;
+    const uint32_t nb = std::min(std::min(std::max(1u, (c.n + lm_threads - 1) / lm_threads),
+                                          shape == kLmBig ? kMaxLmBlocksBig : kMaxLmBlocks),
+                                 nb_limit);
     double *d_trace = nullptr;  // lom_debug_lm_trace: k_lm of outer iteration `trace_outer` records its evaluations
     if (trace_out) {
         if ((rc = ensure(m, m->dbg_trace, 201 * 8)) != LOM_OK) return rc;
@@ -2015,10 +2029,12 @@ static int align_chained(lom_map *m, const char *d_src, size_t n, size_t stride,
                                server_timeout_ticks(), dbg, px,
                                (d_trace && i == trace_outer) ? d_trace : (double *)nullptr);
         };
-        if (small)
+        if (shape == kLmSmall)
             launch(k_lm<(int)kLmSmallThreads>);
-        else
+        else if (shape == kLmMid)
             launch(k_lm<kEvalThreads>);
+        else
+            launch(k_lm<kEvalThreads, (int)kMaxLmBlocksBig>);
         LOM_HIP(m, hipGetLastError());
         if (m->profiling && c.prof_used) {
             LOM_HIP(m, hipEventRecord(m->prof_events[(size_t)(c.prof_used - 1) * 3 + 2], m->stream));
