@@ -182,6 +182,33 @@ def test_randomized_map_and_search_parity(lom, oracle, seed):
         _assert_same_pairs(g.findMatchingPairs(q, lom.Pose3D(*pose), d), og.findMatchingPairs(q, oracle.Pose3D(*pose), d))
 
 
+def test_large_cap_voxels(lom, oracle):
+    """max_points beyond 2048: the search's other prefix path (27 x K no longer fits 16 bits per set), voxels that
+    hold thousands of points, caps that cut in the middle of a batch; map, pairs and align against the oracle."""
+    rng = np.random.default_rng(77)
+    for K in (3000, 2049, 40000):
+        g, og = _both(lom, oracle, 2.0, K)
+        centers = rng.uniform(-5, 5, (6, 3))
+        for rnd in range(2):
+            n = 9000
+            pts = (centers[rng.integers(0, len(centers), n)] + rng.normal(0, 0.4, (n, 3))).astype(np.float32)
+            nrm = scenes._unit(rng.standard_normal((n, 3))).astype(np.float32)
+            g.addCloud(pts, nrm)
+            og.addCloud(pts, nrm)
+            _assert_same_map(g, og)
+        assert g.pointCount() // max(g.size(), 1) > 100            # crowded voxels
+        q = (centers[rng.integers(0, len(centers), 800)] + rng.normal(0, 0.6, (800, 3))).astype(np.float32)
+        pose = ((0.02, -0.03, 0.01), scenes.angle_axis_q(0.01, (0, 0, 1)))
+        for d in (0.05, 0.3):
+            _assert_same_pairs(g.findMatchingPairs(q, lom.Pose3D(*pose), d), og.findMatchingPairs(q, oracle.Pose3D(*pose), d))
+        m, om = lom.CloudMatcher(), oracle.CloudMatcher()
+        p = m.align(g, q, lom.Pose3D(*pose))
+        r = om.align(og, q, oracle.Pose3D(*pose))
+        dt, dr = scenes.pose_delta(p.translation, p.rotation, r.translation, r.rotation)
+        assert dt < 1e-4 and dr < 1e-4 and m.stats["outer_iterations"] == om.stats["outer_iterations"]
+        assert m.stats["cand_total"] == om.stats["cand_total"]
+
+
 def test_out_of_range_rejected_and_nothing_inserted(lom):
     g = lom.VoxelGrid(0.5, 20)
     g.addCloudWithoutNormals(scenes.UNIQUE_POINTS)
