@@ -209,6 +209,30 @@ def test_large_cap_voxels(lom, oracle):
         assert m.stats["cand_total"] == om.stats["cand_total"]
 
 
+def test_more_than_a_million_voxels(lom, oracle):
+    """A map beyond 16 x 65536 voxels: the cleanup's multi-launch scan (its in-kernel scan covers 1,048,576), table
+    growth while inserting, bulk inserts of more than 65536 points, a second batch over the first; bytewise against
+    the oracle before and after two cleanups."""
+    rng = np.random.default_rng(2026)
+    g, og = _both(lom, oracle, 0.1, 3)
+    pts = rng.uniform(-60, 60, (1_250_000, 3)).astype(np.float32)
+    nrm = rng.standard_normal((len(pts), 3)).astype(np.float32)
+    g.addCloud(pts, nrm)
+    og.addCloud(pts, nrm)
+    assert g.size() == og.size() > 16 * 65536
+    more = np.ascontiguousarray(pts[::7] + np.float32(0.01))
+    g.addCloudWithoutNormals(more)
+    og.addCloudWithoutNormals(more)
+    _assert_same_map(g, og)
+    for center, r in (((5, -3, 2), 75.0), ((0, 0, 0), 30.0)):
+        c = np.array(center, np.float32)
+        g.radiusCleanup(c, r)
+        og.radiusCleanup(c, r)
+        _assert_same_map(g, og)
+    q = rng.uniform(-25, 25, (5000, 3)).astype(np.float32)
+    _assert_same_pairs(g.findMatchingPairs(q, lom.Pose3D(), 0.3), og.findMatchingPairs(q, oracle.Pose3D(), 0.3))
+
+
 def test_out_of_range_rejected_and_nothing_inserted(lom):
     g = lom.VoxelGrid(0.5, 20)
     g.addCloudWithoutNormals(scenes.UNIQUE_POINTS)
