@@ -564,6 +564,26 @@ def test_sampled_profiling_events(lom):
     assert m.stats["profiled_launches"] == 0
 
 
+def test_align_is_a_pure_function_of_its_inputs(lom):
+    """Sums are added in a fixed order at every level (lane, wave, workgroup, grid): the same align 300 times gives
+    the same pose bit for bit, on a cloud of each kernel shape (256- / 512-thread workgroups of the solve).
+    tools/soak_align.py is the long version (275k aligns)."""
+    sm = scenes.small_synth_case()
+    c = scenes.synth_case(16, 1800, 120_000)
+    for scan, mx, mn in ((sm["scan"], sm["map_xyz"], sm["map_nrm"]), (c["scan"], c["map_xyz"], c["map_nrm"])):
+        g = lom.VoxelGrid(0.5, 20)
+        g.addCloud(mx, mn)
+        m = lom.CloudMatcher()
+        guess = lom.Pose3D((0.05, -0.04, 0.02), scenes.angle_axis_q(0.0175, (0, 0, 1)))
+        first = m.align(g, scan, guess)
+        ref = first.translation.tobytes() + first.rotation.tobytes()
+        ev = m.stats["evaluations"]
+        for _ in range(300):
+            p = m.align(g, scan, guess)
+            assert p.translation.tobytes() + p.rotation.tobytes() == ref
+            assert m.stats["evaluations"] == ev and not m.stats["host_fallback"]
+
+
 def test_zero_matches_returns_guess(lom):
     g = lom.VoxelGrid(0.5, 20)
     g.addCloudWithoutNormals(np.array([[50, 50, 50]], np.float32))
