@@ -269,6 +269,33 @@ int lom_profile_match(lom_map *m, const float *d_src_xyz, size_t n, size_t strid
  * stream (all kernels of the insert, no host wait in between); microseconds from the first kernel to the last. */
 int lom_profile_insert(lom_map *m, const float *d_xyz, const float *d_nrm, size_t n, size_t stride_bytes,
                        double *total_us_out);
+/* Run-time switches of a handle.  The environment is read ONCE, by lom_map_create (LOM_HOST_LM, LOM_DEBUG_LM,
+ * LOM_DEBUG_TIMING: the production-side switches); afterwards only this call changes them -- nothing on the
+ * align path looks at the environment.  Options of the 100 range exist for the tests. */
+typedef enum {
+    LOM_OPT_HOST_LM = 1,               /* 1: outer loop and LM policy on the host (one round trip per LM iteration) */
+    LOM_OPT_DEVICE_PATIENCE_TICKS = 2, /* bound of every in-kernel wait, ticks of 10 ns; default 5,000,000 = 50 ms.
+                                          Waits for a peer RANK take ten times that; the host-side agreement after
+                                          a device-to-device align outlasts both (see lom_comm_attach_p2p). */
+    LOM_OPT_DEBUG_LM_STAMPS = 3,       /* 1: print k_lm's phase stamps after every align (stderr) */
+    LOM_OPT_DEBUG_TIMING = 4,          /* 1: print host launch / wait times per evaluation (stderr) */
+    LOM_OPT_TEST_GIVE_UP_AT_OUTER = 100, /* k: the k_lm of outer iteration k of the NEXT align behaves as if its
+                                          workgroups had timed out waiting (one shot; -1 = off) */
+    LOM_OPT_TEST_GRID_GIVE_UP = 101,   /* b >= 0: in the NEXT map-maintenance call with an in-kernel scan, workgroups
+                                          b, b+1, ... give up waiting for their predecessors (one shot; -1 = off;
+                                          + 65536 per such call to let pass first) */
+    /* lom_odometry_set_option only: */
+    LOM_OPT_TEST_FORCE_HOST_REDO = 102,        /* 1: every frame is handed back to the host stages */
+    LOM_OPT_TEST_GRID_GIVE_UP_MATCHING_DS = 103, /* LOM_OPT_TEST_GRID_GIVE_UP on the matching down-sampler ... */
+    LOM_OPT_TEST_GRID_GIVE_UP_UPDATE_DS = 104,   /* ... the next frame's update down-sampler ... */
+    LOM_OPT_TEST_GRID_GIVE_UP_KEYFRAME = 105     /* ... the keyframe (its next insert or cleanup) */
+} lom_option;
+int lom_map_set_option(lom_map *m, int option, int64_t value);
+/* diagnostics: LOM_COUNTER_GRID_REDOS = calls of this handle redone with the multi-launch scan after an
+ * in-kernel scan gave up (such a call changes nothing; see csrc/grid_scan.hpp) */
+enum { LOM_COUNTER_GRID_REDOS = 0 };
+int64_t lom_map_debug_counter(const lom_map *m, int which);
+
 /* make the handle's stream wait for a hipEvent_t recorded elsewhere */
 int lom_map_wait_event(lom_map *m, void *hip_event);
 /* run the handle's work on a caller-owned hipStream_t (NULL = handle's own stream) */
@@ -293,6 +320,14 @@ typedef struct lom_host_comm lom_host_comm;
 int lom_comm_host_id(char id_out[LOM_COMM_ID_BYTES]);
 int lom_host_comm_create(int rank, int nranks, const char id[LOM_COMM_ID_BYTES], lom_host_comm **out);
 int lom_host_comm_allreduce(lom_host_comm *c, double *buf, int count); /* in place, count <= LOM_NSUMS */
+/* Deadline of one exchange (default 60 s).  A rank that reaches it ABANDONS the exchange object: it marks its
+ * slots, so that every rank still waiting for it -- or arriving later -- fails with LOM_ERR_COMM as well instead
+ * of pairing with slots their owner has walked away from; all later calls on the object fail at once.
+ * lom_host_comm_abort does the same on purpose (a rank that cannot continue tells its peers).
+ * lom_host_comm_last_error says which exchange was abandoned, and by whom. */
+int lom_host_comm_set_timeout(lom_host_comm *c, double seconds);
+int lom_host_comm_abort(lom_host_comm *c);
+const char *lom_host_comm_last_error(const lom_host_comm *c);
 /* every rank contributes `bytes` (<= 256) raw bytes; all_out receives nranks * bytes in rank order */
 int lom_host_comm_allgather(lom_host_comm *c, const void *mine, size_t bytes, void *all_out);
 void lom_host_comm_destroy(lom_host_comm *c);
@@ -303,7 +338,12 @@ int lom_comm_attach_host(lom_map *m, lom_host_comm *c_or_null);
  * ranks' words in rank order: no host round trip per evaluation.  `c` carries rank / nranks and the
  * exchange of the IPC handles.  The call runs a self-test of the device-to-device exchange on all
  * ranks and returns LOM_ERR_COMM on EVERY rank if it fails on any (fall back to
- * lom_comm_attach_host).  Ranks must issue the same sequence of aligns. */
+ * lom_comm_attach_host).  Ranks must issue the same sequence of aligns.
+ * Failure handling: a rank whose kernel gives up waiting (LOM_OPT_DEVICE_PATIENCE_TICKS) tells its peers through
+ * an abort word in their exchange buffers, so they leave their waits at once instead of after their own patience;
+ * after EVERY align the ranks agree on its outcome through `c` (deadline: 30 s + 12 x the patience for a peer
+ * rank): all ranks keep the device result, or all redo the align through the host exchange (equal poses), or --
+ * when a rank failed for good, or the agreement itself timed out -- all return an error. */
 int lom_comm_attach_p2p(lom_map *m, lom_host_comm *c);
 
 /* ---- host-side align driver over user evaluators ------------------------ */
@@ -362,6 +402,7 @@ typedef struct lom_frontend lom_frontend;
 int lom_frontend_create(int device, void *hip_stream_or_null, lom_frontend **out);
 void lom_frontend_destroy(lom_frontend *f);
 const char *lom_frontend_last_error(const lom_frontend *f);
+int lom_frontend_set_option(lom_frontend *f, int option, int64_t value); /* LOM_OPT_TEST_GRID_GIVE_UP: the next frame's scan */
 /* enqueue one frame: upload, time normalisation, deskew from start_pose to end_pose, classification, range filter */
 int lom_frontend_process(lom_frontend *f, const lom_point_xyzirt *pts, size_t n, const lom_pose *start_pose,
                          const lom_pose *end_pose, float min_range, float max_range);
@@ -481,6 +522,11 @@ int lom_odometry_get_pose(const lom_odometry *o, lom_pose *out);   /* getCurrent
  * NULL with cap 0 (count only). */
 int64_t lom_odometry_get_temp_cloud(const lom_odometry *o, lom_point_xyzirt *out, size_t cap);
 int lom_odometry_get_stats(const lom_odometry *o, lom_odometry_frame_stats *out);
+/* switches of the pipeline (LOM_OPT_TEST_FORCE_HOST_REDO, the LOM_OPT_TEST_GRID_GIVE_UP family) and, for every other
+ * option, of its keyframe handle (the align's).  The environment is read once, by lom_odometry_create
+ * (LOM_HOST_THREADS, LOM_SYNC_KEYFRAME_UPDATE, LOM_HOST_FRONTEND, LOM_DEBUG_TIMING). */
+int lom_odometry_set_option(lom_odometry *o, int option, int64_t value);
+int64_t lom_odometry_debug_counter(const lom_odometry *o, int which); /* LOM_COUNTER_GRID_REDOS: all its handles + frames redone */
 /* test hook (teacher-forced parity tests): overwrite previous_transform_ / current_transform_
  * (lidar_odometry.h:84-85); the keyframe itself can be replaced through lom_odometry_keyframe() */
 int lom_odometry_debug_set_state(lom_odometry *o, const lom_pose *previous, const lom_pose *current);

@@ -95,6 +95,13 @@ class VoxelGrid:
     def handle(self):
         return self._h
 
+    def setOption(self, option, value):
+        """lom_map_set_option: run-time switches of the handle (capi.OPT_*)."""
+        capi.check(capi.lib().lom_map_set_option(self._h, int(option), int(value)), self._h)
+
+    def debugCounter(self, which=capi.COUNTER_GRID_REDOS):
+        return capi.check(capi.lib().lom_map_debug_counter(self._h, int(which)), self._h)
+
     def setMaxPoints(self, max_points):                    # voxel_grid.h:56-59
         capi.check(capi.lib().lom_map_set_max_points(self._h, int(max_points)), self._h)
         self.max_points = int(max_points)
@@ -463,6 +470,15 @@ class LidarOdometry:
         if h and capi is not None:
             capi.lib().lom_odometry_destroy(h)
             self._h = None
+
+    def setOption(self, option, value):
+        """lom_odometry_set_option: switches of the pipeline and of its keyframe handle (capi.OPT_*)."""
+        rc = capi.lib().lom_odometry_set_option(self._h, int(option), int(value))
+        if rc != 0:
+            raise LomError(int(rc), "lom_odometry_set_option")
+
+    def debugCounter(self, which=capi.COUNTER_GRID_REDOS):
+        return int(capi.lib().lom_odometry_debug_counter(self._h, int(which)))
 
     def processCloud(self, input_cloud):                   # lidar_odometry.cpp:22-77
         a = _cloud(input_cloud)

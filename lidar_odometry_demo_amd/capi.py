@@ -124,7 +124,15 @@ EXPORTED = [
     "lom_frontend_process", "lom_frontend_results", "lom_frontend_wait", "lom_frontend_fetch", "lom_frontend_stream", "lom_frontend_stage", "lom_frontend_done_event", "lom_map_wait_event", "lom_frontend_sequence", "lom_map_status_words", "lom_debug_sinf",
     "lom_voxel_downsample_device_nowait", "lom_map_read_device_words", "lom_map_read_device_words_begin", "lom_map_read_device_words_end",
     "lom_pointcloud2_unpack", "lom_pointcloud2_layout", "lom_pointcloud2_pack_xyz", "lom_pointcloud2_last_error",
+    "lom_map_set_option", "lom_map_debug_counter", "lom_odometry_set_option", "lom_odometry_debug_counter",
+    "lom_frontend_set_option", "lom_host_comm_set_timeout", "lom_host_comm_abort", "lom_host_comm_last_error",
 ]
+
+# lom_option / counters of include/lidar_odometry_amd.h
+OPT_HOST_LM, OPT_DEVICE_PATIENCE_TICKS, OPT_DEBUG_LM_STAMPS, OPT_DEBUG_TIMING = 1, 2, 3, 4
+OPT_TEST_GIVE_UP_AT_OUTER, OPT_TEST_GRID_GIVE_UP, OPT_TEST_FORCE_HOST_REDO = 100, 101, 102
+OPT_TEST_GRID_GIVE_UP_MATCHING_DS, OPT_TEST_GRID_GIVE_UP_UPDATE_DS, OPT_TEST_GRID_GIVE_UP_KEYFRAME = 103, 104, 105
+COUNTER_GRID_REDOS = 0
 
 _lib = None
 
@@ -280,6 +288,17 @@ def lib():
     L.lom_pointcloud2_pack_xyz.argtypes = [vp, C.c_size_t, C.c_size_t, vp, C.c_size_t]
     L.lom_pointcloud2_pack_xyz.restype = C.c_int64
     L.lom_pointcloud2_last_error.restype = C.c_char_p
+    L.lom_map_set_option.argtypes = [vp, C.c_int, C.c_int64]
+    L.lom_map_debug_counter.argtypes = [vp, C.c_int]
+    L.lom_map_debug_counter.restype = C.c_int64
+    L.lom_odometry_set_option.argtypes = [vp, C.c_int, C.c_int64]
+    L.lom_odometry_debug_counter.argtypes = [vp, C.c_int]
+    L.lom_odometry_debug_counter.restype = C.c_int64
+    L.lom_frontend_set_option.argtypes = [vp, C.c_int, C.c_int64]
+    L.lom_host_comm_set_timeout.argtypes = [vp, C.c_double]
+    L.lom_host_comm_abort.argtypes = [vp]
+    L.lom_host_comm_last_error.argtypes = [vp]
+    L.lom_host_comm_last_error.restype = C.c_char_p
     _lib = L
     return L
 

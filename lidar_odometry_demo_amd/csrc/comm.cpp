@@ -92,12 +92,19 @@ struct HostSlot {
 };
 static_assert(sizeof(HostSlot) == 512, "slot size");
 
+// A rank that gives up on an exchange (deadline, or lom_host_comm_abort) marks BOTH of its slots with this
+// bit: whoever waits for that rank now or later sees it and fails too, instead of pairing with a slot that
+// was published for an exchange its owner has walked away from.  An abandoned exchange object stays broken.
+constexpr unsigned long long kAbandoned = 1ull << 63;
+
 struct lom_host_comm {
     HostSlot *slots = nullptr;  // [2 buffers][nranks]
     size_t bytes = 0;
     std::string name;
     int rank = 0, nranks = 1;
     unsigned long long seq = 0;
+    double timeout_s = 60.0;  // deadline of one exchange (lom_host_comm_set_timeout)
+    bool broken = false;      // this rank abandoned an exchange, or saw a peer that had
     std::string error;
 };
 
@@ -108,6 +115,44 @@ double mono_s()
     timespec ts;
     clock_gettime(CLOCK_MONOTONIC, &ts);
     return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+void abandon(lom_host_comm *hc, const std::string &why)
+{
+    hc->broken = true;
+    hc->error = why;
+    for (int b = 0; b < 2; b++)
+        __atomic_store_n(&hc->slots[(size_t)b * hc->nranks + hc->rank].seq, kAbandoned | hc->seq, __ATOMIC_RELEASE);
+}
+
+// publish this rank's slot of exchange `seq` (payload written by the caller), then wait for every rank's;
+// `take(r, slot)` consumes rank r's payload in rank order.  Double buffered: a rank can start exchange k+2
+// only after every rank finished k+1, i.e. after every rank is done reading exchange k, whose buffer it
+// then reuses.
+template <typename Take>
+int exchange(lom_host_comm *hc, HostSlot *slots, unsigned long long seq, double timeout_s, Take take)
+{
+    __atomic_store_n(&slots[hc->rank].seq, seq, __ATOMIC_RELEASE);
+    const double t0 = mono_s();
+    for (int r = 0; r < hc->nranks; r++) {
+        unsigned long long spins = 0;
+        for (;;) {
+            const unsigned long long v = __atomic_load_n(&slots[r].seq, __ATOMIC_ACQUIRE);
+            if (v == seq) break;
+            if (v & kAbandoned) {
+                abandon(hc, "host exchange: rank " + std::to_string(r) + " abandoned exchange " +
+                                std::to_string(v & ~kAbandoned) + " (this rank is at " + std::to_string(seq) + ")");
+                return LOM_ERR_COMM;
+            }
+            __builtin_ia32_pause();
+            if ((++spins & 0xFFFF) == 0 && mono_s() - t0 > timeout_s) {
+                abandon(hc, "host exchange timed out waiting for rank " + std::to_string(r));
+                return LOM_ERR_COMM;
+            }
+        }
+        take(r, slots[r]);
+    }
+    return LOM_OK;
 }
 
 }  // namespace
@@ -122,6 +167,27 @@ int host_comm_rank(void *hc, int *rank, int *nranks, unsigned long long *seq)
     *nranks = c->nranks;
     if (seq) *seq = c->seq;  // operations so far: the same number on every rank
     return LOM_OK;
+}
+
+const char *host_comm_error(void *hc)
+{
+    lom_host_comm *c = reinterpret_cast<lom_host_comm *>(hc);
+    return c ? c->error.c_str() : "";
+}
+
+int host_comm_allreduce_deadline(void *hcv, double *buf, int count, double timeout_s)
+{
+    lom_host_comm *hc = reinterpret_cast<lom_host_comm *>(hcv);
+    if (!hc || !buf || count < 0 || count > LOM_NSUMS) return LOM_ERR_ARG;
+    if (hc->broken) return LOM_ERR_COMM;  // hc->error says which exchange was abandoned, and by whom
+    const unsigned long long seq = ++hc->seq;
+    HostSlot *slots = hc->slots + (size_t)(seq & 1) * hc->nranks;
+    HostSlot &me = slots[hc->rank];
+    for (int k = 0; k < count; k++) me.data[k] = buf[k];
+    for (int k = 0; k < count; k++) buf[k] = 0.0;
+    return exchange(hc, slots, seq, timeout_s, [&](int, HostSlot &s) {
+        for (int k = 0; k < count; k++) buf[k] += s.data[k];  // rank order
+    });
 }
 
 int host_exchange_sums(lom_map *m, const double *mine, double *out)
@@ -170,56 +236,41 @@ int lom_host_comm_create(int rank, int nranks, const char id_in[LOM_COMM_ID_BYTE
     return LOM_OK;
 }
 
+int lom_host_comm_set_timeout(lom_host_comm *hc, double seconds)
+{
+    if (!hc || !(seconds > 0.0)) return LOM_ERR_ARG;
+    hc->timeout_s = seconds;
+    return LOM_OK;
+}
+
+int lom_host_comm_abort(lom_host_comm *hc)
+{
+    if (!hc) return LOM_ERR_ARG;
+    if (!hc->broken) abandon(hc, "host exchange aborted by this rank");
+    return LOM_OK;
+}
+
+const char *lom_host_comm_last_error(const lom_host_comm *hc) { return hc ? hc->error.c_str() : ""; }
+
 // In-place sum over the ranks of buf[0..count), count <= LOM_NSUMS, added in rank order on every
-// rank (bitwise the same result everywhere).  Double buffered: a rank can start exchange k+2 only
-// after every rank finished k+1, i.e. after every rank is done reading exchange k, whose buffer it
-// then reuses.
+// rank (bitwise the same result everywhere).
 int lom_host_comm_allreduce(lom_host_comm *hc, double *buf, int count)
 {
-    if (!hc || !buf || count < 0 || count > LOM_NSUMS) return LOM_ERR_ARG;
-    const unsigned long long seq = ++hc->seq;
-    HostSlot *slots = hc->slots + (size_t)(seq & 1) * hc->nranks;
-    HostSlot &me = slots[hc->rank];
-    for (int k = 0; k < count; k++) me.data[k] = buf[k];
-    __atomic_store_n(&me.seq, seq, __ATOMIC_RELEASE);
-    for (int k = 0; k < count; k++) buf[k] = 0.0;
-    const double t0 = mono_s();
-    for (int r = 0; r < hc->nranks; r++) {
-        unsigned long long spins = 0;
-        while (__atomic_load_n(&slots[r].seq, __ATOMIC_ACQUIRE) != seq) {
-            __builtin_ia32_pause();
-            if ((++spins & 0xFFFFF) == 0 && mono_s() - t0 > 60.0) {
-                hc->error = "host exchange timed out waiting for rank " + std::to_string(r);
-                return LOM_ERR_COMM;
-            }
-        }
-        for (int k = 0; k < count; k++) buf[k] += slots[r].data[k];  // rank order
-    }
-    return LOM_OK;
+    if (!hc) return LOM_ERR_ARG;
+    return lom::host_comm_allreduce_deadline(hc, buf, count, hc->timeout_s);
 }
 
 // Raw bytes through the same double-buffered slots (a slot's data area is 256 bytes).
 int lom_host_comm_allgather(lom_host_comm *hc, const void *mine, size_t bytes, void *all_out)
 {
     if (!hc || !mine || !all_out || bytes == 0 || bytes > sizeof(double) * LOM_NSUMS) return LOM_ERR_ARG;
+    if (hc->broken) return LOM_ERR_COMM;
     const unsigned long long seq = ++hc->seq;
     HostSlot *slots = hc->slots + (size_t)(seq & 1) * hc->nranks;
-    HostSlot &me = slots[hc->rank];
-    std::memcpy(me.data, mine, bytes);
-    __atomic_store_n(&me.seq, seq, __ATOMIC_RELEASE);
-    const double t0 = mono_s();
-    for (int r = 0; r < hc->nranks; r++) {
-        unsigned long long spins = 0;
-        while (__atomic_load_n(&slots[r].seq, __ATOMIC_ACQUIRE) != seq) {
-            __builtin_ia32_pause();
-            if ((++spins & 0xFFFFF) == 0 && mono_s() - t0 > 60.0) {
-                hc->error = "host exchange timed out waiting for rank " + std::to_string(r);
-                return LOM_ERR_COMM;
-            }
-        }
-        std::memcpy(static_cast<char *>(all_out) + (size_t)r * bytes, slots[r].data, bytes);
-    }
-    return LOM_OK;
+    std::memcpy(slots[hc->rank].data, mine, bytes);
+    return exchange(hc, slots, seq, hc->timeout_s, [&](int r, HostSlot &s) {
+        std::memcpy(static_cast<char *>(all_out) + (size_t)r * bytes, s.data, bytes);
+    });
 }
 
 void lom_host_comm_destroy(lom_host_comm *hc)

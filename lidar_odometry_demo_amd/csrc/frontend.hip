@@ -304,7 +304,7 @@ template <int kItems>  // cells per thread: 1 while a frame's cells fit one resi
 __global__ __launch_bounds__(kThreads) void k_fe_planar(const float4 *__restrict__ org, uint32_t *win, uint32_t cell_cap,
                                                         FrameConst F, float *__restrict__ out_xyz,
                                                         float *__restrict__ out_nrm, Granule *agg, uint32_t seq,
-                                                        uint32_t *words)
+                                                        uint32_t *words, uint32_t test_fail_from)
 {
     __shared__ unsigned long long s_w[8];
     const uint32_t H = words[2], W = words[3];
@@ -366,18 +366,19 @@ __global__ __launch_bounds__(kThreads) void k_fe_planar(const float4 *__restrict
     }
     unsigned long long tot;
     const unsigned long long excl = block_scan64(mine, s_w, tot);
-    const unsigned long long before = grid_prefix64(tot, agg, seq, words + 5, s_w);
+    bool gave_up;  // no prefix: nothing is written (the cell table is at rest already); the host stages redo the frame
+    const unsigned long long before = grid_prefix64(tot, agg, seq, words + 5, s_w, gave_up, test_fail_from);
     uint32_t at = (uint32_t)(before + excl);  // low word: filtered points before this thread
 #pragma unroll
     for (int k = 0; k < kItems; k++) {
-        if (!keep[k]) continue;
+        if (!keep[k] || gave_up) continue;
         float *o = out_xyz + (size_t)at * 3, *no = out_nrm + (size_t)at * 3;
         o[0] = px[k], o[1] = py[k], o[2] = pz[k];
         no[0] = nx[k], no[1] = ny[k], no[2] = nz[k];
         at++;
     }
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
-        const unsigned long long all = before + tot;
+        const unsigned long long all = gave_up ? 0ull : before + tot;  // a grid that gave up hands an empty cloud on
         words[0] = (uint32_t)(all >> 32);  // planar points
         words[1] = (uint32_t)all;          // after the range filter
     }
@@ -411,6 +412,7 @@ struct lom_frontend {
     uint32_t *h_words = nullptr; // pinned copy
     uint32_t seq = 0;
     uint32_t n_last = 0;
+    int test_grid_give_up = -1;  // LOM_OPT_TEST_GRID_GIVE_UP (one shot)
     std::string error;
 };
 
@@ -541,6 +543,16 @@ void lom_frontend_destroy(lom_frontend *f)
 
 const char *lom_frontend_last_error(const lom_frontend *f) { return f ? f->error.c_str() : ""; }
 
+int lom_frontend_set_option(lom_frontend *f, int option, int64_t value)
+{
+    if (!f) return LOM_ERR_ARG;
+    if (option == LOM_OPT_TEST_GRID_GIVE_UP && value >= -1 && value <= 65535) {
+        f->test_grid_give_up = (int)value;
+        return LOM_OK;
+    }
+    return LOM_ERR_ARG;
+}
+
 int lom_frontend_process(lom_frontend *f, const lom_point_xyzirt *pts, size_t n, const lom_pose *start, const lom_pose *end,
                          float min_range, float max_range)
 {
@@ -577,12 +589,15 @@ int lom_frontend_process(lom_frontend *f, const lom_point_xyzirt *pts, size_t n,
                        cells_bound, seq, f->d_words);
     hipLaunchKernelGGL(k_fe_curv, dim3(blocks_for(cells_bound)), dim3(kThreads), 0, f->stream, f->d_desk, f->d_win,
                        f->d_words, cells_bound, f->d_org);
+    const uint32_t fail_from = f->test_grid_give_up < 0 ? 0xFFFFFFFFu : (uint32_t)f->test_grid_give_up;
+    f->test_grid_give_up = -1;
     if (cells_bound <= kOnePassMax)
         hipLaunchKernelGGL(k_fe_planar<1>, dim3(blocks_for(cells_bound)), dim3(kThreads), 0, f->stream, f->d_org, f->d_win,
-                           cells_bound, F, f->d_xyz, f->d_nrm, fe_agg(f), seq, f->d_words);
+                           cells_bound, F, f->d_xyz, f->d_nrm, fe_agg(f), seq, f->d_words, fail_from);
     else
         hipLaunchKernelGGL(k_fe_planar<kFeItems>, dim3(blocks_for((cells_bound + kFeItems - 1) / kFeItems)), dim3(kThreads), 0,
-                           f->stream, f->d_org, f->d_win, cells_bound, F, f->d_xyz, f->d_nrm, fe_agg(f), seq, f->d_words);
+                           f->stream, f->d_org, f->d_win, cells_bound, F, f->d_xyz, f->d_nrm, fe_agg(f), seq, f->d_words,
+                           fail_from);
     FE_HIP(f, hipGetLastError());
     FE_HIP(f, hipEventRecord(f->done_ev, f->stream));
     return LOM_OK;
@@ -656,8 +671,8 @@ int lom_frontend_wait(lom_frontend *f, uint32_t counts_out[4])
     FE_HIP(f, hipStreamSynchronize(f->stream));
     if (counts_out)
         for (int k = 0; k < 4; k++) counts_out[k] = f->h_words[k];
-    if (f->h_words[5] == f->seq) return fe_fail(f, LOM_ERR_HIP, "front end: a workgroup timed out waiting for the others of its grid");
-    return f->h_words[4] == f->seq ? 1 : LOM_OK;
+    // a grid that gave up has written nothing and left the cell table at rest: the frame goes to the host stages
+    return (f->h_words[4] == f->seq || f->h_words[5] == f->seq) ? 1 : LOM_OK;
 }
 
 // copies of the device results for callers on the host (getTempCloud, tests): what = 0 the deskewed cloud

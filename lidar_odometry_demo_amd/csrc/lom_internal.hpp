@@ -162,6 +162,11 @@ struct lom_map {
     // the one up to which lom_map_status has looked, and whether the table is known to be all-empty
     uint32_t call_seq = 0, status_seq = 0;
     bool table_clean = true;
+    // the handle's last single-pass insert, for lom_map_status() to redo should its in-kernel scan have given up
+    const char *pending_xyz = nullptr, *pending_nrm = nullptr;
+    size_t pending_n = 0, pending_stride = 0;
+    uint32_t pending_seq = 0, grid_resolved_seq = 0;
+    uint32_t grid_redos = 0;  // calls redone with the multi-launch scan after a give-up (lom_map_debug_counter)
     // per-scan buffers of align/find_pairs
     lom::DeviceBuf scan_src, scan_idx, scan_on, scan_stats, partials, results;
 
@@ -182,6 +187,7 @@ struct lom_map {
     // device-resident outer loop (single GPU): state in HBM, exchange records of k_lm's workgroups,
     // report in pinned host memory
     lom::DeviceBuf align_state, xrec, dbg_trace, dbg_stamps;
+    bool align_state_dirty = true;  // AlignState must be zeroed before the next chain (fresh, or left with its error flag set)
     void *h_report = nullptr, *d_report = nullptr;  // 1 KiB: AlignReport, and at 512 the words of gather_words()
     uint32_t words_tag = 0;
     int words_pending = 0;  // words of a lom_map_read_device_words_begin not yet collected
@@ -198,11 +204,20 @@ struct lom_map {
     bool p2p = false;
     void *p2p_local = nullptr;          // [4 sets][kP2pMaxRanks][32] exchange words in this GPU's HBM
     void *p2p_peer[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    unsigned long long p2p_epoch = 0;   // device-to-device aligns since the attach: the same number on every rank
     // RCCL
     void *comm = nullptr;       // RCCL communicator (device-side all-gather)
     void *host_comm = nullptr;  // host shared-memory exchange between the ranks of one node
     int rank = 0, nranks = 1;
     lom::DeviceBuf gather;
+
+    // run-time switches: environment read ONCE at lom_map_create, afterwards lom_map_set_option only
+    bool opt_host_lm = false;       // LOM_OPT_HOST_LM / LOM_HOST_LM=1
+    bool opt_debug_lm = false;      // LOM_OPT_DEBUG_LM_STAMPS / LOM_DEBUG_LM=1
+    bool opt_debug_timing = false;  // LOM_OPT_DEBUG_TIMING / LOM_DEBUG_TIMING=1
+    unsigned long long patience_ticks = 5000000ull;  // bounded in-kernel waits: 50 ms of s_memrealtime (100 MHz)
+    int test_grid_give_up = -1;     // LOM_OPT_TEST_GRID_GIVE_UP: first workgroup that gives up in the next in-kernel scan
+    int test_give_up_outer = -1;    // LOM_OPT_TEST_GIVE_UP_AT_OUTER: k_lm of that outer iteration of the next align gives up
 
     std::string last_error;
 };
@@ -212,6 +227,7 @@ namespace lom {
 int set_error(lom_map *m, int code, const char *what, hipError_t e = hipSuccess);
 int ensure(lom_map *m, DeviceBuf &b, size_t bytes);  // grow-only device buffer
 MapView view_of(const lom_map *m);
+int resolve_pending(lom_map *m);  // voxel_map.hip: redo the last single-pass insert if its in-kernel scan gave up
 
 #define LOM_HIP(m, expr)                                                        \
     do {                                                                        \
@@ -224,6 +240,10 @@ int comm_allgather_sums(lom_map *m, const double *d_send, double *d_recv, int co
 // host shared-memory exchange: out = sum over ranks (rank order) of `mine`
 int host_exchange_sums(lom_map *m, const double *mine, double *out);
 int host_comm_rank(void *host_comm, int *rank, int *nranks, unsigned long long *seq = nullptr);
+// lom_host_comm_allreduce with a deadline of the caller's choosing (the exchange that follows a device-to-device
+// align must outlast the device-side patience of the slowest rank)
+int host_comm_allreduce_deadline(void *host_comm, double *buf, int count, double timeout_s);
+const char *host_comm_error(void *host_comm);
 // device-to-device exchange (match.hip)
 constexpr int kP2pMaxRanks = 8;
 void p2p_detach(lom_map *m);

@@ -801,7 +801,8 @@ __device__ __forceinline__ void reduce_and_exchange(const double acc[28], double
                                                     const uint32_t *__restrict__ block_counters,
                                                     uint32_t n_match_blocks, XWord *set, uint32_t nb,
                                                     unsigned long long seq, unsigned long long timeout_ticks,
-                                                    double *s_tot, int *s_failed, unsigned long long *dbg = nullptr)
+                                                    double *s_tot, int *s_failed, const int32_t *chain_error,
+                                                    unsigned long long *dbg = nullptr)
 {
 #define RX_STAMP(k)                                                     \
     if (dbg && blockIdx.x == 0 && threadIdx.x == 0) {                   \
@@ -883,6 +884,7 @@ __device__ __forceinline__ void reduce_and_exchange(const double acc[28], double
         // 0.1539 / 0.1548.
         __builtin_amdgcn_s_sleep(16);
         const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+        uint32_t polls = 0;
         for (;;) {
             unsigned long long cb[kPer];
 #pragma unroll
@@ -902,6 +904,12 @@ __device__ __forceinline__ void reduce_and_exchange(const double acc[28], double
             if (all) break;
             if (__builtin_amdgcn_s_memrealtime() - t_start > timeout_ticks) {
                 *s_failed = 1;  // some workgroup never published: give up (the grid drains)
+                break;
+            }
+            // a wait that drags on: has a workgroup of this launch given up already?  Then the words this one waits
+            // for will never come; it leaves now, not after its own patience.
+            if ((++polls & 255u) == 0 && __hip_atomic_load(chain_error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                *s_failed = 1;
                 break;
             }
             __builtin_amdgcn_s_sleep(1);
@@ -1298,11 +1306,31 @@ __device__ __forceinline__ int lmw_propose(LmState &S, int lane)
 // peers' through their IPC mappings: xGMI), system-coherent stores, same {bits, seq ^ bits} words as
 // inside a GPU.  Every workgroup of every rank then reads its own GPU's buffer and adds the ranks'
 // words in rank order: identical bits on all workgroups of all ranks, no host in the loop.
+// Behind the four sets every buffer holds one ABORT word per rank: a rank whose kernel gives up (its workgroups not
+// all resident, a peer that never published) stores the number of the align it abandons -- the same number on every
+// rank -- into its word in EVERY rank's buffer.  A kernel waiting for that rank's totals looks at the abort words
+// whenever a wait drags on and leaves at once, instead of after its own (ten times longer) patience: without that
+// word the ranks reached the host-side agreement up to 100 s apart (round 2's three-rank failure).
+constexpr size_t kP2pExchangeWords = (size_t)4 * kP2pMaxRanks * kRecWords;  // XWords before the abort words
+constexpr size_t kP2pBufferBytes = kP2pExchangeWords * sizeof(XWord) + kP2pMaxRanks * sizeof(unsigned long long);
 struct P2pArgs {
     XWord *peer[kP2pMaxRanks];  // peer[r]: rank r's buffer as seen from this GPU (peer[rank] = local)
     int rank, nranks;
     int set_base;  // 0 or 2: consecutive launches use disjoint pairs of exchange sets (see global_exchange)
+    unsigned long long epoch;  // number of this device-to-device align (>= 1; ~0: the attach self-test)
 };
+
+__device__ __forceinline__ unsigned long long *p2p_abort_words(XWord *buffer)
+{
+    return reinterpret_cast<unsigned long long *>(buffer + kP2pExchangeWords);
+}
+
+// this rank abandons align `epoch`: tell every rank (own buffer included)
+__device__ __forceinline__ void p2p_publish_abort(const P2pArgs &A)
+{
+    for (int r = 0; r < A.nranks; r++)
+        __hip_atomic_store(p2p_abort_words(A.peer[r]) + A.rank, A.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 __device__ __forceinline__ void global_exchange(const P2pArgs &A, double *s_tot, unsigned long long seq,
                                                 unsigned long long timeout_ticks, int *s_failed, bool publisher,
@@ -1322,7 +1350,9 @@ __device__ __forceinline__ void global_exchange(const P2pArgs &A, double *s_tot,
     const int k = lane & 31, h = lane >> 5;
     unsigned long long vb[4] = {0, 0, 0, 0};
     const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long *aborts = p2p_abort_words(A.peer[A.rank]);
     bool failed = false;
+    uint32_t polls = 0;
     for (;;) {
         bool all = true;
 #pragma unroll
@@ -1340,6 +1370,14 @@ __device__ __forceinline__ void global_exchange(const P2pArgs &A, double *s_tot,
         if (__builtin_amdgcn_s_memrealtime() - t_start > timeout_ticks) {
             failed = true;  // a rank never published: give up (every grid drains)
             break;
+        }
+        if ((++polls & 63u) == 0) {  // a wait that drags on: has a rank abandoned this align?
+            unsigned long long ab = 0;
+            if (lane < A.nranks) ab = __hip_atomic_load(aborts + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (__ballot(lane < A.nranks && ab == A.epoch) != 0ull) {
+                failed = true;
+                break;
+            }
         }
         __builtin_amdgcn_s_sleep(1);
     }
@@ -1421,7 +1459,7 @@ __global__ __launch_bounds__(kT) void k_lm(const MatchRec *__restrict__ rec, uin
                                                      unsigned long long report_seq,
                                                      unsigned long long timeout_ticks,
                                                      unsigned long long *dbg_stamps, P2pArgs px,
-                                                     double *dbg_trace)
+                                                     double *dbg_trace, int test_give_up)
 {
     __shared__ double s_acc[(kT / 64) * 32];  // the waves' totals of one evaluation
     __shared__ double s_tot[kRecWords];
@@ -1450,7 +1488,7 @@ __global__ __launch_bounds__(kT) void k_lm(const MatchRec *__restrict__ rec, uin
     }
     if (!first_outer && (state->finished | state->error)) return;  // chained launch after the end
     if (tid < 7) s_x[tid] = (double)x0;  // cloud_matcher.cpp:122-131
-    if (tid == 0) s_failed = 0;
+    if (tid == 0) s_failed = test_give_up;  // LOM_OPT_TEST_GIVE_UP_AT_OUTER: this launch behaves as if its waits had timed out
     __syncthreads();
     unsigned long long seq = seq_base;
     uint32_t counters_from = n_match_blocks;  // k_match's counters are folded by the first evaluation only
@@ -1471,7 +1509,8 @@ __global__ __launch_bounds__(kT) void k_lm(const MatchRec *__restrict__ rec, uin
         seq++;
         XWord *set = xrec + (size_t)(seq & 1) * kMaxLmBlocksBig * kRecWords;
         reduce_and_exchange<kT, kBlocks>(acc, s_acc, s_part, block_counters, counters_from, set, nb, seq, timeout_ticks,
-                            s_tot, &s_failed, (dbg_stamps && first_outer && ev == 1) ? dbg_stamps + 32 : nullptr);
+                            s_tot, &s_failed, &state->error,
+                            (dbg_stamps && first_outer && ev == 1) ? dbg_stamps + 32 : nullptr);
         counters_from = 0;
         if (px.nranks > 1 && wave == 0 && !s_failed) {
             // ranks of one node: this GPU's totals become the totals over all ranks
@@ -1515,6 +1554,7 @@ __global__ __launch_bounds__(kT) void k_lm(const MatchRec *__restrict__ rec, uin
         if (s_failed) {  // uniform over the workgroup
             if (tid == 0) {
                 __hip_atomic_store(&state->error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (px.nranks > 1) p2p_publish_abort(px);  // the peers leave their waits for this rank at once
                 __hip_atomic_store(&report->error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
             return;
@@ -1727,16 +1767,8 @@ static int launch_match(ScanCtx &c, const float t[3], const float q[4], float ma
 }
 
 constexpr size_t kEvalLdsBytes = (size_t)28 * kAccStride * sizeof(double);
-constexpr unsigned long long kServerTimeoutTicks = 5000000ull;  // 50 ms of s_memrealtime (100 MHz)
-
-// LOM_TEST_SERVER_TIMEOUT_TICKS shortens the server's patience so that tests can exercise the
-// "server left, relaunch" path deterministically
-static unsigned long long server_timeout_ticks()
-{
-    const char *e = getenv("LOM_TEST_SERVER_TIMEOUT_TICKS");
-    if (e && *e) return strtoull(e, nullptr, 10);
-    return kServerTimeoutTicks;
-}
+// Every in-kernel wait is bounded by the handle's patience (lom_map::patience_ticks, 50 ms unless
+// LOM_OPT_DEVICE_PATIENCE_TICKS changed it; tests shorten it to exercise the give-up paths).
 
 static int eval_kernel_attrs(lom_map *m)
 {
@@ -1836,7 +1868,7 @@ static int launch_eval(ScanCtx &c, const double q[4], const double t[3], bool fr
                                    (const MatchRec *)m->scan_on.p, c.n, E, (const uint32_t *)d_block_counters(m),
                                    fresh_match ? c.match_blocks : 0u, m->d_mail, seq,
                                    reinterpret_cast<const EvalCmd *>(m->d_cmd), (unsigned long long)cmd->seq,
-                                   server_timeout_ticks());
+                                   m->patience_ticks);
                 LOM_HIP(m, hipGetLastError());
                 m->server_alive = true;
             } else {
@@ -1852,7 +1884,7 @@ static int launch_eval(ScanCtx &c, const double q[4], const double t[3], bool fr
             std::memset(out, 0, LOM_NSUMS * 8);
             rc = collect_records(m, nb, seq, out);
             c.wait_s += now_s() - t_w;
-            if (getenv("LOM_DEBUG_TIMING"))
+            if (m->opt_debug_timing)
                 fprintf(stderr, "eval %s launch %.1f us wait %.1f us\n", fresh_match ? "fresh" : "fixed",
                         (t_w - t_l) * 1e6, (now_s() - t_w) * 1e6);
             if (rc == LOM_OK) break;
@@ -1902,6 +1934,7 @@ static P2pArgs p2p_args(const lom_map *m)
     A.rank = m->p2p ? m->rank : 0;
     A.nranks = m->p2p ? m->nranks : 1;
     A.set_base = 0;
+    A.epoch = ~0ull;
     return A;
 }
 
@@ -1974,7 +2007,13 @@ static int align_chained(lom_map *m, const char *d_src, size_t n, size_t stride,
                   "AlignReport is written as 64-bit words");
     int rc = scan_buffers(m, (uint32_t)n, false);
     if (rc != LOM_OK) return rc;
+    if (!m->align_state.p) m->align_state_dirty = true;
     if ((rc = ensure(m, m->align_state, sizeof(AlignState))) != LOM_OK) return rc;
+    if (m->align_state_dirty) {
+        // a fresh allocation, or an align that ended in a give-up: its error flag must not be mistaken for this one's
+        LOM_HIP(m, hipMemsetAsync(m->align_state.p, 0, sizeof(AlignState), m->stream));
+        m->align_state_dirty = false;
+    }
     if (!m->xrec.p) {
         const size_t bytes = (size_t)2 * kMaxLmBlocksBig * kRecWords * sizeof(XWord);
         if ((rc = ensure(m, m->xrec, bytes)) != LOM_OK) return rc;
@@ -2007,8 +2046,11 @@ static int align_chained(lom_map *m, const char *d_src, size_t n, size_t stride,
     const unsigned long long seq0 = m->report_seq;
     int launched = 0;
     P2pArgs px = p2p_args(m);
-    unsigned long long *dbg = nullptr;  // LOM_DEBUG_LM: phase stamps of the last k_lm of the align
-    if (getenv("LOM_DEBUG_LM")) {
+    if (m->p2p) px.epoch = ++m->p2p_epoch;  // the same count on every rank: ranks issue the same sequence of aligns
+    const int give_up_outer = m->test_give_up_outer;  // one shot
+    m->test_give_up_outer = -1;
+    unsigned long long *dbg = nullptr;  // LOM_OPT_DEBUG_LM_STAMPS: phase stamps of the last k_lm of the align
+    if (m->opt_debug_lm) {
         if ((rc = ensure(m, m->dbg_stamps, 4096)) != LOM_OK) return rc;
         dbg = (unsigned long long *)m->dbg_stamps.p;
         LOM_HIP(m, hipMemsetAsync(dbg, 0, 40 * 8, m->stream));
@@ -2026,8 +2068,8 @@ static int align_chained(lom_map *m, const char *d_src, size_t n, size_t stride,
                                (AlignState *)m->align_state.p, init, i == 0 ? 1 : 0,
                                (const uint32_t *)d_block_counters(m), c.match_blocks, (XWord *)m->xrec.p, m->lm_seq,
                                reinterpret_cast<AlignReport *>(m->d_report), seq0 + (unsigned long long)i + 1,
-                               server_timeout_ticks(), dbg, px,
-                               (d_trace && i == trace_outer) ? d_trace : (double *)nullptr);
+                               m->patience_ticks, dbg, px,
+                               (d_trace && i == trace_outer) ? d_trace : (double *)nullptr, i == give_up_outer ? 1 : 0);
         };
         if (shape == kLmSmall)
             launch(k_lm<(int)kLmSmallThreads>);
@@ -2068,8 +2110,10 @@ static int align_chained(lom_map *m, const char *d_src, size_t n, size_t stride,
         __atomic_thread_fence(__ATOMIC_ACQUIRE);
         c.wait_s += now_s() - t_w;
         if (rp->error) {
+            // the kernels still enqueued see the flag in AlignState and return at once
             (void)hipStreamSynchronize(m->stream);
             m->report_seq = want;
+            m->align_state_dirty = true;
             set_error(m, LOM_ERR_HIP, "device solve: a workgroup timed out waiting for the others");
             return kDeviceLoopGaveUp;
         }
@@ -2139,24 +2183,43 @@ static int align_device(lom_map *m, const char *d_src, size_t n, size_t stride, 
                         const float guess_q[4], float out_t[3], float out_q[4], lom_align_stats *stats)
 {
     if (n >= 0x7FFFFFFFull) return set_error(m, LOM_ERR_ARG, "too many source points");
+    {   // an insert nobody has looked at since (no lom_map_status): the search must see its points
+        const int rcp = resolve_pending(m);
+        if (rcp != LOM_OK) return rcp;
+    }
     m->profiling = m->profile_period > 0 && (m->align_count++ % (unsigned)m->profile_period) == 0;
     bool fell_back = false;
-    if (!m->comm && (!m->host_comm || m->p2p) && !getenv("LOM_HOST_LM")) {
+    if (!m->comm && (!m->host_comm || m->p2p) && !m->opt_host_lm) {
         server_stop(m);
         int rc = align_chained(m, d_src, n, stride, guess_t, guess_q, out_t, out_q, stats);
         if (m->p2p) {
-            // The ranks agree on the outcome of every align: a time-out that lands on the last exchange
-            // of an align lets the peers that already hold all words finish with LOM_OK, and the rank
-            // that gave up must not redo the align alone (the host exchange pairs operations by its
-            // own counter only).  One status word through the host exchange; any failure anywhere
-            // sends every rank to the host-driven loop below.
-            double verdict[1] = {rc == LOM_OK ? 0.0 : 1.0};
-            if (lom_host_comm_allreduce((lom_host_comm *)m->host_comm, verdict, 1) != LOM_OK)
-                return set_error(m, LOM_ERR_COMM, "status exchange after a device-to-device align failed");
-            if (rc != LOM_OK && rc != kDeviceLoopGaveUp) return rc;
+            // The ranks agree on the outcome of EVERY align, whatever happened on this one: a time-out that lands
+            // on the last exchange of an align lets the peers that already hold all words finish with LOM_OK, and
+            // a rank that gave up -- or failed for good -- must neither redo the align alone nor leave its peers
+            // waiting (the host exchange pairs operations by its own counter only).  Two counts through the host
+            // exchange: ranks that gave up (recoverable: everybody redoes the align over the host exchange) and
+            // ranks that failed for good (nobody continues).  The deadline outlasts the device side: a rank can
+            // be late by its kernels' patience for a peer rank, once per pair still enqueued at worst (the abort
+            // words normally cut that to one patience), and an exchange nobody completes is ABANDONED, which
+            // every late rank sees (comm.cpp) -- round 2's failure was a fixed 60 s here against 10 x 10 s there.
+            const bool gave_up = rc == kDeviceLoopGaveUp, hard = rc != LOM_OK && !gave_up;
+            double verdict[2] = {gave_up ? 1.0 : 0.0, hard ? 1.0 : 0.0};
+            const double cross_s = (double)m->patience_ticks * 10.0 * 1e-8;
+            const double deadline_s = 30.0 + 2.0 * (kPairsAhead + 1) * cross_s;
+            if (host_comm_allreduce_deadline(m->host_comm, verdict, 2, deadline_s) != LOM_OK) {
+                m->p2p = false;
+                const std::string why = std::string("agreement after a device-to-device align failed: ") + host_comm_error(m->host_comm);
+                return set_error(m, LOM_ERR_COMM, why.c_str());
+            }
+            if (verdict[1] != 0.0) {  // some rank cannot continue: the same for all
+                m->p2p = false;
+                (void)hipStreamSynchronize(m->stream);
+                if (hard) return rc;
+                return set_error(m, LOM_ERR_COMM, "a peer rank failed during a device-to-device align");
+            }
             if (verdict[0] == 0.0) return LOM_OK;
-            fprintf(stderr, "lidar_odometry_amd: device-to-device exchange failed on some rank (%s); rank %d continues with the host exchange\n",
-                    m->last_error.empty() ? "a peer gave up" : m->last_error.c_str(), m->rank);
+            fprintf(stderr, "lidar_odometry_amd: device-to-device exchange given up on %d rank(s) (%s); rank %d redoes the align over the host exchange\n",
+                    (int)verdict[0], gave_up ? m->last_error.c_str() : "a peer gave up", m->rank);
             (void)hipStreamSynchronize(m->stream);
             m->p2p = false;
         } else if (rc != kDeviceLoopGaveUp) {
@@ -2181,6 +2244,8 @@ static int align_device(lom_map *m, const char *d_src, size_t n, size_t stride, 
     server_stop(m);
     if (rc != LOM_OK) {
         if (m->last_error.empty()) set_error(m, rc, "align failed");
+        // ranks of one node: a rank that leaves the loop tells its peers (they would wait for its sums otherwise)
+        if (m->host_comm) (void)lom_host_comm_abort((lom_host_comm *)m->host_comm);
         return rc == LOM_ERR_HOOK ? LOM_ERR_HIP : rc;
     }
     if (m->profiling && c.prof_used) {
@@ -2223,8 +2288,9 @@ int64_t lom_match_find_pairs(lom_map *m, const float *src, size_t n, size_t stri
     if (n == 0) return 0;
     LOM_HIP(m, hipSetDevice(m->device));
     const char *d_src = nullptr;
-    int rc = stage_scan(m, src, n, stride, &d_src);
+    int rc = resolve_pending(m);
     if (rc != LOM_OK) return rc;
+    if ((rc = stage_scan(m, src, n, stride, &d_src)) != LOM_OK) return rc;
     if ((rc = scan_buffers(m, (uint32_t)n, true)) != LOM_OK) return rc;
     ScanCtx c{m, d_src, stride, (uint32_t)n, 0};
     if ((rc = launch_match(c, t, q, max_dist, true)) != LOM_OK) return rc;
@@ -2265,7 +2331,9 @@ int lom_comm_attach_p2p(lom_map *m, lom_host_comm *hc)
     server_stop(m);
     // From here on every step is collective: a rank that fails locally still takes part in the
     // exchanges below, so that all ranks reach the same verdict.
-    const size_t bytes = (size_t)4 * kP2pMaxRanks * kRecWords * sizeof(XWord);
+    const size_t bytes = kP2pBufferBytes;  // four exchange sets + one abort word per rank
+    m->p2p_epoch = 0;
+    m->lm_launches = 0;  // the set pairs alternate with this count: the same on every rank from here on
     int ok = 1;
     struct Blob {
         hipIpcMemHandle_t handle;
@@ -2320,7 +2388,7 @@ int lom_comm_attach_p2p(lom_map *m, lom_host_comm *hc)
         const P2pArgs A = p2p_args(m);
         m->p2p = false;
         hipLaunchKernelGGL(k_p2p_selftest, dim3(1), dim3(64), 0, m->stream, A, m->lm_seq, 200,
-                           server_timeout_ticks(), (uint32_t *)m->results.p);
+                           m->patience_ticks, (uint32_t *)m->results.p);
         if (hipGetLastError() != hipSuccess ||
             hipMemcpyAsync(res, (uint32_t *)m->results.p, 8, hipMemcpyDeviceToHost, m->stream) != hipSuccess ||
             hipStreamSynchronize(m->stream) != hipSuccess)

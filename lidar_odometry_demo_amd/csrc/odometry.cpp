@@ -31,10 +31,11 @@ namespace {
 
 constexpr double kPi = 3.14159265358979323846;
 
-// LOM_DEBUG_TIMING=1: per-stage wall times of processCloud on stderr
+// LOM_DEBUG_TIMING=1 (read once, by lom_odometry_create): per-stage wall times of processCloud on stderr
 struct StageTimer {
-    bool on = getenv("LOM_DEBUG_TIMING") != nullptr;
+    bool on;
     double t0 = now(), last = t0;
+    explicit StageTimer(bool enabled) : on(enabled) {}
     static double now()
     {
         timespec ts;
@@ -522,7 +523,14 @@ struct lom_odometry {
     std::vector<lom_point_xyzirt> normalized, deskewed;
     lom_frontend *frontend = nullptr;  // :25-35 on the device (csrc/frontend.hip); LOM_HOST_FRONTEND=1 keeps them on the host
     bool temp_on_device = false;       // temp_cloud_ lives in the front end's HBM buffer
-    bool keyframe_has_voxels = false;  // keyframe_.size() != 0 (lidar_odometry.cpp:40), tracked on the host
+    // keyframe_.size() != 0 (lidar_odometry.cpp:40), tracked on the host.  Atomic: the deferred keyframe update of
+    // frame k writes it on the helper thread while frame k+1's stages read it.  A stale `true` is harmless -- the
+    // frame prepares a matching cloud it does not use, and the init branch collects the update cloud's count --
+    // and it never goes from false to true on the helper thread.
+    std::atomic<bool> keyframe_has_voxels{false};
+    bool test_force_host_redo = false;  // LOM_OPT_TEST_FORCE_HOST_REDO
+    bool debug_timing = false;          // LOM_DEBUG_TIMING=1 at create / LOM_OPT_DEBUG_TIMING
+    int64_t grid_redos = 0;             // frames sent to the host stages because an in-kernel scan gave up
     size_t temp_points = 0;  // temp_cloud_ (lidar_odometry.h:73-77) = the first temp_points records of `deskewed`
     ClassifyScratch classify_scratch;
     std::vector<float> planar, planar_n, filtered, filtered_n, down, down_n, match, upd, upd_n;
@@ -584,6 +592,7 @@ int lom_odometry_create(const lom_odometry_params *params, int device, lom_odome
     lom_odometry *o = new (std::nothrow) lom_odometry();
     if (!o) return LOM_ERR_OOM;
     o->cfg = *params;
+    o->debug_timing = getenv("LOM_DEBUG_TIMING") != nullptr;
     {
         unsigned hw = std::thread::hardware_concurrency();
         if (const char *e = getenv("LOM_HOST_THREADS")) hw = (unsigned)std::max(1, atoi(e));
@@ -664,6 +673,35 @@ int lom_odometry_debug_set_state(lom_odometry *o, const lom_pose *previous, cons
     return rc;
 }
 
+int lom_odometry_set_option(lom_odometry *o, int option, int64_t value)
+{
+    if (!o) return LOM_ERR_ARG;
+    int rc = o->settle();
+    if (rc != LOM_OK) return rc;
+    switch (option) {
+    case LOM_OPT_TEST_FORCE_HOST_REDO: o->test_force_host_redo = value != 0; return LOM_OK;
+    case LOM_OPT_DEBUG_TIMING: o->debug_timing = value != 0; return lom_map_set_option(o->keyframe, option, value);
+    case LOM_OPT_TEST_GRID_GIVE_UP:  // the front end's scan of the next frame
+        return o->frontend ? lom_frontend_set_option(o->frontend, option, value) : LOM_ERR_STATE;
+    case LOM_OPT_TEST_GRID_GIVE_UP_MATCHING_DS: return lom_map_set_option(o->matching_ds, LOM_OPT_TEST_GRID_GIVE_UP, value);
+    case LOM_OPT_TEST_GRID_GIVE_UP_UPDATE_DS:  // the workspace of the NEXT frame
+        return lom_map_set_option(o->update_ds2[o->parity ^ 1], LOM_OPT_TEST_GRID_GIVE_UP, value);
+    case LOM_OPT_TEST_GRID_GIVE_UP_KEYFRAME: return lom_map_set_option(o->keyframe, LOM_OPT_TEST_GRID_GIVE_UP, value);
+    default: return lom_map_set_option(o->keyframe, option, value);  // the align's switches live on the keyframe handle
+    }
+}
+
+int64_t lom_odometry_debug_counter(const lom_odometry *o, int which)
+{
+    if (!o) return LOM_ERR_ARG;
+    if (which == LOM_COUNTER_GRID_REDOS) {
+        int64_t v = o->grid_redos;
+        for (lom_map *m : {o->keyframe, o->update_ds2[0], o->update_ds2[1], o->matching_ds}) v += lom_map_debug_counter(m, which);
+        return v;
+    }
+    return LOM_ERR_ARG;
+}
+
 int lom_odometry_get_stats(const lom_odometry *o, lom_odometry_frame_stats *out)
 {
     if (!o || !out) return LOM_ERR_ARG;
@@ -685,6 +723,11 @@ struct FrameInputs {  // what the stages before the align leave in HBM for it an
     // workspace); collect_update() waits for them.  Returns LOM_OK / LOM_ERR_RANGE / LOM_ERR_HIP.
     lom_map *pending_update = nullptr;
     uint32_t pending_seq = 0;
+    // the front end's filtered cloud (input of both down-samplers), for the redo of an update down-sampling whose
+    // in-kernel scan gave up
+    const float *d_fx = nullptr, *d_fn = nullptr;
+    int64_t nf = 0;
+    static constexpr int kScanGaveUp = 2;
     int collect_update(const char **error_out)
     {
         if (!pending_update) return LOM_OK;
@@ -696,10 +739,7 @@ struct FrameInputs {  // what the stages before the align leave in HBM for it an
             if (error_out) *error_out = lom_last_error(m);
             return rc;
         }
-        if (w[2] == pending_seq) {
-            if (error_out) *error_out = "a workgroup timed out waiting for the others of its grid";
-            return LOM_ERR_HIP;
-        }
+        if (w[2] == pending_seq) return kScanGaveUp;  // nothing written, workspace at rest: the caller redoes it
         if (w[1] == pending_seq) {
             if (error_out) *error_out = "coordinate / voxel_size out of range or not finite";
             return LOM_ERR_RANGE;
@@ -808,7 +848,8 @@ int stages_on_device(lom_odometry *o, const lom_point_xyzirt *pts, size_t n, con
         return LOM_OK;
     };
     lom_map *reader = o->update_ds;
-    if (o->keyframe_has_voxels) {
+    const bool has_keyframe = o->keyframe_has_voxels.load();  // one look; possibly a stale `true` (see the member)
+    if (has_keyframe) {
         if ((rc = lom_voxel_downsample_device_nowait(o->matching_ds, o->cfg.keyframe_matching_voxel_size, d_fx, nullptr, bound,
                                                      d_fe + 1, 12, &in.d_match, nullptr, &d_nm)) != LOM_OK)
             return fail_map(o, rc, o->matching_ds);
@@ -841,15 +882,13 @@ int stages_on_device(lom_odometry *o, const lom_point_xyzirt *pts, size_t n, con
     }
     tm.lap("settle");
     const uint32_t fe_seq = lom_frontend_sequence(o->frontend);
-    const uint32_t seq_ds = o->keyframe_has_voxels ? seq_m : seq_u;
-    if (got[3] == fe_seq || got[6] == seq_ds) {
-        (void)in.collect_update(nullptr);
-        o->error = "a workgroup timed out waiting for the others of its grid";
-        return LOM_ERR_HIP;
-    }
-    // an azimuth on a bin boundary, or an organised cloud beyond the buffers (LOM_TEST_FORCE_HOST_REDO: tests take
-    // this path on every frame)
-    if (got[2] == fe_seq || getenv("LOM_TEST_FORCE_HOST_REDO")) {
+    const uint32_t seq_ds = has_keyframe ? seq_m : seq_u;
+    // An azimuth on a bin boundary, an organised cloud beyond the buffers -- or an in-kernel scan of the front end
+    // or of the down-sampler that gave up waiting: such a grid has written nothing and left its tables at rest
+    // (grid_scan.hpp), so the frame simply takes the host stages, whose kernels wait for nobody.
+    // (LOM_OPT_TEST_FORCE_HOST_REDO: tests take this path on every frame.)
+    if (got[2] == fe_seq || got[3] == fe_seq || got[6] == seq_ds || o->test_force_host_redo) {
+        if (got[3] == fe_seq || got[6] == seq_ds) o->grid_redos++;
         (void)in.collect_update(nullptr);
         return 1;
     }
@@ -860,10 +899,31 @@ int stages_on_device(lom_odometry *o, const lom_point_xyzirt *pts, size_t n, con
     }
     cur.planar_points = got[0];
     cur.filtered_points = got[1];
-    if (o->keyframe_has_voxels) {
+    in.d_fx = d_fx;
+    in.d_fn = d_fn;
+    in.nf = got[1];
+    if (has_keyframe) {
         in.nm = got[4];
     } else {
         in.nd = got[4];
+    }
+    return LOM_OK;
+}
+
+// the update cloud's size and verdict; a down-sampling whose in-kernel scan gave up is redone here from the
+// filtered cloud still in HBM (lom_voxel_downsample_device waits for its own verdict and falls back to the
+// multi-launch scan by itself)
+int collect_or_redo_update(lom_odometry *o, FrameInputs &in, const char **why)
+{
+    lom_map *ws = in.pending_update;
+    int rc = in.collect_update(why);
+    if (rc != FrameInputs::kScanGaveUp) return rc;
+    o->grid_redos++;
+    in.nd = lom_voxel_downsample_device(ws, o->cfg.keyframe_update_voxel_size, in.d_fx, in.d_fn, (size_t)in.nf, 12,
+                                        &in.d_down, &in.d_down_n);
+    if (in.nd < 0) {
+        *why = lom_last_error(ws);
+        return (int)in.nd;
     }
     return LOM_OK;
 }
@@ -877,7 +937,7 @@ int lom_odometry_process_cloud(lom_odometry *o, const lom_point_xyzirt *pts, siz
     if (!o || (!pts && n)) return LOM_ERR_ARG;
     try {
         lom_odometry_frame_stats cur{};  // becomes o->last when the frame is through
-        StageTimer tm;
+        StageTimer tm(o->debug_timing);
         lom_pose relative, rel_inv, ident, guess, result;
         lom_pose_relative_to(&o->previous, &o->current, &relative);  // :27
         // :28 previous_transform_ = current_transform_ -- committed where the frame succeeds (the
@@ -900,6 +960,15 @@ int lom_odometry_process_cloud(lom_odometry *o, const lom_point_xyzirt *pts, siz
         // :40 keyframe_.size() == 0 -- known on the host: the keyframe is empty until a frame has put voxels
         // into it (nd > 0 points always create at least one), and stays non-empty unless a cleanup empties it
         if (!o->keyframe_has_voxels) {  // :40-44 init keyframe
+            {   // the stages ran on a stale "has voxels" (the previous update emptied the keyframe meanwhile): the
+                // update cloud's count is still on its way
+                const char *why = nullptr;
+                const int rcu = collect_or_redo_update(o, in, &why);
+                if (rcu != LOM_OK) {
+                    o->error = why ? why : "keyframe-update down-sampling failed";
+                    return rcu;
+                }
+            }
             if ((rc = lom_map_add_points_device(o->keyframe, in.d_down, in.d_down_n, (size_t)in.nd, 12)) != LOM_OK)
                 return fail_map(o, rc, o->keyframe);
             cur.initialised_keyframe = 1;
@@ -920,7 +989,7 @@ int lom_odometry_process_cloud(lom_odometry *o, const lom_point_xyzirt *pts, siz
         }
         {   // the update cloud was down-sampled beside the align: its size and verdict (long since on the host)
             const char *why = nullptr;
-            const int rcu = in.collect_update(&why);
+            const int rcu = collect_or_redo_update(o, in, &why);
             if (rcu != LOM_OK) {
                 o->error = why ? why : "keyframe-update down-sampling failed";
                 return rcu;

@@ -411,7 +411,7 @@ template <int kItems>  // consecutive points per thread: 1 up to 65536 points, 4
 __global__ __launch_bounds__(kThreads) void k_ds_emit(Slot *table, uint32_t n, const uint32_t *n_dev,
                                                       const uint32_t *__restrict__ pt_slot, uint32_t *head, const char *xyz,
                                                       const char *nrm, size_t stride, float *out_xyz, float *out_nrm,
-                                                      Granule *agg, uint32_t seq, uint32_t *words)
+                                                      Granule *agg, uint32_t seq, uint32_t *words, uint32_t test_fail_from)
 {
     __shared__ unsigned long long s_w[8];
     const uint32_t base = (blockIdx.x * kThreads + threadIdx.x) * kItems;
@@ -432,7 +432,8 @@ __global__ __launch_bounds__(kThreads) void k_ds_emit(Slot *table, uint32_t n, c
     }
     unsigned long long total;
     const unsigned long long excl = block_scan64(mine, s_w, total);
-    const unsigned long long before = grid_prefix64(total, agg, seq, words + 7, s_w);
+    bool gave_up;
+    const unsigned long long before = grid_prefix64(total, agg, seq, words + 7, s_w, gave_up, test_fail_from);
     uint32_t at = (uint32_t)(before + excl);
 #pragma unroll
     for (int k = 0; k < kItems; k++) {
@@ -440,18 +441,20 @@ __global__ __launch_bounds__(kThreads) void k_ds_emit(Slot *table, uint32_t n, c
         const uint32_t i = base + k;
         const size_t d = (size_t)at * 3;
         at++;
-        const float *p = point_at(xyz, i, stride);
-        out_xyz[d] = p[0];
-        out_xyz[d + 1] = p[1];
-        out_xyz[d + 2] = p[2];
-        if (out_nrm) {
-            if (nrm) {
-                const float *q = point_at(nrm, i, stride);
-                out_nrm[d] = q[0];
-                out_nrm[d + 1] = q[1];
-                out_nrm[d + 2] = q[2];
-            } else {
-                out_nrm[d] = out_nrm[d + 1] = out_nrm[d + 2] = 0.f;
+        if (!gave_up) {  // without a prefix there is no place to write to; the workspace still goes back to rest below
+            const float *p = point_at(xyz, i, stride);
+            out_xyz[d] = p[0];
+            out_xyz[d + 1] = p[1];
+            out_xyz[d + 2] = p[2];
+            if (out_nrm) {
+                if (nrm) {
+                    const float *q = point_at(nrm, i, stride);
+                    out_nrm[d] = q[0];
+                    out_nrm[d + 1] = q[1];
+                    out_nrm[d + 2] = q[2];
+                } else {
+                    out_nrm[d] = out_nrm[d + 1] = out_nrm[d + 2] = 0.f;
+                }
             }
         }
         Slot e;
@@ -461,7 +464,8 @@ __global__ __launch_bounds__(kThreads) void k_ds_emit(Slot *table, uint32_t n, c
         table[h[k]] = e;
         head[h[k]] = 0xFFFFFFFFu;
     }
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) words[4] = (uint32_t)(before + total);  // voxels kept
+    // voxels kept; a grid that gave up reports none (whoever consumes the count on the device finds an empty cloud)
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) words[4] = gave_up ? 0u : (uint32_t)(before + total);
 }
 
 // ---- insert, four kernels ----------------------------------------------------------------------
@@ -498,7 +502,7 @@ __global__ __launch_bounds__(kThreads) void k_ins_assign2(Slot *table, uint32_t 
                                                           const uint32_t *__restrict__ bkt_head, uint32_t *bkt_off,
                                                           uint32_t *bkt_old, const uint32_t *n_vox_dev,
                                                           unsigned long long *slab_key, Granule *agg, uint32_t seq,
-                                                          uint32_t *words)
+                                                          uint32_t *words, uint32_t test_fail_from)
 {
     __shared__ unsigned long long s_w[8];
     const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
@@ -519,8 +523,11 @@ __global__ __launch_bounds__(kThreads) void k_ins_assign2(Slot *table, uint32_t 
     unsigned long long total;
     const unsigned long long v = ((unsigned long long)m << 32) | (is_new ? 1ull : 0ull);
     const unsigned long long excl = block_scan64(v, s_w, total);
-    const unsigned long long before = grid_prefix64(total, agg, seq, words + 7, s_w);
-    if (is_head) {
+    bool gave_up;
+    const unsigned long long before = grid_prefix64(total, agg, seq, words + 7, s_w, gave_up, test_fail_from);
+    // A workgroup without a prefix assigns nothing; what the others assigned before the give-up is taken back by
+    // k_ins_place2 (slab ids at or beyond the voxel counter, which such a call does not advance).
+    if (is_head && !gave_up) {
         const unsigned long long at = before + excl;
         bkt_off[h] = (uint32_t)(at >> 32);
         bkt_old[h] = old_count;
@@ -530,7 +537,7 @@ __global__ __launch_bounds__(kThreads) void k_ins_assign2(Slot *table, uint32_t 
             slab_key[slab] = table[h].key;
         }
     }
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) words[0] = (uint32_t)(before + total);  // new voxels of this call
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0 && !gave_up) words[0] = (uint32_t)(before + total);  // new voxels of this call
 }
 
 __global__ __launch_bounds__(kThreads) void k_ins_scatter2(uint32_t n, const uint32_t *__restrict__ pt_slot,
@@ -541,7 +548,7 @@ __global__ __launch_bounds__(kThreads) void k_ins_scatter2(uint32_t n, const uin
                                                            const uint32_t *words)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n || words[5] == seq) return;
+    if (i >= n || words[5] == seq || words[7] == seq) return;  // a call that failed (range / grid give-up) inserts nothing
     const uint32_t h = pt_slot[i];
     const uint32_t off = bkt_off[h];
     items[off + pt_pos[i]] = i;
@@ -563,7 +570,15 @@ __global__ __launch_bounds__(kThreads) void k_ins_place2(Slot *table, uint32_t n
     const uint32_t h = pt_slot[i];
     if (h == kInvalidSlot) return;
     const bool is_head = bkt_head[h] == i;  // only this thread resets the word, and only after this read
-    if (words[5] != seq) {
+    if (words[7] == seq) {
+        // the scan of k_ins_assign2 gave up part-way: take back the slab ids the workgroups before the give-up
+        // handed to NEW voxels (at or beyond the voxel counter, which this call does not advance), so that the
+        // table is what it was before the call -- apart from claimed keys without a voxel, as after a range error
+        if (is_head) {
+            const uint32_t slab = table[h].slab;
+            if (slab != kNoSlab && slab >= *n_vox_dev) table[h].slab = kNoSlab;
+        }
+    } else if (words[5] != seq) {
         const uint32_t old = bkt_old[h];
         const uint32_t slab = table[h].slab;
         const uint32_t m = pt_m[i];
@@ -615,7 +630,7 @@ __global__ void k_cleanup_flag(const float *pts, uint32_t K, uint32_t n_vox, flo
 template <int kItems>
 __global__ __launch_bounds__(kThreads) void k_cleanup_scan(const float *pts, uint32_t K, uint32_t n_vox, float cx, float cy,
                                                            float cz, float r2, uint32_t *keep, uint32_t *newid,
-                                                           Granule *agg, uint32_t seq, uint32_t *words)
+                                                           Granule *agg, uint32_t seq, uint32_t *words, uint32_t test_fail_from)
 {
     __shared__ unsigned long long s_w[8];
     const uint32_t base = (blockIdx.x * kThreads + threadIdx.x) * kItems;
@@ -634,12 +649,13 @@ __global__ __launch_bounds__(kThreads) void k_cleanup_scan(const float *pts, uin
     }
     unsigned long long total;
     const unsigned long long excl = block_scan64(mine, s_w, total);
-    const unsigned long long before = grid_prefix64(total, agg, seq, words + 7, s_w);
+    bool gave_up;
+    const unsigned long long before = grid_prefix64(total, agg, seq, words + 7, s_w, gave_up, test_fail_from);
     uint32_t run = (uint32_t)(before + excl);
 #pragma unroll
     for (int k = 0; k < kItems; k++) {
         const uint32_t s = base + k;
-        if (s < n_vox) {
+        if (s < n_vox && !gave_up) {  // keep[] / newid[] are scratch: the host redoes a scan that gave up
             keep[s] = f[k];
             newid[s] = run;
         }
@@ -728,10 +744,14 @@ static uint32_t *d_word(lom_map *m, int i) { return (uint32_t *)m->scr[S_MISC].p
 int read_words(lom_map *m, int first, int n);
 
 // exact voxel count on the host (waits for pending inserts of this handle)
+int resolve_pending(lom_map *m);
+
 static int refresh_nvox(lom_map *m)
 {
+    int rc = resolve_pending(m);
+    if (rc != LOM_OK) return rc;
     if (!m->n_vox_stale) return LOM_OK;
-    int rc = read_words(m, 6, 1);
+    rc = read_words(m, 6, 1);
     if (rc != LOM_OK) return rc;
     m->n_vox = m->h_flags[0];
     m->n_vox_ub = m->n_vox;
@@ -899,8 +919,26 @@ static int ensure_rest(lom_map *m, DeviceBuf &b, size_t bytes, int fill)
 
 static Granule *d_agg(lom_map *m) { return (Granule *)((char *)m->scr[S_MISC].p + 256); }
 
+static int add_points_device(lom_map *m, const char *d_xyz, const char *d_nrm, size_t n, size_t stride,
+                             bool validated_on_host, bool sync_status, bool allow_shrink = true, bool multi_launch = false);
+
+// one-shot test hook (LOM_OPT_TEST_GRID_GIVE_UP): the first workgroup that gives up in the next in-kernel scan
+static uint32_t take_test_fail_from(lom_map *m)
+{
+    const int v = m->test_grid_give_up;
+    if (v >= 65536) {  // + 65536 per in-kernel scan to let pass first
+        m->test_grid_give_up = v - 65536;
+        return 0xFFFFFFFFu;
+    }
+    m->test_grid_give_up = -1;
+    return v < 0 ? 0xFFFFFFFFu : (uint32_t)v;
+}
+
 // deferred verdict of the calls enqueued since the last check (waits for them): a point out of range
-// (such a call inserted / returned nothing) or a workgroup that gave up waiting inside a single-pass kernel
+// (such a call inserted / returned nothing) or a workgroup that gave up waiting inside a single-pass kernel.
+// A call that gave up has changed nothing (grid_scan.hpp); if it is the handle's last insert -- whose input
+// buffers the caller keeps valid until this check -- it is redone here with the multi-launch scan, whose
+// kernels do not wait for each other.
 static int map_status(lom_map *m)
 {
     int rc = read_words(m, 5, 3);  // [0] range flag, [1] voxel counter, [2] grid error: sequence numbers of failed calls
@@ -912,20 +950,52 @@ static int map_status(lom_map *m)
         m->n_vox_ub = m->n_vox;
         m->n_vox_stale = false;
     }
-    if (m->h_flags[2] > checked) return set_error(m, LOM_ERR_HIP, "a workgroup timed out waiting for the others of its grid");
-    if (m->h_flags[0] > checked) return set_error(m, LOM_ERR_RANGE, "coordinate / voxel_size out of range or not finite");
+    const uint32_t grid_seq = m->h_flags[2], range_seq = m->h_flags[0];
+    const size_t pending = m->pending_n;
+    m->pending_n = 0;  // the last single-pass insert is through, one way or the other
+    if (grid_seq > checked && grid_seq != m->grid_resolved_seq) {
+        if (grid_seq == m->pending_seq && pending) {
+            m->grid_redos++;
+            m->grid_resolved_seq = grid_seq;
+            const int rc2 = add_points_device(m, m->pending_xyz, m->pending_nrm, pending, m->pending_stride, false, true, true, true);
+            if (rc2 != LOM_OK) return rc2;
+            if (range_seq > checked && range_seq != grid_seq)
+                return set_error(m, LOM_ERR_RANGE, "coordinate / voxel_size out of range or not finite");
+            return LOM_OK;
+        }
+        return set_error(m, LOM_ERR_HIP,
+                         "a workgroup timed out waiting for the others of its grid; that call changed nothing, repeat it");
+    }
+    if (range_seq > checked) return set_error(m, LOM_ERR_RANGE, "coordinate / voxel_size out of range or not finite");
     return LOM_OK;
+}
+
+// The handle's last single-pass insert has not been looked at yet (a caller that never asks for lom_map_status):
+// before anything consumes or changes the map, see whether its in-kernel scan gave up, and redo it if so.
+// Callers that check lom_map_status() themselves (the streaming path) never pay this read-back.
+int resolve_pending(lom_map *m)
+{
+    if (!m->pending_n) return LOM_OK;
+    int rc = read_words(m, 7, 1);
+    if (rc != LOM_OK) return rc;
+    const size_t n = m->pending_n;
+    m->pending_n = 0;
+    if (m->h_flags[0] != m->pending_seq) return LOM_OK;
+    m->grid_redos++;
+    m->grid_resolved_seq = m->pending_seq;
+    return add_points_device(m, m->pending_xyz, m->pending_nrm, n, m->pending_stride, false, true, true, true);
 }
 
 // sync_status: wait for the insert's verdict (LOM_ERR_RANGE when a point's index is out of range; such a
 // call inserts nothing).  Without it the call only enqueues; lom_map_status() reports later.
 static int add_points_device(lom_map *m, const char *d_xyz, const char *d_nrm, size_t n, size_t stride,
-                             bool validated_on_host, bool sync_status, bool allow_shrink = true)
+                             bool validated_on_host, bool sync_status, bool allow_shrink, bool multi_launch)
 {
     if (n == 0) return LOM_OK;
     if (n >= 0x7FFFFFFFull) return set_error(m, LOM_ERR_ARG, "too many points in one call");
     const uint32_t N = (uint32_t)n;
     int rc;
+    if ((rc = resolve_pending(m)) != LOM_OK) return rc;  // inserts apply in call order
     // 1. table capacity for the worst case (every point a new voxel); shrunk afterwards
     uint64_t worst = (uint64_t)m->n_vox_ub + N;
     if ((uint64_t)m->cap < 2 * worst) {
@@ -934,7 +1004,7 @@ static int add_points_device(lom_map *m, const char *d_xyz, const char *d_nrm, s
         if ((uint64_t)m->cap < 2 * worst && (rc = rehash(m, next_pow2(4 * worst))) != LOM_OK) return rc;
     }
     // 2. scratch
-    const bool one_pass = N <= kOnePassMax;
+    const bool one_pass = N <= kOnePassMax && !multi_launch;
     if ((rc = ensure(m, m->scr[S_PT_SLOT], (size_t)N * 4)) != LOM_OK) return rc;
     if ((rc = ensure(m, m->scr[S_PT_POS], (size_t)N * 4)) != LOM_OK) return rc;
     if ((rc = ensure(m, m->scr[S_PT_OFF], (size_t)N * 4)) != LOM_OK) return rc;
@@ -982,7 +1052,14 @@ static int add_points_device(lom_map *m, const char *d_xyz, const char *d_nrm, s
                            m->d_slab_key, boff, bold, seq, words);
     } else {
         hipLaunchKernelGGL(k_ins_assign2, g, b, 0, m->stream, m->d_table, N, pt_slot, bcnt, bhead, boff, bold, d_nvox(m),
-                           m->d_slab_key, d_agg(m), seq, words);
+                           m->d_slab_key, d_agg(m), seq, words, take_test_fail_from(m));
+        // should its scan give up, lom_map_status() / the wait below redoes this insert: the caller keeps the
+        // input valid until then
+        m->pending_xyz = d_xyz;
+        m->pending_nrm = d_nrm;
+        m->pending_n = n;
+        m->pending_stride = stride;
+        m->pending_seq = seq;
     }
     hipLaunchKernelGGL(k_ins_scatter2, g, b, 0, m->stream, N, pt_slot, pt_pos, boff, bcnt, items, pt_off, pt_m, seq, words);
     hipLaunchKernelGGL(k_ins_place2, g, b, 0, m->stream, m->d_table, N, pt_slot, pt_off, pt_m, bcnt, bhead, bold, items,
@@ -991,7 +1068,7 @@ static int add_points_device(lom_map *m, const char *d_xyz, const char *d_nrm, s
     m->table_clean = false;
     m->n_vox_ub = (uint32_t)std::min<uint64_t>(worst, 0xFFFFFFFFull);
     m->n_vox_stale = true;
-    if (sync_status && !validated_on_host) {
+    if (sync_status && (!validated_on_host || multi_launch)) {
         if ((rc = map_status(m)) != LOM_OK) return rc;
     }
     // keep the table dense enough to stay cache-resident: load factor in (1/16, 1/2] (measured on C2/C3:
@@ -1133,6 +1210,10 @@ int lom_map_create(float voxel_size, size_t max_points, size_t capacity_hint, in
     m->device = device;
     m->voxel_size = voxel_size;
     m->K = (uint32_t)max_points;
+    // the environment is looked at here and nowhere on the align path (lom_map_set_option changes the switches later)
+    m->opt_host_lm = getenv("LOM_HOST_LM") != nullptr;
+    m->opt_debug_lm = getenv("LOM_DEBUG_LM") != nullptr;
+    m->opt_debug_timing = getenv("LOM_DEBUG_TIMING") != nullptr;
     hipError_t e;
     if ((e = hipSetDevice(device)) != hipSuccess ||
         (e = hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking)) != hipSuccess ||
@@ -1224,6 +1305,36 @@ int lom_map_set_profiling(lom_map *m, int period)
     return LOM_OK;
 }
 
+int lom_map_set_option(lom_map *m, int option, int64_t value)
+{
+    if (!m) return LOM_ERR_ARG;
+    switch (option) {
+    case LOM_OPT_HOST_LM: m->opt_host_lm = value != 0; return LOM_OK;
+    case LOM_OPT_DEVICE_PATIENCE_TICKS:
+        if (value < 1) return LOM_ERR_ARG;
+        m->patience_ticks = (unsigned long long)value;
+        return LOM_OK;
+    case LOM_OPT_DEBUG_LM_STAMPS: m->opt_debug_lm = value != 0; return LOM_OK;
+    case LOM_OPT_DEBUG_TIMING: m->opt_debug_timing = value != 0; return LOM_OK;
+    case LOM_OPT_TEST_GIVE_UP_AT_OUTER:
+        if (value < -1 || value >= 35) return LOM_ERR_ARG;
+        m->test_give_up_outer = (int)value;
+        return LOM_OK;
+    case LOM_OPT_TEST_GRID_GIVE_UP:
+        if (value < -1 || value >= (1 << 20)) return LOM_ERR_ARG;
+        m->test_grid_give_up = (int)value;
+        return LOM_OK;
+    default: return set_error(m, LOM_ERR_ARG, "unknown option");
+    }
+}
+
+int64_t lom_map_debug_counter(const lom_map *m, int which)
+{
+    if (!m) return LOM_ERR_ARG;
+    if (which == LOM_COUNTER_GRID_REDOS) return (int64_t)m->grid_redos;
+    return LOM_ERR_ARG;
+}
+
 int lom_map_clear(lom_map *m, float voxel_size)
 {
     if (!m || !(voxel_size > 0.f)) return LOM_ERR_ARG;
@@ -1233,6 +1344,7 @@ int lom_map_clear(lom_map *m, float voxel_size)
     m->n_vox_ub = 0;
     m->n_vox_stale = false;
     m->n_points = 0;
+    m->pending_n = 0;
     if (!m->table_clean) {
         hipLaunchKernelGGL(k_table_init, dim3(blocks_for(m->cap)), dim3(kThreads), 0, m->stream, m->d_table, m->cap);
         LOM_HIP(m, hipMemsetAsync(d_nvox(m), 0, 4, m->stream));
@@ -1342,8 +1454,9 @@ int lom_map_add_points(lom_map *m, const float *xyz, const float *nrm, size_t n,
         if (bad) return set_error(m, LOM_ERR_RANGE, "coordinate / voxel_size out of range or not finite");
     }
     const char *dx = nullptr, *dn = nullptr;
-    int rc = stage_host_points(m, xyz, nrm, n, stride, &dx, &dn);
+    int rc = resolve_pending(m);  // before the staging buffers (a pending insert's input) are overwritten
     if (rc != LOM_OK) return rc;
+    if ((rc = stage_host_points(m, xyz, nrm, n, stride, &dx, &dn)) != LOM_OK) return rc;
     // the caller's buffer has been copied into the pinned bounce buffer: no need to wait for the GPU
     return add_points_device(m, dx, dn, n, stride, true, false);
 }
@@ -1367,7 +1480,7 @@ int lom_map_radius_cleanup(lom_map *m, const float center[3], float radius)
         constexpr int kItems = decltype(items)::value;
         hipLaunchKernelGGL((k_cleanup_scan<kItems>), dim3(blocks_for((nv + kItems - 1) / kItems)), dim3(kThreads), 0,
                            m->stream, m->d_pts, m->K, nv, center[0], center[1], center[2], r2, keep, newid, d_agg(m), seq,
-                           d_word(m, 0));
+                           d_word(m, 0), take_test_fail_from(m));
     };
     if (nv <= kOnePassMax)
         launch_scan(std::integral_constant<int, 1>());
@@ -1385,7 +1498,16 @@ int lom_map_radius_cleanup(lom_map *m, const float center[3], float radius)
     }
     LOM_HIP(m, hipGetLastError());
     if ((rc = read_words(m, 4, 4)) != LOM_OK) return rc;
-    if (m->h_flags[3] == seq) return set_error(m, LOM_ERR_HIP, "a workgroup timed out waiting for the others of its grid");
+    if (one_pass && m->h_flags[3] == seq) {
+        // the in-kernel scan gave up (it has written scratch only): flags + multi-launch scan instead
+        m->grid_redos++;
+        m->status_seq = std::max(m->status_seq, seq);
+        hipLaunchKernelGGL(k_cleanup_flag, dim3(blocks_for(nv)), dim3(kThreads), 0, m->stream, m->d_pts, m->K, nv,
+                           center[0], center[1], center[2], r2, keep);
+        LOM_HIP(m, hipGetLastError());
+        if ((rc = scan_exclusive(m, keep, newid, nv, d_word(m, 4), (uint32_t *)m->scr[S_SCAN].p)) != LOM_OK) return rc;
+        if ((rc = read_words(m, 4, 1)) != LOM_OK) return rc;
+    }
     const uint32_t n_keep = m->h_flags[0];
     if (n_keep == nv) return LOM_OK;
     // stable compaction into the second (persistent) set of slab arrays, swap, rebuild the table
@@ -1430,7 +1552,7 @@ int64_t lom_map_size(const lom_map *cm)
 {
     lom_map *m = const_cast<lom_map *>(cm);
     if (!m) return LOM_ERR_ARG;
-    if (m->n_vox_stale) {
+    if (m->n_vox_stale || m->pending_n) {
         if (hipSetDevice(m->device) != hipSuccess) return LOM_ERR_HIP;
         const int rc = refresh_nvox(m);
         if (rc != LOM_OK) return rc;
@@ -1449,13 +1571,13 @@ int64_t lom_map_point_count(const lom_map *cm)
 // wait: read the count and the verdict back (one synchronisation); otherwise the call only enqueues and
 // the count stays on the device (d_word(m, 4)) for the kernels that consume the result.
 static int downsample_core(lom_map *m, float voxel_size, const char *dx, const char *dn, uint32_t N, size_t stride,
-                           bool want_normals, bool wait, const uint32_t *n_dev = nullptr)
+                           bool want_normals, bool wait, const uint32_t *n_dev = nullptr, bool multi_launch = false)
 {
     int rc;
     if ((uint64_t)m->cap < 2ull * N) {
         if ((rc = rehash(m, next_pow2(4ull * N))) != LOM_OK) return rc;
     }
-    const bool one_pass = N <= 4 * kOnePassMax;
+    const bool one_pass = N <= 4 * kOnePassMax && !multi_launch;
     if ((rc = ensure(m, m->scr[S_PT_SLOT], (size_t)N * 4)) != LOM_OK) return rc;
     if ((rc = ensure_rest(m, m->scr[S_DS_HEAD], (size_t)m->cap * 4, 0xFF)) != LOM_OK) return rc;
     if ((rc = ensure(m, m->scr[S_ITEMS], (size_t)N * 12)) != LOM_OK) return rc;     // compacted xyz
@@ -1471,10 +1593,10 @@ static int downsample_core(lom_map *m, float voxel_size, const char *dx, const c
     if (one_pass) {
         if (N <= kOnePassMax)
             hipLaunchKernelGGL(k_ds_emit<1>, g, b, 0, m->stream, m->d_table, N, n_dev, pt_slot, head, dx, dn, stride, oxyz,
-                               onrm, d_agg(m), seq, d_word(m, 0));
+                               onrm, d_agg(m), seq, d_word(m, 0), take_test_fail_from(m));
         else
             hipLaunchKernelGGL(k_ds_emit<4>, dim3(blocks_for((N + 3) / 4)), b, 0, m->stream, m->d_table, N, n_dev, pt_slot,
-                               head, dx, dn, stride, oxyz, onrm, d_agg(m), seq, d_word(m, 0));
+                               head, dx, dn, stride, oxyz, onrm, d_agg(m), seq, d_word(m, 0), take_test_fail_from(m));
         LOM_HIP(m, hipGetLastError());
     } else {
         if ((rc = ensure(m, m->scr[S_FLAG], (size_t)N * 4)) != LOM_OK) return rc;
@@ -1492,7 +1614,13 @@ static int downsample_core(lom_map *m, float voxel_size, const char *dx, const c
     if (!wait) return LOM_OK;
     if ((rc = read_words(m, 4, 4)) != LOM_OK) return rc;  // [0] voxels, [1] range flag, [3] grid error
     m->status_seq = seq;
-    if (m->h_flags[3] == seq) return set_error(m, LOM_ERR_HIP, "a workgroup timed out waiting for the others of its grid");
+    if (m->h_flags[3] == seq) {
+        // the in-kernel scan gave up: every kept point has still put its slot and head word back to rest, so the
+        // workspace is empty again; same call through the flag / scan / write kernels, which wait for nobody
+        if (n_dev) return set_error(m, LOM_ERR_HIP, "a workgroup timed out waiting for the others of its grid");
+        m->grid_redos++;
+        return downsample_core(m, voxel_size, dx, dn, N, stride, want_normals, true, nullptr, true);
+    }
     if (m->h_flags[1] == seq) return set_error(m, LOM_ERR_RANGE, "coordinate / voxel_size out of range or not finite");
     return LOM_OK;
 }
@@ -1618,8 +1746,9 @@ int lom_upload_points(lom_map *m, const float *xyz, const float *nrm, size_t n, 
     if (d_nrm_out) *d_nrm_out = nullptr;
     if (n == 0) return LOM_OK;
     const char *dx = nullptr, *dn = nullptr;
-    const int rc = stage_host_points(m, xyz, nrm, n, stride, &dx, &dn);
+    int rc = resolve_pending(m);
     if (rc != LOM_OK) return rc;
+    if ((rc = stage_host_points(m, xyz, nrm, n, stride, &dx, &dn)) != LOM_OK) return rc;
     *d_xyz_out = (const float *)dx;
     if (d_nrm_out) *d_nrm_out = (const float *)dn;
     return LOM_OK;
@@ -1635,6 +1764,7 @@ int lom_transform_points_device(lom_map *m, const lom_pose *pose, const float *d
     if (d_nrm_out) *d_nrm_out = nullptr;
     if (n == 0) return LOM_OK;
     int rc;
+    if ((rc = resolve_pending(m)) != LOM_OK) return rc;
     const bool with_n = d_nrm && d_nrm_out;
     if ((rc = ensure(m, m->scr[S_IN_XYZ], n * 12)) != LOM_OK) return rc;
     if (with_n && (rc = ensure(m, m->scr[S_IN_NRM], n * 12)) != LOM_OK) return rc;

@@ -454,7 +454,7 @@ def test_host_driven_path_matches_device_loop(lom, monkeypatch):
     m = lom.CloudMatcher()
     dev = m.align(g, sm["scan"], lom.Pose3D())
     dev_stats = dict(m.stats)
-    monkeypatch.setenv("LOM_HOST_LM", "1")
+    g.setOption(lom.capi.OPT_HOST_LM, 1)
     host = m.align(g, sm["scan"], lom.Pose3D())
     dt, dr = scenes.pose_delta(dev.translation, dev.rotation, host.translation, host.rotation)
     assert dt < 1e-6 and dr < 1e-6, (dt, dr)
@@ -466,20 +466,20 @@ def test_evaluation_server_timeout_recovery(lom, monkeypatch):
     """Host-driven path: the resident evaluation server leaves when the host stays away (bounded
     spin); the host then relaunches it.  With a 1-tick timeout every LM iteration takes that path:
     same bits."""
-    monkeypatch.setenv("LOM_HOST_LM", "1")
     sm = scenes.small_synth_case()
     g = lom.VoxelGrid(0.5, 20)
+    g.setOption(lom.capi.OPT_HOST_LM, 1)
     g.addCloud(sm["map_xyz"], sm["map_nrm"])
     m = lom.CloudMatcher()
     ref = m.align(g, sm["scan"], lom.Pose3D())
     ref_stats = dict(m.stats)
-    monkeypatch.setenv("LOM_TEST_SERVER_TIMEOUT_TICKS", "1")
+    g.setOption(lom.capi.OPT_DEVICE_PATIENCE_TICKS, 1)
     got = m.align(g, sm["scan"], lom.Pose3D())
     assert got.translation.tobytes() == ref.translation.tobytes()
     assert got.rotation.tobytes() == ref.rotation.tobytes()
     for k in ("outer_iterations", "evaluations", "queries", "cand_total", "valid_last"):
         assert m.stats[k] == ref_stats[k]
-    monkeypatch.delenv("LOM_TEST_SERVER_TIMEOUT_TICKS")
+    g.setOption(lom.capi.OPT_DEVICE_PATIENCE_TICKS, 5_000_000)
     again = m.align(g, sm["scan"], lom.Pose3D())
     assert again.translation.tobytes() == ref.translation.tobytes()
 
@@ -496,22 +496,31 @@ def test_device_loop_gives_up_cleanly_and_falls_back(lom, monkeypatch):
     m = lom.CloudMatcher()
     ref = m.align(g, sm["scan"], lom.Pose3D())
     assert m.stats["host_fallback"] == 0
-    monkeypatch.setenv("LOM_HOST_LM", "1")
+    g.setOption(lom.capi.OPT_HOST_LM, 1)
     host = m.align(g, sm["scan"], lom.Pose3D())
     host_stats = dict(m.stats)
-    monkeypatch.delenv("LOM_HOST_LM")
-    monkeypatch.setenv("LOM_TEST_SERVER_TIMEOUT_TICKS", "1")
+    g.setOption(lom.capi.OPT_HOST_LM, 0)
+    g.setOption(lom.capi.OPT_DEVICE_PATIENCE_TICKS, 1)
     got = m.align(g, sm["scan"], lom.Pose3D())
     assert m.stats["host_fallback"] == 1
     assert got.translation.tobytes() == host.translation.tobytes()
     assert got.rotation.tobytes() == host.rotation.tobytes()
     for k in ("outer_iterations", "lm_iterations", "evaluations", "queries", "cand_total", "valid_last"):
         assert m.stats[k] == host_stats[k], k
-    monkeypatch.delenv("LOM_TEST_SERVER_TIMEOUT_TICKS")
+    g.setOption(lom.capi.OPT_DEVICE_PATIENCE_TICKS, 5_000_000)
     again = m.align(g, sm["scan"], lom.Pose3D())
     assert m.stats["host_fallback"] == 0
     assert again.translation.tobytes() == ref.translation.tobytes()
     assert again.rotation.tobytes() == ref.rotation.tobytes()
+    # a give-up late in the chain (the k_lm of the fourth outer iteration, pairs still enqueued behind it): the
+    # kernels behind it return at once, the align is redone on the host-driven path, the next one is back on the device
+    g.setOption(lom.capi.OPT_TEST_GIVE_UP_AT_OUTER, 3)
+    late = m.align(g, sm["scan"], lom.Pose3D())
+    assert m.stats["host_fallback"] == 1
+    assert late.translation.tobytes() == host.translation.tobytes() and late.rotation.tobytes() == host.rotation.tobytes()
+    again = m.align(g, sm["scan"], lom.Pose3D())
+    assert m.stats["host_fallback"] == 0
+    assert again.translation.tobytes() == ref.translation.tobytes()
 
 
 def test_comm_path_single_rank(lom):
@@ -772,3 +781,56 @@ def test_deferred_insert_verdict(lom):
     assert g.size() == 3 and g.pointCount() == 7
     xyz, _ = g.getCloud()
     assert tuple(xyz[-1]) == (np.float32(5.1), np.float32(0.1), np.float32(0.1))
+
+
+# ---- an in-kernel scan that gives up: the call changes nothing and is redone with the multi-launch scan -------
+
+@pytest.mark.parametrize("fail_from", [1, 3])
+def test_map_maintenance_survives_a_grid_give_up(lom, oracle, fixture_cloud, fail_from):
+    """The single-pass kernels of insert / down-sampling / cleanup wait for their predecessor workgroups with a
+    bounded patience.  LOM_OPT_TEST_GRID_GIVE_UP makes the workgroups from `fail_from` on give up in the next
+    such call -- those before it have already written (slab ids, outputs), those from it on have no prefix.
+    The call must change nothing the redo could trip over: results stay bytewise the oracle's, the handle
+    reports the redo, and the scratch is at rest (the following plain calls are exact as well)."""
+    _, xyzn = fixture_cloud
+    xyz, nrm = xyzn[:, :3], xyzn[:, 3:]
+    g, og = _both(lom, oracle, 0.25, 20)
+    cuts = [0, 20000, 40000, len(xyz)]                     # three single-pass batches (<= 65536 points)
+    redo = 0
+    for i, (a, b) in enumerate(zip(cuts[:-1], cuts[1:])):
+        if i != 1:                                         # first (all voxels new) and third (mixed) batch give up
+            g.setOption(lom.capi.OPT_TEST_GRID_GIVE_UP, fail_from)
+            redo += 1
+        g.addCloud(xyz[a:b], nrm[a:b])
+        og.addCloud(xyz[a:b], nrm[a:b])
+        assert g.size() == og.size()                       # resolves the pending insert
+        assert g.debugCounter() == redo
+    _assert_same_map(g, og)
+    # cleanup: the scan that flags and numbers the voxels gives up -> flags + multi-launch scan
+    g.setOption(lom.capi.OPT_TEST_GRID_GIVE_UP, fail_from)
+    g.radiusCleanup((5.0, 3.0, 10.0), 40.0)
+    og.radiusCleanup((5.0, 3.0, 10.0), 40.0)
+    assert g.debugCounter() == redo + 1
+    _assert_same_map(g, og)
+    g.addCloud(xyz[:30000], nrm[:30000])                   # and the map is a working map afterwards
+    og.addCloud(xyz[:30000], nrm[:30000])
+    _assert_same_map(g, og)
+    # the search sees the redone insert without anybody asking for the status in between
+    g2, og2 = _both(lom, oracle, 0.25, 20)
+    g2.setOption(lom.capi.OPT_TEST_GRID_GIVE_UP, fail_from)
+    g2.addCloud(xyz[:50000], nrm[:50000])
+    og2.addCloud(xyz[:50000], nrm[:50000])
+    src = np.ascontiguousarray(xyz[::7])
+    _assert_same_pairs(g2.findMatchingPairs(src, lom.Pose3D(), 0.3), og2.findMatchingPairs(src, oracle.Pose3D(), 0.3))
+    assert g2.debugCounter() == 1
+    # down-sampler workspace: outputs equal, workspace left empty and reusable
+    ods = oracle.VoxelGrid(0.3, 1)
+    ods.addCloud(xyz, nrm)
+    oxyz, onrm = ods.getCloud()
+    ws = lom.VoxelGrid(1.0, 1)
+    ws.setOption(lom.capi.OPT_TEST_GRID_GIVE_UP, fail_from)
+    dx, dn = ws.downsample(xyz, nrm, 0.3)
+    assert dx.tobytes() == oxyz.tobytes() and dn.tobytes() == onrm.tobytes()
+    assert ws.debugCounter() == 1 and ws.size() == 0
+    dx, dn = ws.downsample(xyz, nrm, 0.3)
+    assert dx.tobytes() == oxyz.tobytes() and dn.tobytes() == onrm.tobytes()

@@ -143,3 +143,79 @@ def test_sharded_align_over_host_exchange(world, oracle):
     dt, dr = scenes.pose_delta(t, qq, ref.translation, ref.rotation)
     assert dt < 1e-4 and dr < 1e-4, (dt, dr)
     assert outer == m.stats["outer_iterations"] and queries == m.stats["queries"]
+
+
+# ---- an exchange nobody completes is ABANDONED, and every rank sees that -----------------------------------
+# Round 2's three-rank failure: ranks 0 and 1 gave up on an exchange after their deadline
+# but left their slots published; rank 2 arrived later, found all three slots at its sequence number, "succeeded"
+# and carried on alone.  Now a rank that walks away marks its slots, and whoever pairs with them fails as well.
+
+def _abandon_worker(rank, world, ident, mode, q):
+    sys.path.insert(0, ROOT)
+    import time
+
+    import lidar_odometry_demo_amd as lom
+
+    L = lom.capi.lib()
+    h = C.c_void_p()
+    assert L.lom_host_comm_create(rank, world, ident, C.byref(h)) == 0
+    buf = (C.c_double * 2)(1.0, float(rank))
+    assert L.lom_host_comm_allreduce(h, buf, 2) == 0            # exchange 1: everybody is there
+    assert buf[0] == float(world)
+    out = {}
+    if mode == "late":
+        # exchange 2: the last rank arrives after the others' deadline (0.4 s) has passed
+        L.lom_host_comm_set_timeout(h, C.c_double(0.4 if rank != world - 1 else 30.0))
+        if rank == world - 1:
+            time.sleep(1.5)
+        t0 = time.time()
+        buf = (C.c_double * 1)(1.0)
+        out["rc2"] = L.lom_host_comm_allreduce(h, buf, 1)
+        out["t2"] = time.time() - t0
+    else:
+        # exchange 2: rank 0 cannot continue and says so; the others are already waiting for it
+        L.lom_host_comm_set_timeout(h, C.c_double(30.0))
+        if rank == 0:
+            time.sleep(0.5)
+            assert L.lom_host_comm_abort(h) == 0
+            out["rc2"], out["t2"] = -6, 0.0
+        else:
+            t0 = time.time()
+            buf = (C.c_double * 1)(1.0)
+            out["rc2"] = L.lom_host_comm_allreduce(h, buf, 1)
+            out["t2"] = time.time() - t0
+    out["err"] = L.lom_host_comm_last_error(h).decode()
+    t0 = time.time()
+    buf = (C.c_double * 1)(1.0)
+    out["rc3"] = L.lom_host_comm_allreduce(h, buf, 1)           # and the object stays broken, at once
+    out["t3"] = time.time() - t0
+    big = C.create_string_buffer(world * 8)
+    out["rc4"] = L.lom_host_comm_allgather(h, b"12345678", 8, big)
+    L.lom_host_comm_destroy(h)
+    q.put((rank, out))
+
+
+@pytest.mark.parametrize("mode", ["late", "abort"])
+def test_abandoned_exchange_fails_on_every_rank(mode):
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ident = os.urandom(16) + bytes(112)
+    procs = [ctx.Process(target=_abandon_worker, args=(r, world, ident, mode, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    for r in range(world):
+        o = res[r]
+        assert o["rc2"] == -6 and o["rc3"] == -6 and o["rc4"] == -6, (r, o)     # LOM_ERR_COMM, nobody carries on alone
+        assert o["t3"] < 0.2, (r, o)
+    if mode == "late":
+        assert "timed out waiting for rank 2" in res[0]["err"] and "timed out waiting for rank 2" in res[1]["err"]
+        assert "abandoned exchange" in res[2]["err"], res[2]                    # the late rank does not pair with stale slots
+        assert res[2]["t2"] < 0.5                                               # ... and learns it at once, not after 30 s
+    else:
+        assert all("abandoned exchange" in res[r]["err"] for r in (1, 2)), res
+        assert all(res[r]["t2"] < 5.0 for r in (1, 2)), res                     # at once, not after the 30 s deadline

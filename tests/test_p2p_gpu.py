@@ -17,13 +17,13 @@ pytestmark = pytest.mark.gpu
 
 def _rank_main(rank, world, ident, q):
     sys.path.insert(0, ROOT)
-    os.environ["LOM_TEST_SERVER_TIMEOUT_TICKS"] = "300000000"     # 3 s: two fresh processes start unevenly
     import lidar_odometry_demo_amd as lom
     from tests import scenes
 
     L = lom.capi.lib()
     sm = scenes.small_synth_case()
     g = lom.VoxelGrid(0.5, 20)
+    g.setOption(lom.capi.OPT_DEVICE_PATIENCE_TICKS, 300_000_000)   # 3 s: two fresh processes start unevenly
     g.addCloud(sm["map_xyz"], sm["map_nrm"])
     hc = C.c_void_p()
     assert L.lom_host_comm_create(rank, world, ident, C.byref(hc)) == 0
@@ -43,13 +43,13 @@ def _rank_main(rank, world, ident, q):
         out.append((p.translation.tobytes(), p.rotation.tobytes(), dict(m.stats)))
     # a rank that gives up waiting stops publishing, so all ranks give up on the same align: they
     # fall back to the host-driven loop over the host exchange and redo it (1-tick patience forces that)
-    os.environ["LOM_TEST_SERVER_TIMEOUT_TICKS"] = "1"
+    g.setOption(lom.capi.OPT_DEVICE_PATIENCE_TICKS, 1)
     guess = lom.Pose3D((0.0, 0.0, 0.0), scenes.angle_axis_q(0.01, (0, 0, 1)))
     buf = (C.c_double * 1)(0.0)
     L.lom_host_comm_allreduce(hc, buf, 1)
     p = m.align(g, np.ascontiguousarray(scan[lo:hi]), guess)
     out.append((p.translation.tobytes(), p.rotation.tobytes(), dict(m.stats)))
-    os.environ["LOM_TEST_SERVER_TIMEOUT_TICKS"] = "300000000"
+    g.setOption(lom.capi.OPT_DEVICE_PATIENCE_TICKS, 300_000_000)
     L.lom_host_comm_allreduce(hc, buf, 1)
     p = m.align(g, np.ascontiguousarray(scan[lo:hi]), guess)          # stays on the host exchange
     out.append((p.translation.tobytes(), p.rotation.tobytes(), dict(m.stats)))
@@ -99,12 +99,12 @@ def test_ranks_exchange_on_the_device(lom, world):
 
 def _rank_main_c4(rank, world, ident, q, case_dir):
     sys.path.insert(0, ROOT)
-    os.environ["LOM_TEST_SERVER_TIMEOUT_TICKS"] = "1000000000"    # 10 s: fresh processes build a 2M-point map unevenly
     import lidar_odometry_demo_amd as lom
 
     L = lom.capi.lib()
     scan = np.load(os.path.join(case_dir, "scan.npy"), mmap_mode="r")
     g = lom.VoxelGrid(0.5, 20)
+    g.setOption(lom.capi.OPT_DEVICE_PATIENCE_TICKS, 1_000_000_000)  # 10 s: fresh processes build a 2M-point map unevenly
     g.addCloud(np.load(os.path.join(case_dir, "map_xyz.npy")), np.load(os.path.join(case_dir, "map_nrm.npy")))
     hc = C.c_void_p()
     assert L.lom_host_comm_create(rank, world, ident, C.byref(hc)) == 0
@@ -160,3 +160,107 @@ def test_c4_range_sharded_on_the_device(lom, oracle, world, tmp_path):
         for k in ("outer_iterations", "lm_iterations", "queries", "cand_total", "occ_total", "valid_last"):
             assert s[k] == om.stats[k], (r[0], k)                     # totals over all ranks
         assert s["evaluations"] == om.stats["points_evaluated"]
+
+
+# ---- ONE rank gives up, late: every rank leaves its waits at once, all redo the align over the host exchange ----
+# Round 2 (gpurun_out/fail.log): with three ranks on one GPU a rank's k_lm gave up after its
+# in-GPU patience while its peers kept waiting for it with their ten times longer patience for a peer rank; they
+# reached the host-side agreement more than its fixed 60 s apart, the early ranks abandoned it leaving their slots
+# published, the late rank paired with those slots and carried on alone.  Now: the rank that gives up stores an
+# abort word into its peers' exchange buffers (they leave within a few polls), the agreement's deadline is derived
+# from the device patience, and an abandoned exchange is visible to whoever arrives late (tests/test_host_exchange.py).
+
+def _rank_main_give_up(rank, world, ident, q):
+    sys.path.insert(0, ROOT)
+    import time
+
+    import lidar_odometry_demo_amd as lom
+    from tests import scenes
+
+    L = lom.capi.lib()
+    sm = scenes.small_synth_case()
+    g = lom.VoxelGrid(0.5, 20)
+    g.addCloud(sm["map_xyz"], sm["map_nrm"])
+    hc = C.c_void_p()
+    assert L.lom_host_comm_create(rank, world, ident, C.byref(hc)) == 0
+    scan = sm["scan"]
+    lo, hi = len(scan) * rank // world, len(scan) * (rank + 1) // world
+    shard = np.ascontiguousarray(scan[lo:hi])
+    guess = lom.Pose3D((0.0, 0.0, 0.0), scenes.angle_axis_q(0.01, (0, 0, 1)))
+    m = lom.CloudMatcher()
+    out = []
+    buf = (C.c_double * 1)(0.0)
+
+    def attach():
+        g.setOption(lom.capi.OPT_DEVICE_PATIENCE_TICKS, 300_000_000)      # 3 s (a peer rank: 30 s) while attaching
+        rc = L.lom_comm_attach_p2p(g.handle, hc)
+        if rc != 0:
+            q.put((rank, "attach failed", rc, L.lom_last_error(g.handle).decode()))
+            raise SystemExit(0)
+
+    # (A) an unforced give-up on ONE rank: rank `world - 1` has a patience (20 ms, a peer rank: 200 ms) far below
+    # the skew of the ranks -- its peers start the align 1.5 s later.  Its first k_lm times out waiting for their
+    # totals and publishes the abort word; the peers find it when they start, 1.3 s before their own patience
+    # would even begin to matter.
+    attach()
+    if rank == world - 1:
+        g.setOption(lom.capi.OPT_DEVICE_PATIENCE_TICKS, 2_000_000)
+    L.lom_host_comm_allreduce(hc, buf, 1)
+    if rank != world - 1:
+        time.sleep(1.5)
+    t0 = time.time()
+    p = m.align(g, shard, guess)
+    out.append((p.translation.tobytes(), p.rotation.tobytes(), dict(m.stats), time.time() - t0))
+    # (B) a give-up in the middle of the chain: rank 1's k_lm of the fourth outer iteration behaves as timed out
+    # while pairs are still enqueued behind it on every rank; everybody's patience is long (3 s / 30 s), so only
+    # the abort word can bring the peers out in time
+    attach()
+    if rank == 1:
+        g.setOption(lom.capi.OPT_TEST_GIVE_UP_AT_OUTER, 3)
+    L.lom_host_comm_allreduce(hc, buf, 1)
+    t0 = time.time()
+    p = m.align(g, shard, guess)
+    out.append((p.translation.tobytes(), p.rotation.tobytes(), dict(m.stats), time.time() - t0))
+    # (C) back on the device-to-device exchange after a fresh attach
+    attach()
+    L.lom_host_comm_allreduce(hc, buf, 1)
+    p = m.align(g, shard, guess)
+    out.append((p.translation.tobytes(), p.rotation.tobytes(), dict(m.stats), 0.0))
+    L.lom_comm_finalize(g.handle)
+    L.lom_host_comm_destroy(hc)
+    q.put((rank, "ok", out))
+
+
+def test_one_rank_gives_up_late_and_all_ranks_recover(lom):
+    from tests import scenes
+
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ident = os.urandom(16) + bytes(112)
+    procs = [ctx.Process(target=_rank_main_give_up, args=(r, world, ident, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[1] == "ok" for r in res), res
+    sm = scenes.small_synth_case()
+    g = lom.VoxelGrid(0.5, 20)
+    g.addCloud(sm["map_xyz"], sm["map_nrm"])
+    m = lom.CloudMatcher()
+    ref = m.align(g, sm["scan"], lom.Pose3D((0.0, 0.0, 0.0), scenes.angle_axis_q(0.01, (0, 0, 1))))
+    for i in range(3):
+        t0, q0, s0, _ = res[0][2][i]
+        assert all(r[2][i][0] == t0 and r[2][i][1] == q0 for r in res), i      # the same bits on every rank
+        dt, dr = scenes.pose_delta(np.frombuffer(t0, np.float32), np.frombuffer(q0, np.float32),
+                                   ref.translation, ref.rotation)
+        assert dt < 1e-6 and dr < 1e-6, (i, dt, dr)
+        for r in res:
+            s = r[2][i][2]
+            assert s["host_fallback"] == (1 if i < 2 else 0), (i, r[0])        # (A), (B): redone over the host exchange
+            assert s["outer_iterations"] == m.stats["outer_iterations"] and s["queries"] == m.stats["queries"]
+    # nobody sat out a patience: (A) the late ranks come out of a 30 s wait at once, (B) likewise
+    for r in res:
+        assert r[2][0][3] < 8.0 and r[2][1][3] < 8.0, (r[0], r[2][0][3], r[2][1][3])

@@ -230,12 +230,11 @@ def test_frame_handed_back_by_the_device_front_end(lom, monkeypatch):
     boxes = synth.make_boxes()
     dev = lom.LidarOdometry()
     redo = lom.LidarOdometry()
+    redo.setOption(lom.capi.OPT_TEST_FORCE_HOST_REDO, 1)
     for k in range(8):
         f = synth.make_sequence_frame(k, boxes=boxes)
         dev.processCloud(f)
-        monkeypatch.setenv("LOM_TEST_FORCE_HOST_REDO", "1")
         redo.processCloud(f)
-        monkeypatch.delenv("LOM_TEST_FORCE_HOST_REDO")
         assert dev.stats["host_stages"] == 0 and redo.stats["host_stages"] == 1
         for key in ("planar_points", "filtered_points", "update_points", "matching_points", "outer_iterations", "keyframe_voxels"):
             assert dev.stats[key] == redo.stats[key], (k, key)
@@ -262,3 +261,35 @@ def test_lidar_odometry_64_beam_frames_on_the_device_path(lom, oracle):
         pg, po = g.getCurrentPose(), o.getCurrentPose()
         dt, dr = scenes.pose_delta(pg.translation, pg.rotation, po.translation, po.rotation)
         assert dt < 1e-4 and dr < 1e-4, (k, dt, dr)
+
+
+@pytest.mark.gpu
+def test_processcloud_survives_grid_give_ups(lom):
+    """Every in-kernel scan on the streaming path (front end, both down-samplers, the keyframe's insert and
+    cleanup) may give up waiting for its predecessor workgroups.  Forced once each, on different frames: a
+    frame whose stages gave up goes through the host stages, a keyframe update that gave up is redone with the
+    multi-launch scan -- counts and pose bits stay those of the undisturbed run, frame after frame."""
+    boxes = synth.make_boxes()
+    plain = lom.LidarOdometry()
+    hit = lom.LidarOdometry()
+    plan = {3: lom.capi.OPT_TEST_GRID_GIVE_UP, 5: lom.capi.OPT_TEST_GRID_GIVE_UP_MATCHING_DS,
+            7: lom.capi.OPT_TEST_GRID_GIVE_UP_UPDATE_DS, 9: lom.capi.OPT_TEST_GRID_GIVE_UP_KEYFRAME,
+            11: lom.capi.OPT_TEST_GRID_GIVE_UP_KEYFRAME}
+    redone_on_host = 0
+    for k in range(14):
+        f = synth.make_sequence_frame(k, boxes=boxes)
+        if k in plan:
+            hit.setOption(plan[k], 2 if k != 11 else 1 + 65536)     # frame 11: past the cleanup's scan, into the insert's
+        plain.processCloud(f)
+        hit.processCloud(f)
+        ps, hs = plain.stats, hit.stats
+        redone_on_host += hs["host_stages"]
+        assert hs["host_stages"] == (1 if k in (3, 5) else 0), k    # the update cloud (7) is redone in place
+        for key in ("planar_points", "filtered_points", "update_points", "matching_points", "outer_iterations",
+                    "queries", "keyframe_voxels", "unstable_rotation"):
+            assert ps[key] == hs[key], (k, key)
+        a, b = plain.getCurrentPose(), hit.getCurrentPose()
+        assert a.translation.tobytes() == b.translation.tobytes() and a.rotation.tobytes() == b.rotation.tobytes(), k
+    assert redone_on_host == 2
+    assert hit.debugCounter() >= 5 and plain.debugCounter() == 0
+    assert plain.getFullKeyFrameCloud().tobytes() == hit.getFullKeyFrameCloud().tobytes()
