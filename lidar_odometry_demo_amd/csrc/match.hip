@@ -31,6 +31,7 @@
 #include <vector>
 
 #include "lm_core.hpp"
+#include "lm_wave.hpp"
 #include "lom_internal.hpp"
 #include "pose_math.hpp"
 
@@ -40,7 +41,6 @@ constexpr int kMatchThreads = 256;             // 4 waves
 constexpr int kMatchG = 16;                    // lanes per query: four queries per wave
 constexpr int kGroupsPerBlock = kMatchThreads / kMatchG;
 constexpr int kMatchMinWaves = 7;              // waves per SIMD the register budget is held to (72 VGPRs)
-constexpr uint32_t kMatchSmallMax = 16384;   // queries up to which k_match runs its four-loads-in-flight variant
 constexpr int kEvalThreads = 512;
 
 // what k_match leaves behind for the evaluations of one outer iteration: source point,
@@ -72,8 +72,9 @@ struct __attribute__((aligned(8))) QStat {
 //  3. flatten  the remaining voxels' points form one candidate sequence in scan
 //              order (inclusive prefix of the counts in LDS); lane l takes
 //              candidates l, l+G, ... and finds each one's voxel by a 5-step
-//              binary search -- every load of a query is in flight at once instead
-//              of one dependent round trip per occupied voxel.
+//              binary search; a lane's kP candidates of a trip have their loads in
+//              flight together (issued by one asm block: left to the compiler, the
+//              first use of load 1 was scheduled ahead of the address of load 2).
 //  4. select   private strict minimum per lane (candidates arrive in scan order),
 //              then the lexicographic minimum of (sq_dist, candidate ordinal) over
 //              the group == "first encountered wins" of voxel_grid.h:183-191.
@@ -160,6 +161,19 @@ __device__ __forceinline__ u32x4 load_slot(const Slot *a)
     return r;
 }
 
+// A lane's two candidate points of a trip as two 12-byte loads issued back to back and waited for together.
+// Left to the compiler, the first use of load 1 was scheduled ahead of the address computation of load 2: the
+// "two loads in flight" of round 2 were two dependent round trips (C2 / C3 / C4: 7.9 / 29.9 / 53.7 us; with this
+// block 6.8 / 28.1 / 47.7 us, profiles/r03_*).
+typedef float f32x3 __attribute__((ext_vector_type(3)));
+__device__ __forceinline__ void load_points2(const float *a, const float *b, f32x3 &ra, f32x3 &rb)
+{
+    asm volatile("global_load_dwordx3 %0, %2, off\n\tglobal_load_dwordx3 %1, %3, off\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(ra), "=&v"(rb)
+                 : "v"(a), "v"(b)
+                 : "memory");
+}
+
 // kStamp = true is a diagnostic build (lom_debug_match_stamps): thread 0 of every workgroup records
 // the shader clock after each phase of its first query, every wait fully drained before a stamp.
 // Its run time is not representative; the product launches kStamp = false only.
@@ -201,7 +215,8 @@ __global__ __launch_bounds__(kMatchThreads, kMinWaves) void k_match(MapView map,
                                                          unsigned long long *__restrict__ stamps = nullptr,
                                                          const AlignState *state = nullptr)
 {
-    static_assert(G == 16 && kU >= 1 && kU <= 4, "one query per 16-lane DPP row");
+    static_assert(G == 16 && kU == 2, "one query per 16-lane DPP row, two candidates per lane and trip");
+    constexpr int kP = kU;
     struct {
         double R[9], t[3];
         float max_sq;
@@ -354,74 +369,73 @@ __global__ __launch_bounds__(kMatchThreads, kMinWaves) void k_match(MapView map,
         // occupied voxels (<= 27) above bit 26, stored points (<= 27 K, K < 2^16) below: one row sum for both sets
         const uint32_t tot = row_sum((cnt[0] + cnt[1]) | (((cnt[0] ? 1u : 0u) + (cnt[1] ? 1u : 0u)) << 26));
         const uint32_t n_cand = tot & ((1u << 26) - 1u), n_occ = tot >> 26;
-        uint32_t T;
-        if (map.K <= 2048u) {
-            // both sets' counts in one register (16 voxels x K < 2^16 each): ONE row scan, one broadcast
-            const uint32_t inc = row_scan_inclusive(scan_cnt[0] | (scan_cnt[1] << 16));
-            const uint32_t last = row_last(inc);
-            const uint32_t tot0 = last & 0xFFFFu, inc0 = inc & 0xFFFFu, inc1 = tot0 + (inc >> 16);
-            s_pb[grp][gl] = make_uint2(inc0, slab[0] * map.K - (inc0 - scan_cnt[0]));
-            s_pb[grp][gl + G] = make_uint2((gl + G < 27) ? inc1 : 0xFFFFFFFFu, slab[1] * map.K - (inc1 - scan_cnt[1]));
-            T = tot0 + (last >> 16);
-        } else {
-            uint32_t run = 0;
-#pragma unroll
-            for (int s = 0; s < kSets; s++) {
-                const uint32_t inc = row_scan_inclusive(scan_cnt[s]);
-                const int b = gl + s * G;
-                s_pb[grp][b] = make_uint2((b < 27) ? run + inc : 0xFFFFFFFFu, slab[s] * map.K - (run + inc - scan_cnt[s]));
-                run += row_last(inc);
-            }
-            T = run;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-        LOM_STAMP(3);  // prefix in LDS
         float best = INFINITY, bpx = 0.f, bpy = 0.f, bpz = 0.f;
         uint32_t best_c = 0xFFFFFFFFu, best_idx = 0;
-        // Binary search of a candidate's voxel: the first two of its five levels compare with three values read once
-        // per query, the last reads the entry and its successor's base together -- three dependent LDS round trips
-        // per candidate instead of six.
-        const uint2 *pb = s_pb[grp];
-        const uint32_t p7 = pb[7].x, p15 = pb[15].x, p23 = pb[23].x;
-        // lane l takes candidates l, l + 16, ... of the flattened sequence (scan order: strict
-        // minimum per lane, first wins)
-        // kU candidates per lane and trip: their loads are in flight together (a scan with few waves per SIMD --
-        // a small cloud -- is a chain of round trips otherwise); compared in ascending order, as one by one
-        for (uint32_t c0 = gl; c0 < T; c0 += G * kU) {
-            float ax[kU], ay[kU], az[kU];
-            uint32_t pi[kU];
+        uint32_t T;  // points actually read
+        {
+            // both sets' counts in one register (16 voxels x K < 2^16 each): ONE row scan, one broadcast
+            uint32_t run0 = 0;
+            if (map.K <= 2048u) {
+                const uint32_t inc = row_scan_inclusive(scan_cnt[0] | (scan_cnt[1] << 16));
+                const uint32_t last = row_last(inc);
+                const uint32_t tot0 = last & 0xFFFFu, inc0 = inc & 0xFFFFu, inc1 = tot0 + (inc >> 16);
+                s_pb[grp][gl] = make_uint2(inc0, slab[0] * map.K - (inc0 - scan_cnt[0]));
+                s_pb[grp][gl + G] = make_uint2((gl + G < 27) ? inc1 : 0xFFFFFFFFu, slab[1] * map.K - (inc1 - scan_cnt[1]));
+                T = tot0 + (last >> 16);
+            } else {
 #pragma unroll
-            for (int u = 0; u < kU; u++) {
-                const uint32_t c = c0 + (uint32_t)(u * G);
-                const uint32_t cs = (kU == 1 || c < T) ? c : c0;  // beyond the end: re-read this lane's first (not compared)
-                // smallest b with prefix[b] > cs
-                uint32_t b = (p15 <= cs) ? 16u : 0u;
-                b += ((b ? p23 : p7) <= cs) ? 8u : 0u;
-                b += (pb[b + 3].x <= cs) ? 4u : 0u;
-                b += (pb[b + 1].x <= cs) ? 2u : 0u;
-                const uint2 e = pb[b];
-                const uint32_t next_base = pb[b + 1].y;
-                pi[u] = ((e.x <= cs) ? next_base : e.y) + cs;
-                const float *vp = map.pts + (size_t)pi[u] * 3;
-                ax[u] = vp[0];
-                ay[u] = vp[1];
-                az[u] = vp[2];
+                for (int s = 0; s < kSets; s++) {
+                    const uint32_t inc = row_scan_inclusive(scan_cnt[s]);
+                    const int b = gl + s * G;
+                    s_pb[grp][b] = make_uint2((b < 27) ? run0 + inc : 0xFFFFFFFFu, slab[s] * map.K - (run0 + inc - scan_cnt[s]));
+                    run0 += row_last(inc);
+                }
+                T = run0;
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            LOM_STAMP(3);  // prefix in LDS
+            // Binary search of a candidate's voxel: the first two of its five levels compare with three values read once
+            // per query, the last reads the entry and its successor's base together -- three dependent LDS round trips
+            // per candidate instead of six.
+            const uint2 *pb = s_pb[grp];
+            const uint32_t p7 = pb[7].x, p15 = pb[15].x, p23 = pb[23].x;
+            // lane l takes candidates l, l + 16, ... of the flattened sequence (scan order: strict minimum per lane,
+            // first wins); kP candidates per lane and trip, compared in ascending order, as one by one
+            for (uint32_t c0 = gl; c0 < T; c0 += G * kP) {
+                f32x3 pt[kP];
+                uint32_t pi[kP];
+                const float *ad[kP];
 #pragma unroll
-            for (int u = 0; u < kU; u++) {
-                const uint32_t c = c0 + (uint32_t)(u * G);
-                const float dx = qx - ax[u], dy = qy - ay[u], dz = qz - az[u];
-                const float d2 = dx * dx + (dy * dy + dz * dz);  // voxel_grid.h:184 f32 squaredNorm
-                if ((kU == 1 || c < T) && d2 < P.max_sq && d2 < best) {  // :186-187 strict
-                    best = d2;
-                    best_c = c;
-                    best_idx = pi[u];
-                    bpx = ax[u];
-                    bpy = ay[u];
-                    bpz = az[u];
+                for (int u = 0; u < kP; u++) {
+                    const uint32_t c = c0 + (uint32_t)(u * G);
+                    const uint32_t cs = c < T ? c : c0;  // beyond the end: re-read this lane's first (not compared)
+                    // smallest b with prefix[b] > cs
+                    uint32_t b = (p15 <= cs) ? 16u : 0u;
+                    b += ((b ? p23 : p7) <= cs) ? 8u : 0u;
+                    b += (pb[b + 3].x <= cs) ? 4u : 0u;
+                    b += (pb[b + 1].x <= cs) ? 2u : 0u;
+                    const uint2 e = pb[b];
+                    const uint32_t next_base = pb[b + 1].y;
+                    pi[u] = ((e.x <= cs) ? next_base : e.y) + cs;
+                    ad[u] = map.pts + (size_t)pi[u] * 3;
+                }
+                load_points2(ad[0], ad[1], pt[0], pt[1]);
+#pragma unroll
+                for (int u = 0; u < kP; u++) {
+                    const uint32_t c = c0 + (uint32_t)(u * G);
+                    const f32x3 a = pt[u];
+                    const float dx = qx - a.x, dy = qy - a.y, dz = qz - a.z;
+                    const float d2 = dx * dx + (dy * dy + dz * dz);  // voxel_grid.h:184 f32 squaredNorm
+                    if (c < T && d2 < P.max_sq && d2 < best) {  // :186-187 strict
+                        best = d2;
+                        best_c = c;
+                        best_idx = pi[u];
+                        bpx = a.x;
+                        bpy = a.y;
+                        bpz = a.z;
+                    }
                 }
             }
         }
@@ -951,350 +965,6 @@ __device__ __forceinline__ void reduce_and_exchange(const double acc[28], double
 // pinned host memory.  Every wait is bounded (s_memrealtime); a workgroup that gives up sets
 // the error flags and leaves, the others follow.
 // ---------------------------------------------------------------------------
-// ---- lm_core.hpp's policy, executed by one wave ---------------------------------------------
-// Same decisions, same operation order as lm_begin_head / lm_feed_head / lm_propose, but a single
-// lane issuing ~1500 f64 instructions costs ~4 us per step on a 64-wide SIMD.  Here lane r < 6
-// owns row r of the 6x6 system; values another row needs travel by v_readlane (uniform
-// broadcasts), so a step is ~400 instructions.  Differences from the serial code are at rounding
-// level only: the 6x6 system is solved by Gauss-Jordan elimination on the lanes' rows with reciprocals from
-// v_rcp_f64 + two Newton steps (lm_core.hpp: Cholesky with the correctly rounded library sqrt and division).
-// All 64 lanes run the code (uniform control flow); lanes >= 6 compute unused values and never store.
-__device__ __forceinline__ double lane_bcast(double v, int k)
-{
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), k);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), k);
-    return __hiloint2double(hi, lo);
-}
-
-__device__ __forceinline__ void sqrt_and_inverse(double d, double &root, double &inv)
-{
-    const double y = __builtin_amdgcn_rsq(d);
-    double g = d * y, h = 0.5 * y;
-    double e = __builtin_fma(-h, g, 0.5);
-    g = __builtin_fma(g, e, g);
-    h = __builtin_fma(h, e, h);
-    e = __builtin_fma(-h, g, 0.5);
-    g = __builtin_fma(g, e, g);
-    h = __builtin_fma(h, e, h);
-    const double dd = __builtin_fma(-g, g, d);
-    root = __builtin_fma(dd, h, g);
-    inv = h + h;
-}
-
-__device__ __forceinline__ double fast_rcp(double d)  // v_rcp_f64 + two Newton steps
-{
-    double y = __builtin_amdgcn_rcp(d);
-    double e = __builtin_fma(-d, y, 1.0);
-    y = __builtin_fma(y, e, y);
-    e = __builtin_fma(-d, y, 1.0);
-    return __builtin_fma(y, e, y);
-}
-
-// manifold_plus (pose_math.hpp) with the square root from v_rsq_f64: one dependent chain shorter
-__device__ __forceinline__ void manifold_plus_fast(const double x[7], const double d[6], double out[7])
-{
-    const double n2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
-    if (n2 == 0.0) {
-#pragma unroll
-        for (int i = 0; i < 4; i++) out[i] = x[i];
-    } else {
-        double nd, unused;
-        sqrt_and_inverse(n2, nd, unused);
-        double s, c;
-        sinc_cos(nd, s, c);
-        const double z[4] = {c, s * d[0], s * d[1], s * d[2]};
-        out[0] = z[0] * x[0] - z[1] * x[1] - z[2] * x[2] - z[3] * x[3];
-        out[1] = z[0] * x[1] + z[1] * x[0] + z[2] * x[3] - z[3] * x[2];
-        out[2] = z[0] * x[2] - z[1] * x[3] + z[2] * x[0] + z[3] * x[1];
-        out[3] = z[0] * x[3] + z[1] * x[2] - z[2] * x[1] + z[3] * x[0];
-    }
-#pragma unroll
-    for (int i = 0; i < 3; i++) out[4 + i] = x[4 + i] + d[3 + i];
-}
-
-// lm_assemble for lane r: its row of A, its g, and the (uniform) cost
-__device__ __forceinline__ void lmw_assemble(const double *s, const double *xx, const double *prior_b, int r,
-                                             double Arow[6], double &g_r, double &cost)
-{
-#pragma unroll
-    for (int j = 0; j < 6; j++) {
-        const int a = r < j ? r : j, b = r < j ? j : r;
-        Arow[j] = s[a * 6 - (a * (a - 1)) / 2 + (b - a)];  // upper-triangle index of (a,b)
-    }
-    g_r = s[21 + r];
-    cost = s[27];
-#pragma unroll
-    for (int a = 0; a < 3; a++) {
-        const double res = kPriorW * (xx[4 + a] - prior_b[a]);
-        if (r == 3 + a) {
-            Arow[3 + a] += kPriorW * kPriorW;
-            g_r += kPriorW * res;
-        }
-        cost += 0.5 * res * res;
-    }
-}
-
-__device__ __forceinline__ double lmw_pick(const double v[6], int r)  // v[r], r varies by lane
-{
-    // Conditional moves, kept as such: the compiler recognises a select chain over one index as v[r]
-    // and implements that as an array in scratch memory (stores + a dependent scratch load in the
-    // middle of the policy's chain).  An opaque copy of the index per comparison prevents it.
-    double o = v[0];
-#pragma unroll
-    for (int j = 1; j < 6; j++) {
-        int rj = r;
-        asm volatile("" : "+v"(rj));
-        o = (rj == j) ? v[j] : o;
-    }
-    return o;
-}
-
-__device__ __forceinline__ double lmw_gmax(double g_r)
-{
-    double m = 0.0;
-#pragma unroll
-    for (int c = 0; c < 6; c++) m = fmax(m, fabs(lane_bcast(g_r, c)));
-    return m;
-}
-
-__device__ __forceinline__ void lmw_store_normal(LmState &S, int lane, int r, const double Arow[6], double g_r,
-                                                 double cost)
-{
-    if (lane < 6) {
-#pragma unroll
-        for (int j = 0; j < 6; j++) S.N.A[r][j] = Arow[j];
-        S.N.g[r] = g_r;
-    }
-    if (lane == 0) S.N.cost = cost;
-}
-
-// lm_begin_head
-__device__ __forceinline__ int lmw_begin(LmState &S, const double *first, const double *x, const double *prior_b,
-                                         int lane)
-{
-    const int r = lane < 6 ? lane : 5;
-    double Arow[6], g_r, cost;
-    double pb[3] = {prior_b[0], prior_b[1], prior_b[2]};
-    lmw_assemble(first, x, pb, r, Arow, g_r, cost);
-    const double scale_r = 1.0 / (1.0 + sqrt(lmw_pick(Arow, r)));
-    double xs[7];
-#pragma unroll
-    for (int i = 0; i < 7; i++) xs[i] = x[i];
-    const double x_norm = lm_norm7(xs);
-    lmw_store_normal(S, lane, r, Arow, g_r, cost);
-    if (lane < 6) {
-        S.scale[r] = scale_r;
-        S.diag[r] = 0.0;
-    }
-    if (lane < 7) {
-        S.x[lane] = x[lane];
-        S.cand[lane] = x[lane];
-    }
-    if (lane < 3) S.prior_b[lane] = prior_b[lane];
-    if (lane == 0) {
-        S.x_norm = x_norm;
-        S.radius = 1e4;
-        S.decrease_factor = 2.0;
-        S.reuse_diag = 0;
-        S.invalid_run = 0;
-        S.iter = 1;
-        S.recorded = 1;
-        S.evaluations = 1;
-        S.last_step_norm = 0.0;
-        S.model_change = 0.0;
-        S.cost = cost;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (lmw_gmax(g_r) <= kLmGtol) return LM_DONE;
-    return LM_PROPOSE;
-}
-
-// lm_feed_head
-__device__ __forceinline__ int lmw_feed(LmState &S, const double *sums, int lane)
-{
-    const int r = lane < 6 ? lane : 5;
-    double xs[7], cs[7], pb[3];
-#pragma unroll
-    for (int i = 0; i < 7; i++) {
-        xs[i] = S.x[i];
-        cs[i] = S.cand[i];
-    }
-#pragma unroll
-    for (int i = 0; i < 3; i++) pb[i] = S.prior_b[i];
-    const double n_cost = S.N.cost, x_norm = S.x_norm, model_change = S.model_change;
-    double radius = S.radius, decrease_factor = S.decrease_factor;
-    const int evaluations = S.evaluations + 1, recorded = S.recorded, iter = S.iter;
-    double Crow[6], cg_r, c_cost;
-    lmw_assemble(sums, cs, pb, r, Crow, cg_r, c_cost);
-    double d7[7];
-#pragma unroll
-    for (int i = 0; i < 7; i++) d7[i] = xs[i] - cs[i];
-    const double sn = lm_norm7(d7);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();  // every lane has read the state: lane 0 may now update it
-    if (lane == 0) {
-        S.evaluations = evaluations;
-        S.cost = n_cost;
-    }
-    if (sn <= kLmPtol * (x_norm + kLmPtol)) return LM_DONE;           // parameter tolerance: not recorded
-    const double cost_change = n_cost - c_cost;
-    if (fabs(cost_change) <= kLmFtol * n_cost) return LM_DONE;        // function tolerance: not recorded
-    const double rel_dec = cost_change / model_change;
-    const bool accept = rel_dec > kLmMinRelDec;
-    double g_now = S.N.g[r];
-    double cost_now = n_cost;
-    __builtin_amdgcn_wave_barrier();
-    if (accept) {
-        lmw_store_normal(S, lane, r, Crow, cg_r, c_cost);
-        if (lane < 7) S.x[lane] = S.cand[lane];
-        const double d3 = 2.0 * rel_dec - 1.0;
-        radius = radius / fmax(1.0 / 3.0, 1.0 - d3 * d3 * d3);
-        radius = fmin(kLmMaxRadius, radius);
-        decrease_factor = 2.0;
-        g_now = cg_r;
-        cost_now = c_cost;
-    } else {
-        radius /= decrease_factor;
-        decrease_factor *= 2.0;
-    }
-    if (lane == 0) {
-        if (accept) S.x_norm = lm_norm7(cs);
-        S.radius = radius;
-        S.decrease_factor = decrease_factor;
-        S.reuse_diag = accept ? 0 : 1;
-        S.recorded = recorded + 1;
-        S.last_step_norm = sn;
-        S.cost = cost_now;
-    }
-    const bool done = lmw_gmax(g_now) <= kLmGtol;
-    if (!done && lane == 0) S.iter = iter + 1;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    return done ? LM_DONE : LM_PROPOSE;
-}
-
-// lm_propose
-__device__ __forceinline__ int lmw_propose(LmState &S, int lane)
-{
-    const int r = lane < 6 ? lane : 5;
-    double Arow[6];
-#pragma unroll
-    for (int j = 0; j < 6; j++) Arow[j] = S.N.A[r][j];
-    const double g_r = S.N.g[r], scale_r = S.scale[r];
-    double diag_r = S.diag[r];
-    double radius = S.radius, decrease_factor = S.decrease_factor;
-    int reuse_diag = S.reuse_diag, invalid_run = S.invalid_run, iter = S.iter, recorded = S.recorded;
-    double last_step_norm = S.last_step_norm;
-    double xs[7];
-#pragma unroll
-    for (int i = 0; i < 7; i++) xs[i] = S.x[i];
-    double scale_c[6];
-#pragma unroll
-    for (int j = 0; j < 6; j++) scale_c[j] = lane_bcast(scale_r, j);
-    double As[6];
-#pragma unroll
-    for (int j = 0; j < 6; j++) As[j] = Arow[j] * scale_r * scale_c[j];
-    const double gs_r = g_r * scale_r;
-    int result = LM_DONE;
-    double cand[7] = {0, 0, 0, 0, 0, 0, 0}, model_change = 0.0;
-    while (iter <= kLmMaxIter) {
-        if (!reuse_diag) diag_r = fmin(fmax(lmw_pick(As, r), kLmMinDiag), kLmMaxDiag);
-        const double inv_radius = fast_rcp(radius);
-        double M[6];
-#pragma unroll
-        for (int j = 0; j < 6; j++) M[j] = (r == j) ? As[j] + diag_r * inv_radius : As[j];
-        // Gauss-Jordan on the augmented rows [M_r | gs_r], lane r owns row r: per pivot one reciprocal, the pivot
-        // row travels by v_readlane, and every lane updates its whole row with INDEPENDENT multiply-adds -- no
-        // triangular substitutions afterwards (their 12 dependent broadcast-multiply-add steps were as long as
-        // the factorisation).  Same elimination order as the L D L^T it replaces: the pivots are its D, so
-        // "all pivots positive" is still "the Cholesky factor of lm_core.hpp exists".
-        double rhs = gs_r;
-        bool ok = true;
-#pragma unroll
-        for (int k = 0; k < 6; k++) {
-            double piv[6];
-#pragma unroll
-            for (int j = k; j < 6; j++) piv[j] = lane_bcast(M[j], k);
-            const double prhs = lane_bcast(rhs, k);
-            if (!(piv[k] > 0.0)) ok = false;
-            const double f = (r == k) ? 0.0 : M[k] * fast_rcp(piv[k]);
-#pragma unroll
-            for (int j = k; j < 6; j++) M[j] -= f * piv[j];
-            rhs -= f * prhs;
-        }
-        double y[6];
-        if (ok) {
-            const double y_r = rhs * fast_rcp(lmw_pick(M, r));
-#pragma unroll
-            for (int m = 0; m < 6; m++) y[m] = lane_bcast(y_r, m);
-#pragma unroll
-            for (int i = 0; i < 6; i++)
-                if (!lm_finite(y[i])) ok = false;
-        }
-        reuse_diag = 1;
-        double step[6];
-        model_change = 0.0;
-        if (ok) {
-            double gsdot = 0.0, quad = 0.0, row = 0.0;
-#pragma unroll
-            for (int c = 0; c < 6; c++) step[c] = -y[c];
-#pragma unroll
-            for (int b = 0; b < 6; b++) row += As[b] * step[b];
-#pragma unroll
-            for (int a = 0; a < 6; a++) {
-                gsdot += lane_bcast(gs_r, a) * step[a];
-                quad += step[a] * lane_bcast(row, a);
-            }
-            model_change = -gsdot - 0.5 * quad;
-        }
-        if (!ok || !(model_change > 0.0)) {
-            if (++invalid_run >= 5) break;
-            radius /= decrease_factor;
-            decrease_factor *= 2.0;
-            recorded++;
-            last_step_norm = 0.0;
-            iter++;
-            continue;
-        }
-        invalid_run = 0;
-        double delta[6];
-#pragma unroll
-        for (int c = 0; c < 6; c++) delta[c] = step[c] * scale_c[c];
-        manifold_plus_fast(xs, delta, cand);
-        result = LM_EVAL;
-        break;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();  // every lane has read the state
-    if (lane < 6) S.diag[r] = diag_r;
-    if (lane == 0) {
-        S.radius = radius;
-        S.decrease_factor = decrease_factor;
-        S.reuse_diag = reuse_diag;
-        S.invalid_run = invalid_run;
-        S.iter = iter;
-        S.recorded = recorded;
-        S.last_step_norm = last_step_norm;
-        if (result == LM_EVAL)
-            S.model_change = model_change;
-        else
-            S.cost = S.N.cost;
-    }
-    if (result == LM_EVAL && lane < 7) {  // one store: lane i writes cand[i]
-        double v = cand[0];
-#pragma unroll
-        for (int i = 1; i < 7; i++) v = (lane == i) ? cand[i] : v;
-        S.cand[lane] = v;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    return result;
-}
-
 // ---- ranks of one node: the ranks' totals exchanged by the GPUs themselves -------------------
 // Every rank owns a small buffer in its HBM: [4 sets][kP2pMaxRanks][32] exchange words.  Inside one
 // launch the sets alternate with the sequence number (the dependency chain of a solve keeps a rank at
@@ -1465,7 +1135,8 @@ __global__ __launch_bounds__(kT) void k_lm(const MatchRec *__restrict__ rec, uin
     __shared__ double s_tot[kRecWords];
     __shared__ double s_part[kT];
     __shared__ double s_x[7];
-    __shared__ LmState s_lm;
+    LmWave W;  // the solve's state: per-row part in the registers of the first wave, the rest in LDS (lm_wave.hpp)
+    __shared__ LmShared s_lm;
     __shared__ int s_action, s_failed;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t nb = gridDim.x;
@@ -1531,8 +1202,8 @@ __global__ __launch_bounds__(kT) void k_lm(const MatchRec *__restrict__ rec, uin
             if (lane == 0) dbg_trace[200] = (double)(ev + 1);
         }
         if (wave == 0 && !s_failed) {
-            // the first wave holds the totals (s_tot) and runs the policy (lm_core.hpp's,
-            // lane-parallel: lmw_* above) on the state in LDS
+            // the first wave holds the totals (s_tot) and runs the policy (lm_core.hpp's, lane-parallel and
+            // register-resident: lm_wave.hpp)
             int a;
             if (ev == 0) {
                 if (lane == 0) {
@@ -1541,12 +1212,11 @@ __global__ __launch_bounds__(kT) void k_lm(const MatchRec *__restrict__ rec, uin
                     counters[2] = s_tot[30];
                     counters[3] = px.nranks > 1 ? s_tot[31] : (double)n;
                 }
-                a = lmw_begin(s_lm, s_tot, s_x, init.prior_b, lane);
+                a = lmw2_begin(W, s_lm, s_tot, s_x, init.prior_b, lane);
             } else {
-                a = lmw_feed(s_lm, s_tot, lane);
+                a = lmw2_feed(W, s_lm, s_tot, s_x, init.prior_b, lane);
             }
-            if (a == LM_PROPOSE) a = lmw_propose(s_lm, lane);
-            if (lane < 7) s_x[lane] = s_lm.cand[lane];
+            if (a == LM_PROPOSE) a = lmw2_propose(W, s_lm, s_x, lane);  // the point of the next evaluation lands in s_x
             if (lane == 0) s_action = a;
         }
         LM_STAMP(4);
@@ -1564,7 +1234,7 @@ __global__ __launch_bounds__(kT) void k_lm(const MatchRec *__restrict__ rec, uin
 #undef LM_STAMP
     if (blockIdx.x != 0 || tid != 0) return;
     // ---- end of the outer iteration (workgroup 0, one lane) ----
-    const LmState &S = s_lm;  // read the few fields needed where they live (LDS)
+    const LmShared &S = s_lm;
     const int outer = first_outer ? 0 : state->outer_done;
     float pq[4], pt[3];
     for (int a = 0; a < 4; a++) pq[a] = (float)S.x[a];      // :161-164
@@ -1749,14 +1419,9 @@ static int launch_match(ScanCtx &c, const float t[3], const float q[4], float ma
                                c.n, P, (int32_t *)m->scan_idx.p, (MatchRec *)m->scan_on.p, st, d_block_counters(m),
                                (unsigned long long *)nullptr, as);
         };
-        const bool small = c.n <= kMatchSmallMax;
-        QStat *st = stats ? (QStat *)m->scan_stats.p : (QStat *)nullptr;
-        if (chained && small)
-            launch(k_match<kMatchG, 4, 4, false, true>, (QStat *)nullptr, (const AlignState *)m->align_state.p);
-        else if (chained)
-            launch(k_match<kMatchG, 2, kMatchMinWaves, false, true>, (QStat *)nullptr, (const AlignState *)m->align_state.p);
-        else if (small)
-            launch(k_match<kMatchG, 4, 4>, st, (const AlignState *)nullptr);
+        QStat *st = (stats && !chained) ? (QStat *)m->scan_stats.p : (QStat *)nullptr;
+        if (chained)
+            launch(k_match<kMatchG, 2, kMatchMinWaves, false, true>, st, (const AlignState *)m->align_state.p);
         else
             launch(k_match<kMatchG, 2, kMatchMinWaves>, st, (const AlignState *)nullptr);
         LOM_HIP(m, hipGetLastError());
@@ -2554,7 +2219,7 @@ int lom_debug_match_stamps(lom_map *m, const float *d_src, size_t n, size_t stri
     PoseArgs P;
     pose_args(t, q, max_dist, P);
     for (int rep = 0; rep < 3; rep++)  // the last launch's stamps are kept (warm caches, like an align)
-        hipLaunchKernelGGL((k_match<kMatchG, 1, kMatchMinWaves, true>), dim3(nb), dim3(kMatchThreads), 0, m->stream, view_of(m),
+        hipLaunchKernelGGL((k_match<kMatchG, 2, kMatchMinWaves, true>), dim3(nb), dim3(kMatchThreads), 0, m->stream, view_of(m),
                            (const char *)d_src, stride, (uint32_t)n, P, (int32_t *)m->scan_idx.p,
                            (MatchRec *)m->scan_on.p, (QStat *)nullptr, d_block_counters(m), d_st);
     hipError_t e = hipMemcpyAsync(stamps_out, d_st, (size_t)nb * 64, hipMemcpyDeviceToHost, m->stream);

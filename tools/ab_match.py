@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Back-to-back launch trains of k_match on C2 and C3 (the numbers quoted in match.hip come from
-rebuilding with other template arguments and running this)."""
+"""k_match on C2, C3, C4 and the streaming path's matching cloud: back-to-back launch trains at the identity pose
+(lom_profile_match) and whole aligns.  (The numbers quoted in match.hip / DESIGN.md for other template arguments
+come from rebuilding and running this.)"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -10,22 +11,33 @@ import lidar_odometry_demo_amd as lom
 from lidar_odometry_demo_amd import synth
 
 boxes = synth.make_boxes()
-if os.environ.get("LOM_TABLE_MULT"):
-    print("table mult", os.environ["LOM_TABLE_MULT"], flush=True)
 cases = {}
-for name, (nb, naz, nmap) in {"C2": (16, 1800, 500_000), "C3": (64, 2048, 2_000_000)}.items():
+maps = {}
+for name, (nb, naz, nmap) in {"C2": (16, 1800, 500_000), "C5m": (16, 1800, 500_000), "C3": (64, 2048, 2_000_000),
+                              "C4": (128, 2048, 2_000_000)}.items():
+    if os.environ.get("LOM_AB_CASES") and name not in os.environ["LOM_AB_CASES"].split(","):
+        continue
     scan, _, _, _ = synth.make_scan(nb, naz, boxes=boxes)
-    mp, mn = synth.make_map_points(nmap, boxes=boxes)
-    g = lom.VoxelGrid(0.5, 20)
-    g.addCloud(mp, mn)
+    if name == "C5m":
+        scan = np.ascontiguousarray(scan[::3])      # ~8.9k points, like the streaming path's matching cloud
+    if nmap not in maps:
+        mp, mn = synth.make_map_points(nmap, boxes=boxes)
+        g = lom.VoxelGrid(0.5, 20)
+        g.addCloud(mp, mn)
+        maps[nmap] = g
     d = torch.from_numpy(scan).to("cuda:0")
     torch.cuda.synchronize()
-    cases[name] = (g, d)
+    cases[name] = (maps[nmap], d)
 REPS = int(os.environ.get("LOM_AB_REPS", "100"))
 for rep in range(int(os.environ.get("LOM_AB_ROUNDS", "3"))):
-    for v in ("built-in",):
-        row = []
-        for name, (g, d) in cases.items():
-            us, by, rq = g.profileMatch(d.data_ptr(), d.shape[0], lom.Pose3D(), 0.3, reps=REPS)
-            row.append(f"{name} {us:7.2f} us alg {by / us / 1e3:6.0f} GB/s req {rq / us / 1e3:6.0f} GB/s")
-        print(f"variant {v}: " + " | ".join(row), flush=True)
+    row = []
+    for name, (g, d) in cases.items():
+        us, by, rq, _ = g.profileMatch(d.data_ptr(), d.shape[0], lom.Pose3D(), 0.3, reps=REPS)
+        lom.align_repeat(g, d.data_ptr(), d.shape[0], lom.Pose3D(), 20)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        lom.align_repeat(g, d.data_ptr(), d.shape[0], lom.Pose3D(), 100)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) * 10.0
+        row.append(f"{name} {us:6.2f} us ({rq / us / 1e3:5.0f} GB/s req) align {ms:.4f} ms")
+    print(" | ".join(row), flush=True)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Phase stamps of the device-resident solve (k_lm) on the C2 workload: LOM_DEBUG_LM=1 makes the align
+"""Phase stamps of the device-resident solve (k_lm) on the C2 workload: LOM_OPT_DEBUG_LM_STAMPS makes the align
 print, for workgroup 0's first lane, the shader-clock cycles of accumulate / reduce+exchange / policy
 per evaluation and the split of one reduce+exchange (stderr).  Entries of the different k_lm launches
 of one align overwrite each other: read them as samples, not as one timeline."""
@@ -21,6 +21,6 @@ m = lom.CloudMatcher()
 guess = lom.Pose3D((0.05, -0.04, 0.02), (0.99996, 0.0, 0.0017, 0.0087))
 for _ in range(3):
     m.align(g, scan, guess)
-os.environ["LOM_DEBUG_LM"] = "1"
+g.setOption(lom.capi.OPT_DEBUG_LM_STAMPS, 1)
 m.align(g, scan, guess)
 print(m.stats)

@@ -1,0 +1,144 @@
+// k_lm's policy step (csrc/lm_wave.hpp: lmw_begin / lmw_feed / lmw_propose on one wave) in isolation: replays the
+// evaluations of six real solves (policy_case.h, written by make_policy_case.py from the HOST driver's run of the
+// same align), checks every point the wave proposes against the host's lm_core.hpp, and times the steps with the
+// shader clock.  build: hipcc -O3 -ffp-contract=off --offload-arch=gfx950 -I lidar_odometry_demo_amd/csrc
+//        tools/microbench/policy.hip -o tools/microbench/policy
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+
+#include "lm_wave.hpp"
+#include "policy_case.h"
+
+using namespace lom;
+
+struct Case {
+    double x[kSolves][kMaxEvals][7];
+    double sums[kSolves][kMaxEvals][32];
+    double prior_b[3];
+    int evals[kSolves];
+};
+
+struct Out {
+    double cand[kSolves][kMaxEvals][7];    // the point proposed after evaluation e of solve s
+    int action[kSolves][kMaxEvals];
+    unsigned long long cycles[kSolves][kMaxEvals];
+    int recorded[kSolves], evaluations[kSolves];
+    double last_step_norm[kSolves], cost[kSolves];
+};
+
+template <int kForm>
+__global__ __launch_bounds__(64) void k_policy(const Case *c, Out *o, int reps)
+{
+    __shared__ LmState s_lm;
+    __shared__ LmShared s_sh;
+    __shared__ double s_tot[32], s_x[7];
+    const int lane = threadIdx.x;
+    LmWave W;
+    for (int rep = 0; rep < reps; rep++) {
+        for (int s = 0; s < kSolves; s++) {
+            for (int e = 0; e < c->evals[s]; e++) {
+                if (lane < 32) s_tot[lane] = c->sums[s][e][lane];
+                if (lane < 7 && e == 0) s_x[lane] = c->x[s][0][lane];
+                __syncthreads();
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+                int a;
+                if constexpr (kForm == 1) {
+                    if (e == 0)
+                        a = lmw_begin(s_lm, s_tot, s_x, c->prior_b, lane);
+                    else
+                        a = lmw_feed(s_lm, s_tot, lane);
+                    if (a == LM_PROPOSE) a = lmw_propose(s_lm, lane);
+                    if (lane < 7) s_x[lane] = s_lm.cand[lane];
+                } else {
+                    a = e == 0 ? lmw2_begin(W, s_sh, s_tot, s_x, c->prior_b, lane) : lmw2_feed(W, s_sh, s_tot, s_x, c->prior_b, lane);
+                    if (a == LM_PROPOSE) a = lmw2_propose(W, s_sh, s_x, lane);
+                }
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+                __syncthreads();
+                if (lane < 7) o->cand[s][e][lane] = s_x[lane];
+                if (lane == 0) {
+                    o->action[s][e] = a;
+                    o->cycles[s][e] = t1 - t0;
+                }
+                __syncthreads();
+            }
+            if (lane == 0) {
+                o->recorded[s] = kForm == 1 ? s_lm.recorded : s_sh.recorded;
+                o->evaluations[s] = kForm == 1 ? s_lm.evaluations : s_sh.evaluations;
+                o->last_step_norm[s] = kForm == 1 ? s_lm.last_step_norm : s_sh.last_step_norm;
+                o->cost[s] = kForm == 1 ? s_lm.cost : s_sh.cost;
+            }
+        }
+    }
+}
+
+int main()
+{
+    static Case h;
+    for (int s = 0; s < kSolves; s++) {
+        h.evals[s] = kEvals[s];
+        for (int e = 0; e < kMaxEvals; e++) {
+            for (int k = 0; k < 7; k++) h.x[s][e][k] = kX[s][e][k];
+            for (int k = 0; k < 32; k++) h.sums[s][e][k] = kSums[s][e][k];
+        }
+    }
+    for (int k = 0; k < 3; k++) h.prior_b[k] = kPriorB[k];
+    Case *dc;
+    Out *dout;
+    static Out ho;
+    if (hipMalloc(&dc, sizeof h) != hipSuccess || hipMalloc(&dout, sizeof ho) != hipSuccess) return 2;
+    (void)hipMemcpy(dc, &h, sizeof h, hipMemcpyHostToDevice);
+    int bad = 0, bad_total = 0;
+    for (int form = 1; form <= 2; form++) {
+    if (form == 1)
+        hipLaunchKernelGGL(k_policy<1>, dim3(1), dim3(64), 0, 0, dc, dout, 20);
+    else
+        hipLaunchKernelGGL(k_policy<2>, dim3(1), dim3(64), 0, 0, dc, dout, 20);
+    if (hipMemcpy(&ho, dout, sizeof ho, hipMemcpyDeviceToHost) != hipSuccess) return 2;
+    printf("---- form %d (%s)\n", form, form == 1 ? "state in LDS, v_readlane broadcasts" : "state in registers, DPP broadcasts");
+    // host reference: the serial lm_core.hpp on the same sums
+    bad = 0;
+    double worst = 0.0;
+    unsigned long long solve_cycles = 0, nosolve_cycles = 0;
+    int n_solve = 0, n_nosolve = 0;
+    for (int s = 0; s < kSolves; s++) {
+        LmState S;
+        for (int e = 0; e < kEvals[s]; e++) {
+            const int a = e == 0 ? lm_begin(S, h.sums[s][0], h.x[s][0], h.prior_b) : lm_feed(S, h.sums[s][e]);
+            if (a != ho.action[s][e]) {
+                printf("solve %d evaluation %d: action %d, host %d\n", s, e, ho.action[s][e], a);
+                bad++;
+            }
+            if (a == LM_EVAL) {
+                for (int k = 0; k < 7; k++) {
+                    const double d = fabs(ho.cand[s][e][k] - S.cand[k]);
+                    worst = fmax(worst, d);
+                    if (d > 1e-13) bad++;
+                    if (e + 1 < kEvals[s] && fabs(S.cand[k] - h.x[s][e + 1][k]) > 1e-15) bad++;  // the recorded run itself
+                }
+                solve_cycles += ho.cycles[s][e];
+                n_solve++;
+            } else {
+                nosolve_cycles += ho.cycles[s][e];
+                n_nosolve++;
+            }
+            printf("solve %d evaluation %d: action %d, %6llu cycles\n", s, e, ho.action[s][e], ho.cycles[s][e]);
+        }
+        if (ho.recorded[s] != S.recorded || ho.evaluations[s] != S.evaluations || fabs(ho.last_step_norm[s] - S.last_step_norm) > 1e-13 ||
+            fabs(ho.cost[s] - S.cost) > 1e-12 * fabs(S.cost)) {
+            printf("solve %d: recorded %d/%d evaluations %d/%d step %.17g/%.17g cost %.17g/%.17g\n", s, ho.recorded[s], S.recorded,
+                   ho.evaluations[s], S.evaluations, ho.last_step_norm[s], S.last_step_norm, ho.cost[s], S.cost);
+            bad++;
+        }
+    }
+    printf("policy step with a solve: %.0f cycles (n = %d); without: %.0f (n = %d); worst |cand - host| = %.3g; mismatches %d\n",
+           n_solve ? (double)solve_cycles / n_solve : 0.0, n_solve, n_nosolve ? (double)nosolve_cycles / n_nosolve : 0.0, n_nosolve,
+           worst, bad);
+    bad_total += bad;
+    }
+    return bad_total != 0;
+}
