@@ -144,15 +144,17 @@ def cpu_baseline(work, budget_s=10.0):
                       "CPU restatement of the reference algorithm (oracle/), not the reference binary"}
 
 
-def streaming(args, lom):
+def streaming(args, lom, steps=None, warmup=None, cpu_frames=40):
     """BASELINE.json configs[4]: 10 Hz VLP16 sequence through the full per-frame pipeline
     (time-normalise, deskew, classify, range filter, two down-samplers, align, cleanup, keyframe
     insert; defaults of LidarOdometry::Params).  A step = one processCloud; frames are generated
-    on the host before the timed region."""
+    on the host before the timed region.  Returns the line."""
     from lidar_odometry_demo_amd import synth
 
+    steps = args.steps if steps is None else steps
+    warmup = args.warmup if warmup is None else warmup
     boxes = synth.make_boxes()
-    n_frames = args.warmup + args.steps
+    n_frames = warmup + steps
     frames = [synth.make_sequence_frame(k, boxes=boxes) for k in range(n_frames)]
     spin = lom.LidarOdometry()          # bring an idle GPU up to steady clocks (untimed, separate state)
     t_spin = time.perf_counter()
@@ -161,11 +163,11 @@ def streaming(args, lom):
         spin.processCloud(frames[1])
     del spin
     odo = lom.LidarOdometry()
-    for k in range(args.warmup):
+    for k in range(warmup):
         odo.processCloud(frames[k])
     q0 = odo.stats["queries_total"]      # (waits for the warm-up's last keyframe update)
     t0 = time.perf_counter()
-    for k in range(args.warmup, n_frames):
+    for k in range(warmup, n_frames):
         odo.processCloud(frames[k])      # the keyframe update of frame k runs beside frame k+1's host stages
     queries = odo.stats["queries_total"] - q0   # waits for the last keyframe update: inside the timed region
     elapsed = time.perf_counter() - t0
@@ -174,24 +176,25 @@ def streaming(args, lom):
     dq = abs(float(np.dot(pose.rotation.astype(np.float64), gt_q)))
     line = {
         "metric": "icp_correspondences_per_sec", "value": queries / elapsed / 1e6, "unit": "Mcorr/s", "n_gpus": 1,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "frames_per_s": args.steps / elapsed,
+        "frames_per_s": steps / elapsed,
         "config": {"workload": "C5: streaming 10 Hz VLP16 sequence, full per-frame pipeline, default params",
                    "points_per_frame": int(np.mean([len(f) for f in frames])),
                    "keyframe_voxels": odo.stats["keyframe_voxels"],
+                   "frames_redone_on_host_or_scans_redone": odo.debugCounter(),
                    "matching_points_last": odo.stats["matching_points"],
                    "drift_translation_m": float(np.linalg.norm(pose.translation.astype(np.float64) - gt_t)),
                    "drift_rotation_rad": 2.0 * float(np.arccos(min(1.0, dq))),
                    "drift_note": "x is weakly observable in the street-canyon scene and the reference's "
                                  "translation prior holds it back; yaw, y and z track"},
     }
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and cpu_frames > 0:
         from oracle import oracle as O
 
         cores = min(len(os.sched_getaffinity(0)), 16)
         ref = O.LidarOdometry(nthreads=cores)
-        m = min(n_frames, 40)
+        m = min(n_frames, cpu_frames)
         t1 = time.perf_counter()
         q = 0
         for k in range(m):
@@ -201,7 +204,140 @@ def streaming(args, lom):
         line["cpu_baseline"] = {"value": q / el / 1e6, "unit": "Mcorr/s", "cores": cores, "kind": "port",
                                 "frames_per_s": m / el,
                                 "sample": f"first {m} frames of the same sequence ({el:.1f} s), CPU restatement"}
-    emit(line)
+    return line
+
+
+def concurrent_contexts(lom, torch, grid, d_scan, guess, steps, counts=(2, 3, 4)):
+    """Side figure (never `value`): `k` host threads, one scan context each (lom_scan_create), all aligning the same
+    device-resident scan against the ONE keyframe at the same time -- what `const VoxelGrid&` allows the reference's
+    callers (voxel_grid.h:206, cloud_matcher.h:15).  A solve keeps ~53 of the 256 CUs busy on a VLP16-sized scan, so
+    concurrent callers are how one GPU is filled.  The C calls release the GIL."""
+    import threading
+
+    out = {}
+    for k in counts:
+        ctxs = [lom.ScanContext(grid) for _ in range(k)]
+        for c in ctxs:
+            lom.align_repeat(c, d_scan.data_ptr(), d_scan.shape[0], guess, 20)
+        torch.cuda.synchronize()
+        start = threading.Barrier(k + 1)
+        res = [None] * k
+
+        def work(i):
+            start.wait()
+            res[i] = lom.align_repeat(ctxs[i], d_scan.data_ptr(), d_scan.shape[0], guess, steps)[1]
+
+        th = [threading.Thread(target=work, args=(i,)) for i in range(k)]
+        for t in th:
+            t.start()
+        start.wait()
+        t0 = time.perf_counter()
+        for t in th:
+            t.join()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        out[str(k)] = {"frames_per_s": k * steps / el, "value": sum(r["queries"] for r in res) / el / 1e6, "unit": "Mcorr/s",
+                       "ms_per_align_per_context": el / steps * 1e3,
+                       "host_fallbacks": sum(r["host_fallback"] for r in res)}
+        for c in ctxs:
+            c.close()
+    return out
+
+
+def traffic_record(config):
+    """HBM-side bytes per k_match launch as last collected with rocprofv3 --pmc (tools/collect_traffic.py; FETCH_SIZE
+    doubled + WRITE_SIZE, MI355X_MICROARCH.md): a constant from profiles/, NOT a measurement of this run."""
+    for tag in ("r03", "r02", "r01"):
+        tpath = os.path.join(ROOT, "profiles", f"traffic_{tag}.json")
+        if os.path.exists(tpath):
+            with open(tpath) as f:
+                rec = json.load(f)
+            if rec.get("config", "C2") != config:
+                continue
+            return rec.get("hbm_bytes_per_launch"), (f"profiles/traffic_{tag}.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in "
+                                                       f"separate passes, collected at commit {rec.get('commit', '?')}); "
+                                                       "a constant, not measured in this run")
+    return None, None
+
+
+def match_roofline(n_queries, alg_per_launch, req_per_launch, avg_us, traffic, traffic_source, extra=None):
+    """`roofline` of the dominant kernel on the SURVEY.md 8(d) definition for EVERY configuration: algorithmic bytes per
+    launch / the kernel's average launch duration against the 8 TB/s HBM peak.  Where the map is served from L2 /
+    Infinity Cache that fraction can exceed 1 (the formula also counts candidates the exact pruning never reads): the
+    cache-level yardstick sits beside it under its own key, never in `frac`."""
+    achieved = alg_per_launch / (avg_us * 1e-6) / 1e9
+    roof = {
+        "kernel": "k_match (27-neighbour correspondence search)",
+        "bound": "hbm",
+        "achieved": achieved,
+        "peak": HBM_PEAK_GBS,
+        "unit": "GB/s",
+        "frac": achieved / HBM_PEAK_GBS,
+        "traffic": traffic,
+        "traffic_source": traffic_source,
+        "algorithmic_bytes_per_launch": alg_per_launch,
+        "avg_launch_us": avg_us,
+        "requested_bytes_per_launch": req_per_launch,
+        "requested_gbs": (req_per_launch / (avg_us * 1e-6) / 1e9 if req_per_launch else None),
+        "requested_note": "bytes the kernel itself asks for: neighbour voxels that provably cannot hold a point "
+                          "within max_dist are not scanned (exact pruning), + 52 B output/query",
+        "hbm_measured_gbs": (traffic / (avg_us * 1e-6) / 1e9 if traffic else None),
+        "hbm_measured_frac": (traffic / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS if traffic else None),
+        "kernel_only_mcorr_s": n_queries / (avg_us * 1e-6) / 1e6,
+        "limited_by": "latency and VALU issue, not HBM: the map (payload + table) is L2 / Infinity-Cache resident, a query is "
+                      "a chain of dependent round trips (source point, 27 slots, candidates, winner's normal); SQ counters in "
+                      "profiles/ (waves 60-70 % in s_waitcnt; on the 2M-point map VALU issue ~80 % of the SIMD cycles)",
+    }
+    if req_per_launch:
+        roof["cache_level"] = {
+            "achieved": roof["requested_gbs"], "peak": CACHE_PEAK_GBS, "frac": roof["requested_gbs"] / CACHE_PEAK_GBS,
+            "unit": "GB/s",
+            "basis": "REQUESTED bytes / time against the Infinity-Cache-served rate of random rows (8.6 TB/s, "
+                     "MI355X_MICROARCH.md 'Indexed rows'); a side figure, `frac` above stays on the 8(d) definition"}
+    if extra:
+        roof.update(extra)
+    return roof
+
+
+def align_block(lom, torch, work, dev, steps, warmup_aligns=200):
+    """A short block of aligns of another configuration on this GPU (the default run's extra_configs): map build,
+    warm-up, `steps` aligns issued back to back from compiled code, k_match / k_lm durations from HIP events on
+    every 8th align.  Same definitions as the main line."""
+    grid = lom.VoxelGrid(0.5, 20, device=dev.index or 0)
+    d_map_xyz = torch.from_numpy(work["map_xyz"]).to(dev)
+    d_map_nrm = torch.from_numpy(work["map_nrm"]).to(dev)
+    torch.cuda.synchronize()
+    insert_us = grid.profileInsert(d_map_xyz.data_ptr(), d_map_nrm.data_ptr(), d_map_xyz.shape[0])
+    del d_map_xyz, d_map_nrm
+    d_scan = torch.from_numpy(work["shard"]).to(dev)
+    torch.cuda.synchronize()
+    guess = lom.Pose3D()
+    lom.align_repeat(grid, d_scan.data_ptr(), d_scan.shape[0], guess, warmup_aligns)
+    grid.setProfiling(8)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    pose, tot = lom.align_repeat(grid, d_scan.data_ptr(), d_scan.shape[0], guess, steps)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    grid.setProfiling(0)
+    train_us, _, train_requested, pair_us = grid.profileMatch(d_scan.data_ptr(), d_scan.shape[0], pose, 0.3, reps=50)
+    overhead = max(0.0, pair_us - train_us)
+    prof = max(tot["profiled_launches"], 1)
+    match_us = max(tot["match_kernel_ms"] * 1e3 / prof - overhead, 1e-3)
+    lm_us = max(tot["lm_kernel_ms"] * 1e3 / max(tot["lm_profiled_launches"], 1) - overhead, 1e-3)
+    alg = tot["algorithmic_bytes"] / max(tot["match_launches"], 1)
+    n = int(d_scan.shape[0])
+    return {
+        "workload": work["name"], "steps": steps, "ms_per_step": elapsed / steps * 1e3,
+        "value": tot["queries"] / elapsed / 1e6, "unit": "Mcorr/s", "frames_per_s": steps / elapsed,
+        "outer_iterations_per_frame": tot["outer_iterations"] / steps, "evaluations_per_frame": tot["evaluations"] / steps,
+        "scan_points": n, "map_points_stored": grid.pointCount(), "map_voxels": grid.size(),
+        "roofline": match_roofline(n, alg, train_requested, match_us, None, None,
+                                   {"train_avg_launch_us": train_us, "event_pair_overhead_us": overhead,
+                                    "in_loop_launches_measured": tot["profiled_launches"]}),
+        "k_lm_avg_us": lm_us, "k_match_avg_us": match_us, "insert_chain_us": insert_us,
+        "pose": {"t": [float(v) for v in pose.translation], "q_wxyz": [float(v) for v in pose.rotation]},
+    }
 
 
 def main():
@@ -210,6 +346,8 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="default run only: skip the short C3 block and the 200-frame C5 block attached as extra_configs")
     ap.add_argument("--config", choices=["C2", "C3", "C4", "C5"], default="C2",
                     help="C2 = BASELINE.json configs[1] (the bench line; weak-scaled with --gpus N); C3 = configs[2], "
                          "single GPU only; C4 = configs[3], 128x2048 scan range-sharded over --gpus N ranks (any N "
@@ -253,7 +391,8 @@ def main():
     if args.config not in ("C2", "C4") and n != 1:
         raise SystemExit(f"--config {args.config} is a single-GPU configuration")
     if args.config == "C5":
-        return streaming(args, lom)
+        emit(streaming(args, lom))
+        return
     work = build_workload(n, rank, args.config)
     grid = lom.VoxelGrid(0.5, 20, device=local_rank)
     # the keyframe map: one bulk insert of device-resident points, bracketed by HIP events on the library's
@@ -277,6 +416,7 @@ def main():
     # shared memory.  "rccl": host-driven solve, all-gather over xGMI.
     exchange = os.environ.get("LOM_EXCHANGE", "p2p")
     host_comm = None
+    selftest = {"result": None, "what": "no device-to-device exchange attached"}
     L = lom.capi.lib()
 
     def broadcast_id(make):
@@ -302,7 +442,10 @@ def main():
             host_comm = h
             if kind == "p2p":
                 if L.lom_comm_attach_p2p(grid.handle, h) == 0:
+                    selftest.update(result="passed", what="lom_comm_attach_p2p: 200 exchanges of known values through the "
+                                                         "IPC mappings, verdict agreed by all ranks")
                     return
+                selftest.update(result="failed", what=L.lom_last_error(grid.handle).decode())
                 # the verdict is collective: every rank lands here together
                 print(f"[bench] rank {rank}: device-to-device exchange not available "
                       f"({L.lom_last_error(grid.handle).decode()}); using the host exchange", file=sys.stderr)
@@ -351,6 +494,7 @@ def main():
     launch_ms, wait_ms = tot["host_launch_ms"], tot["host_wait_ms"]
     fence()
     elapsed = time.perf_counter() - t0
+    my_elapsed = elapsed
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if one_device else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -407,6 +551,32 @@ def main():
         matcher.align(grid, work["shard"], guess)
     pcie_ms = (time.perf_counter() - t1) / max(3, args.steps // 4) * 1e3
 
+    # what a scaling run needs to be believed: who took part (rank ids gathered through the exchange object the
+    # transport itself uses), on which devices, and every rank's own step time
+    my_ms = my_elapsed / args.steps * 1e3
+    props = torch.cuda.get_device_properties(local_rank)
+    my_dev = f"{getattr(props, 'name', '?')}|pci {getattr(props, 'pci_domain_id', 0):04x}:{getattr(props, 'pci_bus_id', -1):02x}:" \
+             f"{getattr(props, 'pci_device_id', -1):02x}|uuid {getattr(props, 'uuid', '?')}"
+    if use_dist:
+        objs = [None] * world
+        dist.all_gather_object(objs, (rank, my_dev, my_ms))
+        rank_ms = [o[2] for o in objs]
+        devices_seen = sorted({o[1] for o in objs})
+        if host_comm is not None:
+            import ctypes as C
+
+            mine = (C.c_int32 * 1)(rank)
+            got = (C.c_int32 * world)()
+            rc_g = L.lom_host_comm_allgather(host_comm, mine, 4, got)
+            ranks_seen = {"through": f"lom_host_comm_allgather (the exchange object of the '{exchange}' transport)",
+                          "ranks": [int(v) for v in got] if rc_g == 0 else None, "rc": int(rc_g)}
+        else:
+            ranks_seen = {"through": "torch.distributed all_gather_object (RCCL transport: the library's communicator "
+                                     "carries sums only)", "ranks": [o[0] for o in objs], "rc": 0}
+    else:
+        rank_ms, devices_seen = [my_ms], [my_dev]
+        ranks_seen = {"through": "single rank", "ranks": [0], "rc": 0}
+
     if rank == 0:
         # stats are global (summed over ranks) after the in-library all-gather
         value = queries / elapsed / 1e6
@@ -421,24 +591,8 @@ def main():
         alg_per_launch = alg_bytes / max(launches, 1) / n      # counters are totals over ranks after the exchange
         req_per_launch = train_requested if n == 1 else None   # counted at the final pose (the train)
         achieved = alg_per_launch / (in_loop_us * 1e-6) / 1e9
-        traffic = None
-        for tag in ("r02", "r01"):
-            tpath = os.path.join(ROOT, "profiles", f"traffic_{tag}.json")
-            if n == 1 and args.config == "C2" and os.path.exists(tpath):
-                with open(tpath) as f:
-                    traffic = json.load(f).get("hbm_bytes_per_launch")
-                break
-        cache_served = args.config in ("C3", "C4")
-        roof = {
-            "kernel": "k_match (27-neighbour correspondence search)",
-            "bound": "hbm",
-            "achieved": achieved,
-            "peak": HBM_PEAK_GBS,
-            "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic,
-            "algorithmic_bytes_per_launch": alg_per_launch,
-            "avg_launch_us": in_loop_us,
+        traffic, traffic_source = traffic_record(args.config) if n == 1 else (None, None)
+        roof = match_roofline(int(d_scan.shape[0]), alg_per_launch, req_per_launch, in_loop_us, traffic, traffic_source, {
             "avg_launch_us_method": "HIP event pairs around the k_match launches of every 16th step inside the timed "
                                     "region, minus the per-pair event overhead measured in this run",
             "in_loop_raw_us": in_loop_raw_us,
@@ -447,33 +601,8 @@ def main():
             "train_avg_launch_us": train_us,
             "train_note": "50 back-to-back launches at the final pose under one event pair (best case: warm caches, "
                           "converged pose)",
-            "requested_bytes_per_launch": req_per_launch,
-            "requested_gbs": (req_per_launch / (in_loop_us * 1e-6) / 1e9 if req_per_launch else None),
-            "requested_note": "bytes the kernel itself asks for: neighbour voxels that provably cannot hold a point "
-                              "within max_dist are not scanned (exact pruning), + 52 B output/query",
             "launches": launches,
-            # (ii) rocprof-measured HBM bytes / time beside (i) algorithmic bytes / time
-            "hbm_measured_gbs": (traffic / (in_loop_us * 1e-6) / 1e9 if traffic else None),
-            "hbm_measured_frac": (traffic / (in_loop_us * 1e-6) / 1e9 / HBM_PEAK_GBS if traffic else None),
-            "kernel_only_mcorr_s": int(d_scan.shape[0]) / (in_loop_us * 1e-6) / 1e6,
-            "note": "the map (payload + table) fits the 256 MiB Infinity Cache: algorithmic bytes / time is not what "
-                    "HBM itself delivers; SQ counters (profiles/README.md): the kernel is VALU-issue- and latency-bound "
-                    "at this size",
-        }
-        if cache_served and req_per_launch:
-            # C3 / C4: the formula of SURVEY.md 8(d) counts candidates the exact pruning never reads, and what is
-            # read comes from L2 / Infinity Cache: the honest yardstick is requested bytes against the cache level
-            roof.update({
-                "bound": "hbm",
-                "achieved": roof["requested_gbs"],
-                "peak": CACHE_PEAK_GBS,
-                "frac": roof["requested_gbs"] / CACHE_PEAK_GBS,
-                "basis": "REQUESTED bytes / time against the Infinity-Cache-served rate of random rows (8.6 TB/s, "
-                         "MI355X_MICROARCH.md 'Indexed rows'): the 2M-point map is read from L2 / Infinity Cache, not "
-                         "HBM; the algorithmic-bytes figure of SURVEY.md 8(d) is kept beside it",
-                "algorithmic_gbs": achieved,
-                "algorithmic_frac_of_hbm_peak": achieved / HBM_PEAK_GBS,
-            })
+        })
         # -- the other kernels of the path
         lm_raw_us = lm_ms * 1e3 / max(lm_profiled, 1)
         lm_us = max(lm_raw_us - event_overhead_us, 1e-3) if lm_profiled else None
@@ -524,6 +653,10 @@ def main():
                                    "note": f"the official block first, then {EXTRA_BLOCKS} more blocks of {args.steps} steps"},
             "config": {
                 "workload": work["name"],
+                "ranks_seen": ranks_seen,
+                "devices": devices_seen,
+                "exchange_selftest": selftest,
+                "ms_per_step_ranks": {"min": min(rank_ms), "max": max(rank_ms)},
                 "scan_points_per_gpu": int(d_scan.shape[0]),
                 "scan_points_total": int(len(work["scan"])),
                 "map_points_stored": stored,
@@ -550,6 +683,36 @@ def main():
             line["cpu_baseline"] = cpu_baseline(work)
             line["speedup_vs_cpu_port"] = value / line["cpu_baseline"]["value"]
         line["pose"] = {"t": [float(v) for v in pose.translation], "q_wxyz": [float(v) for v in pose.rotation]}
+        if n == 1 and not use_dist and not args.no_extras:
+            try:
+                cc = concurrent_contexts(lom, torch, grid, d_scan, guess, args.steps)
+                line["concurrent_contexts"] = dict(cc, note="k threads, one scan context each, the same scan against the one "
+                                                            "keyframe at the same time; a side figure, never `value`")
+                line["frames_per_s_2ctx"] = cc["2"]["frames_per_s"]
+            except Exception as e:  # noqa: BLE001
+                line["concurrent_contexts"] = {"error": repr(e)[:300]}
+        if n == 1 and args.config == "C2" and not args.no_extras and not use_dist:
+            # the other single-GPU configurations of BASELINE.json, short blocks on the same box (never `value`)
+            extras = {}
+            t_x = time.perf_counter()
+            try:
+                w3 = build_workload(1, 0, "C3")
+                extras["C3"] = align_block(lom, torch, w3, dev, steps=max(20, args.steps // 4))
+                del w3
+            except Exception as e:  # noqa: BLE001  (an extra must not cost the line)
+                extras["C3"] = {"error": repr(e)[:300]}
+            try:
+                c5 = streaming(args, lom, steps=200, warmup=10, cpu_frames=0)
+                extras["C5"] = {"workload": c5["config"]["workload"], "frames": 200, "ms_per_frame": c5["ms_per_step"],
+                                "frames_per_s": c5["frames_per_s"], "value": c5["value"], "unit": "Mcorr/s",
+                                "drift_translation_m": c5["config"]["drift_translation_m"],
+                                "drift_rotation_rad": c5["config"]["drift_rotation_rad"],
+                                "points_per_frame": c5["config"]["points_per_frame"],
+                                "keyframe_voxels": c5["config"]["keyframe_voxels"]}
+            except Exception as e:  # noqa: BLE001
+                extras["C5"] = {"error": repr(e)[:300]}
+            extras["wall_s"] = time.perf_counter() - t_x
+            line["extra_configs"] = extras
         emit(line)
 
     if use_dist:

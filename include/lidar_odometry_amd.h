@@ -19,7 +19,8 @@
  *   - poses are f32 {t[3], q[4] = w,x,y,z} like the reference's Pose3D.
  *   - a handle owns all device memory, one HIP stream and one pinned result
  *     buffer; it is single-caller (not internally locked).  Independent
- *     handles may be used from different threads.
+ *     handles may be used from different threads; further callers of ONE map
+ *     take a scan context each (lom_scan_create).
  *   - there is NO CPU fallback: without a gfx950 device lom_map_create fails
  *     with LOM_ERR_NO_DEVICE.
  */
@@ -302,6 +303,32 @@ int lom_map_wait_event(lom_map *m, void *hip_event);
 int lom_map_set_stream(lom_map *m, void *hip_stream);
 /* the hipStream_t the handle currently works on (to put several handles on one stream) */
 void *lom_map_get_stream(lom_map *m);
+
+/* ---- scan contexts: several callers aligning against ONE keyframe ------------------------------------- */
+/* VoxelGrid::getCorrespondence / findMatchingPairs are const (src/voxel_grid.h:164,206) and CloudMatcher::align takes
+ * `const VoxelGrid&` (src/cloud_matcher.h:15-16): any number of threads may align against one keyframe at a time.
+ * A map handle is single-caller; a lom_scan is what each further caller owns -- stream, per-scan buffers, solve state,
+ * report block -- while its kernels read the map's table and slabs.  Contexts of one map may be used concurrently
+ * from different threads (one caller per context), as long as nobody changes the map meanwhile (lom_map_add_points*,
+ * lom_map_radius_cleanup, lom_map_clear: the reference's non-const members); destroy them before the map.
+ * One solve keeps 53 of the 256 CUs busy on a VLP16-sized scan: concurrent contexts are how one GPU is filled. */
+typedef struct lom_scan lom_scan;
+int lom_scan_create(lom_map *map, lom_scan **out);
+void lom_scan_destroy(lom_scan *s);
+const char *lom_scan_last_error(const lom_scan *s);
+int lom_scan_set_option(lom_scan *s, int option, int64_t value);   /* lom_map_set_option's switches, per context */
+int lom_scan_set_stream(lom_scan *s, void *hip_stream_or_null);
+void *lom_scan_get_stream(lom_scan *s);
+/* lom_match_align / _align_device / _align_repeat / lom_match_find_pairs on the context */
+int lom_scan_align(lom_scan *s, const float *src_xyz, size_t n, size_t stride_bytes, const float guess_t[3],
+                   const float guess_q_wxyz[4], float out_t[3], float out_q_wxyz[4], lom_align_stats *stats_or_null);
+int lom_scan_align_device(lom_scan *s, const float *d_src_xyz, size_t n, size_t stride_bytes, const float guess_t[3],
+                          const float guess_q_wxyz[4], float out_t[3], float out_q_wxyz[4], lom_align_stats *stats_or_null);
+int lom_scan_align_repeat(lom_scan *s, const float *d_src_xyz, size_t n, size_t stride_bytes, const float guess_t[3],
+                          const float guess_q_wxyz[4], int reps, float out_t[3], float out_q_wxyz[4],
+                          lom_align_stats *total_or_null);
+int64_t lom_scan_find_pairs(lom_scan *s, const float *src_xyz, size_t n, size_t stride_bytes, const float t[3],
+                            const float q_wxyz[4], float max_dist, lom_correspondence *out);
 
 /* ---- multi-GPU: source points range-sharded, map replicated ------------- */
 /* One all-gather of LOM_NSUMS f64 per residual evaluation over RCCL, summed in

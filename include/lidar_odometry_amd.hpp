@@ -17,12 +17,15 @@
 // lom::Error (status code + lom_last_error text).  Without a gfx950 device the
 // VoxelGrid constructor throws -- there is no CPU fallback.
 #pragma once
+#include <atomic>
 #include <cmath>
 #include <cstddef>
 #include <cstdint>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
+#include <unordered_map>
 #include <utility>
 #include <vector>
 
@@ -145,10 +148,38 @@ public:
         const int rc = lom_map_create(voxel_size, max_points, 0, device, &h_);
         if (rc != LOM_OK) throw Error(rc, std::string("lom_map_create: ") + lom_last_error(nullptr));
     }
-    ~VoxelGrid() { lom_map_destroy(h_); }
+    ~VoxelGrid()
+    {
+        for (lom_scan *s : scans_) lom_scan_destroy(s);  // contexts go before their map
+        lom_map_destroy(h_);
+    }
     VoxelGrid(const VoxelGrid &) = delete;
     VoxelGrid &operator=(const VoxelGrid &) = delete;
-    VoxelGrid(VoxelGrid &&o) noexcept : h_(o.h_) { o.h_ = nullptr; }
+    VoxelGrid(VoxelGrid &&o) noexcept : h_(o.h_), id_(o.id_), scans_(std::move(o.scans_))
+    {
+        o.h_ = nullptr;
+        o.scans_.clear();
+    }
+
+    // The const members of the reference (getCorrespondence, findMatchingPairs, and CloudMatcher::align, which takes
+    // `const VoxelGrid&`) may be called from several threads at once.  A map handle is single-caller, so every thread
+    // gets a scan context of its own for this grid (lom_scan_create: stream, per-scan buffers, solve state), created
+    // on its first such call and owned by the grid.  As in the reference, nobody may change the grid meanwhile.
+    lom_scan *scan_context() const
+    {
+        thread_local std::unordered_map<uint64_t, lom_scan *> mine;  // this thread's contexts, by grid id
+        auto it = mine.find(id_);
+        if (it != mine.end()) return it->second;
+        lom_scan *s = nullptr;
+        const int rc = lom_scan_create(h_, &s);
+        if (rc != LOM_OK) throw Error(rc, lom_last_error(h_));
+        {
+            std::lock_guard<std::mutex> lock(scans_mutex_);
+            scans_.push_back(s);
+        }
+        mine.emplace(id_, s);
+        return s;
+    }
 
     void setMaxPoints(size_t max_points) { check(lom_map_set_max_points(h_, max_points)); }
     void setVoxelSize(float voxel_size) { check(lom_map_clear(h_, voxel_size)); }
@@ -247,9 +278,10 @@ private:
         std::vector<Correspondence> out(cloud.points.size());
         if (cloud.points.empty()) return out;
         const lom_pose p = transform.c();
-        const int64_t rc = lom_match_find_pairs(h_, &cloud.points.data()->x, cloud.points.size(), sizeof(PointXYZ),
-                                                p.t, p.q, max_dist, raw.data());
-        if (rc < 0) throw Error((int)rc, lom_last_error(h_));
+        lom_scan *ctx = scan_context();
+        const int64_t rc = lom_scan_find_pairs(ctx, &cloud.points.data()->x, cloud.points.size(), sizeof(PointXYZ),
+                                               p.t, p.q, max_dist, raw.data());
+        if (rc < 0) throw Error((int)rc, lom_scan_last_error(ctx));
         for (size_t i = 0; i < raw.size(); i++) {
             Correspondence &c = out[i];
             c.valid = raw[i].index >= 0;
@@ -264,7 +296,15 @@ private:
         return out;
     }
 
+    static uint64_t next_id()
+    {
+        static std::atomic<uint64_t> n{1};
+        return n.fetch_add(1);
+    }
     lom_map *h_ = nullptr;
+    uint64_t id_ = next_id();  // never reused: a thread's cached context of a destroyed grid is never looked up again
+    mutable std::mutex scans_mutex_;
+    mutable std::vector<lom_scan *> scans_;
 };
 
 // ---- CloudMatcher (src/cloud_matcher.h) --------------------------------------------
@@ -275,9 +315,11 @@ public:
         const lom_pose g = position_guess.c();
         lom_pose o;
         const float *src = planar_cloud.points.empty() ? nullptr : &planar_cloud.points.data()->x;
-        const int rc = lom_match_align(keyframe.handle(), src, planar_cloud.points.size(), sizeof(PointXYZ), g.t, g.q,
-                                       o.t, o.q, &last_stats);
-        if (rc != LOM_OK) throw Error(rc, lom_last_error(keyframe.handle()));
+        // stateless like the reference's (lidar_odometry.cpp:49 constructs one per frame): the solve state lives in the
+        // calling thread's scan context of this keyframe, so several threads may align against one grid at a time
+        lom_scan *ctx = keyframe.scan_context();
+        const int rc = lom_scan_align(ctx, src, planar_cloud.points.size(), sizeof(PointXYZ), g.t, g.q, o.t, o.q, &last_stats);
+        if (rc != LOM_OK) throw Error(rc, lom_scan_last_error(ctx));
         return Pose3D::from(o);
     }
     lom_align_stats last_stats{};

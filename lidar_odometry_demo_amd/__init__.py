@@ -14,7 +14,7 @@ import numpy as np
 from . import capi
 from .capi import LomError  # noqa: F401
 
-__all__ = ["Pose3D", "VoxelGrid", "CloudMatcher", "LidarOdometry", "transform_points", "pointTimeNormalize",
+__all__ = ["Pose3D", "VoxelGrid", "CloudMatcher", "ScanContext", "LidarOdometry", "transform_points", "pointTimeNormalize",
            "transformNonRigid", "rangeFilter", "classify", "loadPCDFile", "fromROSMsg", "toROSMsg", "estimateNormals", "FrontEnd", "LomError", "capi"]
 
 
@@ -209,14 +209,57 @@ class VoxelGrid:
         capi.check(capi.lib().lom_map_set_profiling(self._h, int(period)), self._h)
 
 
+class ScanContext:
+    """lom_scan: what a further caller of ONE keyframe owns (stream, per-scan buffers, solve state) -- the reference's
+    search and align take the grid by const reference (voxel_grid.h:206, cloud_matcher.h:15), so several threads may
+    align against one keyframe at a time.  Pass it to CloudMatcher.align / alignDevice / align_repeat in place of the
+    grid.  One caller per context; nobody changes the grid while contexts are in use."""
+
+    def __init__(self, keyframe):
+        h = C.c_void_p()
+        capi.check(capi.lib().lom_scan_create(keyframe.handle, C.byref(h)), keyframe.handle)
+        self._h = h
+        self.keyframe = keyframe          # keeps the grid alive
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h and capi is not None:
+            capi.lib().lom_scan_destroy(h)
+            self._h = None
+
+    close = __del__
+
+    @property
+    def handle(self):
+        return self._h
+
+    def setOption(self, option, value):
+        if capi.lib().lom_scan_set_option(self._h, int(option), int(value)) != 0:
+            raise LomError(-1, "lom_scan_set_option")
+
+    def _check(self, rc):
+        if rc < 0:
+            text = capi.lib().lom_scan_last_error(self._h)
+            raise LomError(int(rc), text.decode() if text else "")
+        return rc
+
+
+def _align_entry(keyframe, name):
+    """(function, checker) for a grid or a scan context"""
+    L = capi.lib()
+    if isinstance(keyframe, ScanContext):
+        return getattr(L, "lom_scan_" + name), keyframe._check
+    return getattr(L, "lom_match_" + name), (lambda rc: capi.check(rc, keyframe.handle))
+
+
 def align_repeat(keyframe, d_src_ptr, n, position_guess, reps, stride_bytes=12):
     """`reps` back-to-back aligns of a device-resident scan issued from compiled code
     (lom_match_align_repeat): (pose of the last one, accumulated stats)."""
     ot, oq = (C.c_float * 3)(), (C.c_float * 4)()
     st = capi.AlignStats()
-    capi.check(capi.lib().lom_match_align_repeat(
-        keyframe.handle, d_src_ptr, int(n), int(stride_bytes), capi.f3(position_guess.translation),
-        capi.f4(position_guess.rotation), int(reps), ot, oq, C.byref(st)), keyframe.handle)
+    fn, chk = _align_entry(keyframe, "align_repeat")
+    chk(fn(keyframe.handle, d_src_ptr, int(n), int(stride_bytes), capi.f3(position_guess.translation),
+           capi.f4(position_guess.rotation), int(reps), ot, oq, C.byref(st)))
     return Pose3D(np.array(ot[:], np.float32), np.array(oq[:], np.float32)), st.asdict()
 
 
@@ -230,9 +273,9 @@ class CloudMatcher:
         xyz = capi.xyz_array(planar_cloud)
         ot, oq = (C.c_float * 3)(), (C.c_float * 4)()
         st = capi.AlignStats()
-        capi.check(capi.lib().lom_match_align(
-            keyframe.handle, xyz.ctypes.data, len(xyz), 12, capi.f3(position_guess.translation),
-            capi.f4(position_guess.rotation), ot, oq, C.byref(st)), keyframe.handle)
+        fn, chk = _align_entry(keyframe, "align")
+        chk(fn(keyframe.handle, xyz.ctypes.data, len(xyz), 12, capi.f3(position_guess.translation),
+               capi.f4(position_guess.rotation), ot, oq, C.byref(st)))
         self.stats = st.asdict()
         return Pose3D(np.array(ot[:], np.float32), np.array(oq[:], np.float32))
 
@@ -269,9 +312,9 @@ class CloudMatcher:
         """Source cloud already resident in HBM (device pointer, e.g. torch tensor.data_ptr())."""
         ot, oq = (C.c_float * 3)(), (C.c_float * 4)()
         st = capi.AlignStats()
-        capi.check(capi.lib().lom_match_align_device(
-            keyframe.handle, d_src_ptr, int(n), int(stride_bytes), capi.f3(position_guess.translation),
-            capi.f4(position_guess.rotation), ot, oq, C.byref(st)), keyframe.handle)
+        fn, chk = _align_entry(keyframe, "align_device")
+        chk(fn(keyframe.handle, d_src_ptr, int(n), int(stride_bytes), capi.f3(position_guess.translation),
+               capi.f4(position_guess.rotation), ot, oq, C.byref(st)))
         self.stats = st.asdict()
         return Pose3D(np.array(ot[:], np.float32), np.array(oq[:], np.float32))
 

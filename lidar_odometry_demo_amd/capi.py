@@ -126,6 +126,8 @@ EXPORTED = [
     "lom_pointcloud2_unpack", "lom_pointcloud2_layout", "lom_pointcloud2_pack_xyz", "lom_pointcloud2_last_error",
     "lom_map_set_option", "lom_map_debug_counter", "lom_odometry_set_option", "lom_odometry_debug_counter",
     "lom_frontend_set_option", "lom_host_comm_set_timeout", "lom_host_comm_abort", "lom_host_comm_last_error",
+    "lom_scan_create", "lom_scan_destroy", "lom_scan_last_error", "lom_scan_set_option", "lom_scan_set_stream",
+    "lom_scan_get_stream", "lom_scan_align", "lom_scan_align_device", "lom_scan_align_repeat", "lom_scan_find_pairs",
 ]
 
 # lom_option / counters of include/lidar_odometry_amd.h
@@ -299,6 +301,20 @@ def lib():
     L.lom_host_comm_abort.argtypes = [vp]
     L.lom_host_comm_last_error.argtypes = [vp]
     L.lom_host_comm_last_error.restype = C.c_char_p
+    L.lom_scan_create.argtypes = [vp, C.POINTER(vp)]
+    L.lom_scan_destroy.argtypes = [vp]
+    L.lom_scan_destroy.restype = None
+    L.lom_scan_last_error.argtypes = [vp]
+    L.lom_scan_last_error.restype = C.c_char_p
+    L.lom_scan_set_option.argtypes = [vp, C.c_int, C.c_int64]
+    L.lom_scan_set_stream.argtypes = [vp, vp]
+    L.lom_scan_get_stream.argtypes = [vp]
+    L.lom_scan_get_stream.restype = vp
+    L.lom_scan_align.argtypes = L.lom_match_align.argtypes
+    L.lom_scan_align_device.argtypes = L.lom_match_align.argtypes
+    L.lom_scan_align_repeat.argtypes = L.lom_match_align_repeat.argtypes
+    L.lom_scan_find_pairs.argtypes = L.lom_match_find_pairs.argtypes
+    L.lom_scan_find_pairs.restype = C.c_int64
     _lib = L
     return L
 

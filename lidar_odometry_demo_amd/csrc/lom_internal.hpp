@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -124,6 +125,13 @@ struct DeviceBuf {
 
 struct lom_map {
     int device = 0;
+    // a scan context (lom_scan_create): no table or slabs of its own, its kernels read the parent's
+    lom_map *parent = nullptr;
+    // map side: calls that changed the map (their kernels run on THIS handle's stream); context side: the count its
+    // stream has been ordered behind, and the event it uses for that
+    uint64_t mutations = 0, seen_mutations = ~0ull;
+    hipEvent_t parent_ev = nullptr;
+    std::mutex settle_mutex;  // contexts settling a pending insert of / ordering themselves behind their map
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     float voxel_size = 0.5f;

@@ -73,8 +73,9 @@ int ensure(lom_map *m, DeviceBuf &b, size_t bytes)
     return LOM_OK;
 }
 
-MapView view_of(const lom_map *m)
+MapView view_of(const lom_map *self)
 {
+    const lom_map *m = self->parent ? self->parent : self;  // a scan context reads its keyframe's table and slabs
     MapView v;
     v.table = m->d_table;
     v.mask = m->cap - 1;
@@ -761,6 +762,7 @@ static int refresh_nvox(lom_map *m)
 
 static int rehash(lom_map *m, uint32_t new_cap)
 {
+    m->mutations++;
     Slot *t = nullptr;
     int rc = table_alloc(m, new_cap, &t);
     if (rc != LOM_OK) return rc;
@@ -975,6 +977,27 @@ static int map_status(lom_map *m)
 // Callers that check lom_map_status() themselves (the streaming path) never pay this read-back.
 int resolve_pending(lom_map *m)
 {
+    if (m->parent) {
+        // A scan context.  The reference's calls are synchronous: an align that follows an addCloud sees its points.
+        // Here the map's maintenance kernels run on the MAP's stream and a context has a stream of its own, so the
+        // first call of a context after the map changed (a) settles an insert nobody has looked at yet and (b) orders
+        // the context's stream behind the map's.  (Nobody changes the map while contexts are in use; several contexts
+        // may arrive here together after a change, hence the lock.)
+        lom_map *p = m->parent;
+        if (!p->pending_n && m->seen_mutations == p->mutations) return LOM_OK;
+        std::lock_guard<std::mutex> lock(p->settle_mutex);
+        if (p->pending_n) {
+            const int rc = resolve_pending(p);
+            if (rc != LOM_OK) return set_error(m, rc, p->last_error.c_str());
+        }
+        if (m->seen_mutations != p->mutations) {
+            if (!m->parent_ev) LOM_HIP(m, hipEventCreateWithFlags(&m->parent_ev, hipEventDisableTiming));
+            LOM_HIP(m, hipEventRecord(m->parent_ev, p->stream));
+            LOM_HIP(m, hipStreamWaitEvent(m->stream, m->parent_ev, 0));
+            m->seen_mutations = p->mutations;
+        }
+        return LOM_OK;
+    }
     if (!m->pending_n) return LOM_OK;
     int rc = read_words(m, 7, 1);
     if (rc != LOM_OK) return rc;
@@ -991,6 +1014,7 @@ int resolve_pending(lom_map *m)
 static int add_points_device(lom_map *m, const char *d_xyz, const char *d_nrm, size_t n, size_t stride,
                              bool validated_on_host, bool sync_status, bool allow_shrink, bool multi_launch)
 {
+    if (m->parent) return set_error(m, LOM_ERR_STATE, "a scan context has no map of its own");
     if (n == 0) return LOM_OK;
     if (n >= 0x7FFFFFFFull) return set_error(m, LOM_ERR_ARG, "too many points in one call");
     const uint32_t N = (uint32_t)n;
@@ -1026,6 +1050,7 @@ static int add_points_device(lom_map *m, const char *d_xyz, const char *d_nrm, s
     uint32_t *boff = (uint32_t *)m->scr[S_BKT_OFF].p, *bold = (uint32_t *)m->scr[S_BKT_OLD].p;
     uint32_t *words = d_word(m, 0);
     const uint32_t seq = ++m->call_seq;
+    m->mutations++;
     const MapView v = view_of(m);
     const dim3 g(blocks_for(N)), b(kThreads);
     hipLaunchKernelGGL(k_ins_claim2, g, b, 0, m->stream, m->d_table, v.mask, v.shift, d_xyz, stride, N, m->voxel_size,
@@ -1186,6 +1211,84 @@ int lom_device_local_cpus(int device, char *out, size_t cap)
 
 const char *lom_last_error(const lom_map *m) { return m ? m->last_error.c_str() : g_create_error.c_str(); }
 
+// what every handle owns besides a map: a stream and the pinned blocks the align talks to the host through
+static int handle_setup(lom_map *m)
+{
+    hipError_t e;
+    if ((e = hipSetDevice(m->device)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipHostMalloc((void **)&m->h_results, 1024 * sizeof(double), hipHostMallocDefault)) != hipSuccess ||
+        (e = hipHostMalloc((void **)&m->h_flags, 64 * sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess ||
+        (e = hipHostMalloc((void **)&m->h_mail, 64 * 32 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent)) !=
+            hipSuccess ||
+        (e = hipHostGetDevicePointer((void **)&m->d_mail, m->h_mail, 0)) != hipSuccess ||
+        (e = hipHostMalloc(&m->h_cmd, 256, hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess ||
+        (e = hipHostGetDevicePointer(&m->d_cmd, m->h_cmd, 0)) != hipSuccess ||
+        (e = hipHostMalloc(&m->h_report, 1024, hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess ||
+        (e = hipHostGetDevicePointer(&m->d_report, m->h_report, 0)) != hipSuccess)
+        return set_error(nullptr, LOM_ERR_HIP, "handle setup", e);
+    m->stream = m->own_stream;
+    std::memset(m->h_mail, 0, 64 * 32 * sizeof(double));
+    std::memset(m->h_cmd, 0, 256);
+    std::memset(m->h_report, 0, 1024);
+    return LOM_OK;
+}
+
+// ---- scan contexts ---------------------------------------------------------------------------------------------
+// The reference's search and align take the grid by const reference (voxel_grid.h:164,206; cloud_matcher.h:15-16):
+// any number of callers may align against one keyframe at a time.  A context is a handle without a map of its own
+// -- stream, per-scan buffers, solve state, report block -- whose kernels read the keyframe's table and slabs.
+int lom_scan_create(lom_map *map, lom_scan **out)
+{
+    if (!map || !out) return LOM_ERR_ARG;
+    *out = nullptr;
+    if (map->parent) return set_error(map, LOM_ERR_ARG, "a scan context cannot be the keyframe of another");
+    LOM_HIP(map, hipSetDevice(map->device));
+    int rc = refresh_nvox(map);  // settles a pending insert: nothing mutates the keyframe while contexts read it
+    if (rc != LOM_OK) return rc;
+    lom_map *c = new (std::nothrow) lom_map();
+    if (!c) return set_error(map, LOM_ERR_OOM, "host allocation");
+    c->device = map->device;
+    c->parent = map;
+    c->opt_host_lm = map->opt_host_lm;
+    c->opt_debug_lm = map->opt_debug_lm;
+    c->opt_debug_timing = map->opt_debug_timing;
+    c->patience_ticks = map->patience_ticks;
+    if (handle_setup(c) != LOM_OK) {
+        map->last_error = g_create_error;
+        lom_map_destroy(c);
+        return LOM_ERR_HIP;
+    }
+    *out = reinterpret_cast<lom_scan *>(c);
+    return LOM_OK;
+}
+
+void lom_scan_destroy(lom_scan *s) { lom_map_destroy(reinterpret_cast<lom_map *>(s)); }
+const char *lom_scan_last_error(const lom_scan *s) { return s ? reinterpret_cast<const lom_map *>(s)->last_error.c_str() : ""; }
+int lom_scan_set_option(lom_scan *s, int option, int64_t value) { return lom_map_set_option(reinterpret_cast<lom_map *>(s), option, value); }
+int lom_scan_set_stream(lom_scan *s, void *hip_stream) { return lom_map_set_stream(reinterpret_cast<lom_map *>(s), hip_stream); }
+void *lom_scan_get_stream(lom_scan *s) { return lom_map_get_stream(reinterpret_cast<lom_map *>(s)); }
+int lom_scan_align(lom_scan *s, const float *src, size_t n, size_t stride, const float guess_t[3], const float guess_q[4],
+                   float out_t[3], float out_q[4], lom_align_stats *stats)
+{
+    return lom_match_align(reinterpret_cast<lom_map *>(s), src, n, stride, guess_t, guess_q, out_t, out_q, stats);
+}
+int lom_scan_align_device(lom_scan *s, const float *d_src, size_t n, size_t stride, const float guess_t[3],
+                          const float guess_q[4], float out_t[3], float out_q[4], lom_align_stats *stats)
+{
+    return lom_match_align_device(reinterpret_cast<lom_map *>(s), d_src, n, stride, guess_t, guess_q, out_t, out_q, stats);
+}
+int lom_scan_align_repeat(lom_scan *s, const float *d_src, size_t n, size_t stride, const float guess_t[3],
+                          const float guess_q[4], int reps, float out_t[3], float out_q[4], lom_align_stats *total)
+{
+    return lom_match_align_repeat(reinterpret_cast<lom_map *>(s), d_src, n, stride, guess_t, guess_q, reps, out_t, out_q, total);
+}
+int64_t lom_scan_find_pairs(lom_scan *s, const float *src, size_t n, size_t stride, const float t[3], const float q[4],
+                            float max_dist, lom_correspondence *out)
+{
+    return lom_match_find_pairs(reinterpret_cast<lom_map *>(s), src, n, stride, t, q, max_dist, out);
+}
+
 int lom_map_create(float voxel_size, size_t max_points, size_t capacity_hint, int device, lom_map **out)
 {
     if (!out) return LOM_ERR_ARG;
@@ -1214,26 +1317,10 @@ int lom_map_create(float voxel_size, size_t max_points, size_t capacity_hint, in
     m->opt_host_lm = getenv("LOM_HOST_LM") != nullptr;
     m->opt_debug_lm = getenv("LOM_DEBUG_LM") != nullptr;
     m->opt_debug_timing = getenv("LOM_DEBUG_TIMING") != nullptr;
-    hipError_t e;
-    if ((e = hipSetDevice(device)) != hipSuccess ||
-        (e = hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking)) != hipSuccess ||
-        (e = hipHostMalloc((void **)&m->h_results, 1024 * sizeof(double), hipHostMallocDefault)) != hipSuccess ||
-        (e = hipHostMalloc((void **)&m->h_flags, 64 * sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess ||
-        (e = hipHostMalloc((void **)&m->h_mail, 64 * 32 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent)) !=
-            hipSuccess ||
-        (e = hipHostGetDevicePointer((void **)&m->d_mail, m->h_mail, 0)) != hipSuccess ||
-        (e = hipHostMalloc(&m->h_cmd, 256, hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess ||
-        (e = hipHostGetDevicePointer(&m->d_cmd, m->h_cmd, 0)) != hipSuccess ||
-        (e = hipHostMalloc(&m->h_report, 1024, hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess ||
-        (e = hipHostGetDevicePointer(&m->d_report, m->h_report, 0)) != hipSuccess) {
-        set_error(nullptr, LOM_ERR_HIP, "handle setup", e);
+    if (handle_setup(m) != LOM_OK) {
         lom_map_destroy(m);
         return LOM_ERR_HIP;
     }
-    m->stream = m->own_stream;
-    std::memset(m->h_mail, 0, 64 * 32 * sizeof(double));
-    std::memset(m->h_cmd, 0, 256);
-    std::memset(m->h_report, 0, 1024);
     m->min_cap = next_pow2(4ull * std::max<size_t>(capacity_hint, 256));
     // status / counter words (256 bytes) + the block aggregates of the single-pass kernels (256 x 2 granules)
     int rc = ensure(m, m->scr[S_MISC], 256 + 256 * 2 * sizeof(Granule));
@@ -1279,6 +1366,7 @@ void lom_map_destroy(lom_map *m)
     if (m->h_mail) (void)hipHostFree(m->h_mail);
     if (m->h_stage) (void)hipHostFree(m->h_stage);
     if (m->stage_ev) (void)hipEventDestroy(m->stage_ev);
+    if (m->parent_ev) (void)hipEventDestroy(m->parent_ev);
     if (m->h_cmd) (void)hipHostFree(m->h_cmd);
     if (m->h_report) (void)hipHostFree(m->h_report);
     for (auto &e : m->prof_events)
@@ -1345,6 +1433,7 @@ int lom_map_clear(lom_map *m, float voxel_size)
     m->n_vox_stale = false;
     m->n_points = 0;
     m->pending_n = 0;
+    m->mutations++;
     if (!m->table_clean) {
         hipLaunchKernelGGL(k_table_init, dim3(blocks_for(m->cap)), dim3(kThreads), 0, m->stream, m->d_table, m->cap);
         LOM_HIP(m, hipMemsetAsync(d_nvox(m), 0, 4, m->stream));
@@ -1475,6 +1564,7 @@ int lom_map_radius_cleanup(lom_map *m, const float center[3], float radius)
     uint32_t *keep = (uint32_t *)m->scr[S_FLAG].p, *newid = (uint32_t *)m->scr[S_RANK].p;
     const float r2 = radius * radius;  // voxel_grid.h:238
     const uint32_t seq = ++m->call_seq;
+    m->mutations++;
     bool one_pass = true;
     auto launch_scan = [&](auto items) {
         constexpr int kItems = decltype(items)::value;

@@ -7,6 +7,8 @@
 #include <cstdio>
 #include <cstdlib>
 
+#include <thread>
+
 #include "lidar_odometry_amd.hpp"
 
 using namespace lom;
@@ -146,6 +148,34 @@ static void CloudMatcher_MatchingTest()  // protocol of test.cpp:226-262 on a sy
         EXPECT(error.translation.norm() < 0.05);  // test.cpp:261
         EXPECT(rotation_error < 0.01);            // test.cpp:262
         EXPECT(matcher.last_stats.outer_iterations >= 5 && matcher.last_stats.outer_iterations <= 35);
+    }
+    // `const VoxelGrid&` (cloud_matcher.h:15-16): the seven guesses again, one thread each, all at once against the one
+    // keyframe -- every thread must get the pose the serial loop above got for its guess, bit for bit
+    {
+        std::vector<Pose3D> serial, parallel(guess_poses.size());
+        for (const auto &guess_pose : guess_poses)
+            serial.push_back(matcher.align(keyframe, *CloudTransformer::transform(*subsampled_cloud, guess_pose.inverse()), Pose3D()));
+        const VoxelGrid &shared = keyframe;
+        std::vector<std::thread> threads;
+        for (size_t i = 0; i < guess_poses.size(); i++)
+            threads.emplace_back([&, i]() {
+                CloudMatcher mine;  // stateless, like the reference's
+                auto cloud = CloudTransformer::transform(*subsampled_cloud, guess_poses[i].inverse());
+                for (int rep = 0; rep < 5; rep++) parallel[i] = mine.align(shared, *cloud, Pose3D());
+                auto some = shared.findMatchingPairs(*cloud, Pose3D(), 0.3f);
+                if (some.empty()) parallel[i].translation.v[0] = 1e9f;
+            });
+        for (auto &t : threads) t.join();
+        int equal = 0;
+        for (size_t i = 0; i < guess_poses.size(); i++) {
+            bool same = true;
+            for (int k = 0; k < 3; k++) same = same && serial[i].translation.v[k] == parallel[i].translation.v[k];
+            for (int k = 0; k < 4; k++) same = same && serial[i].rotation.q[k] == parallel[i].rotation.q[k];
+            equal += same;
+            const double terr = parallel[i].relativeTo(guess_poses[i]).translation.norm();
+            EXPECT(terr < 0.05);
+        }
+        EXPECT(equal >= (int)guess_poses.size() - 1);  // (a solve that found the GPU too full redoes itself host-driven: 1e-6)
     }
     // findMatchingPairs / getCorrespondence shapes
     auto pairs = keyframe.findMatchingPairs(*subsampled_cloud, Pose3D(), 0.3f);

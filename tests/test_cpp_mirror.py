@@ -14,7 +14,7 @@ LIBDIR = os.path.join(ROOT, "lidar_odometry_demo_amd")
 
 def _build(out):
     cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-I", os.path.join(ROOT, "include"), SRC, "-o", out,
-           "-L", LIBDIR, "-llidar_odometry_amd", f"-Wl,-rpath,{LIBDIR}", "-Wl,-rpath,/opt/rocm/lib"]
+           "-L", LIBDIR, "-llidar_odometry_amd", "-pthread", f"-Wl,-rpath,{LIBDIR}", "-Wl,-rpath,/opt/rocm/lib"]
     subprocess.check_call(cmd)
     return out
 
