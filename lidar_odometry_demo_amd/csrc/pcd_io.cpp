@@ -108,7 +108,24 @@ extern "C" {
 
 const char *lom_pcd_last_error(void) { return g_pcd_error.c_str(); }
 
+static int64_t pcd_read(const char *path, float *xyz_out, float *nrm_out, size_t cap, lom_pcd_info *info);
+
+// Nothing may leave an extern "C" function as an exception (the callers are C, ctypes, JNI ...): allocation
+// failures of the parser's own buffers come back as LOM_ERR_OOM.
 int64_t lom_pcd_read(const char *path, float *xyz_out, float *nrm_out, size_t cap, lom_pcd_info *info)
+{
+    try {
+        return pcd_read(path, xyz_out, nrm_out, cap, info);
+    } catch (const std::bad_alloc &) {
+        return fail(LOM_ERR_OOM, "out of memory while reading the PCD file");
+    } catch (const std::exception &e) {
+        return fail(LOM_ERR_ARG, std::string("PCD reader: ") + e.what());
+    }
+}
+
+}  // extern "C"
+
+static int64_t pcd_read(const char *path, float *xyz_out, float *nrm_out, size_t cap, lom_pcd_info *info)
 {
     if (!path || (cap && !xyz_out)) return fail(LOM_ERR_ARG, "null argument");
     std::FILE *f = std::fopen(path, "rb");
@@ -126,9 +143,11 @@ int64_t lom_pcd_read(const char *path, float *xyz_out, float *nrm_out, size_t ca
     for (;;) {
         std::string line;
         int c;
-        while ((c = std::fgetc(f)) != EOF && c != '\n') line.push_back((char)c);
+        while ((c = std::fgetc(f)) != EOF && c != '\n') {
+            if (line.size() >= 65536) return fail(LOM_ERR_ARG, "PCD header line too long");  // before it is buffered
+            line.push_back((char)c);
+        }
         if (c == EOF && line.empty()) return fail(LOM_ERR_ARG, "PCD header ends before DATA");
-        if (line.size() > 65536) return fail(LOM_ERR_ARG, "PCD header line too long");
         const std::vector<std::string> tok = split(line);
         if (tok.empty() || tok[0][0] == '#') continue;
         const std::string &key = tok[0];
@@ -192,6 +211,9 @@ int64_t lom_pcd_read(const char *path, float *xyz_out, float *nrm_out, size_t ca
         if (nm == "normal_z") inz = (int)i;
     }
     if (ix < 0 || iy < 0 || iz < 0) return fail(LOM_ERR_ARG, "PCD file has no x / y / z fields");
+    // SIZE and COUNT come from the file: a record of more than 64 KiB is not a point cloud this reader is for
+    // (64 fields of COUNT 2^20 x 8 bytes would ask for half a terabyte of chunk buffer below)
+    if (step == 0 || step > 65536) return fail(LOM_ERR_ARG, "PCD record size (sum of SIZE x COUNT) must be 1 .. 65536 bytes");
     const bool has_normals = inx >= 0 && iny >= 0 && inz >= 0;
     if (info) {
         info->points = points;
@@ -205,7 +227,7 @@ int64_t lom_pcd_read(const char *path, float *xyz_out, float *nrm_out, size_t ca
     if (!take) return (int64_t)points;
     if (data_kind == 1) {
         // records in chunks: the file may be far larger than what the caller wants of it
-        const size_t chunk = 65536;
+        const size_t chunk = std::max<size_t>(1, std::min<size_t>(65536, ((size_t)16 << 20) / step));  // <= 16 MiB of buffer
         std::vector<unsigned char> buf(chunk * step);
         size_t done = 0;
         while (done < take) {
@@ -240,7 +262,10 @@ int64_t lom_pcd_read(const char *path, float *xyz_out, float *nrm_out, size_t ca
         int c;
         do {
             line.clear();
-            while ((c = std::fgetc(f)) != EOF && c != '\n') line.push_back((char)c);
+            while ((c = std::fgetc(f)) != EOF && c != '\n') {
+                if (line.size() >= ((size_t)1 << 22)) return fail(LOM_ERR_ARG, "PCD data line too long");
+                line.push_back((char)c);
+            }
         } while (c != EOF && split(line).empty());
         const std::vector<std::string> tok = split(line);
         if (tok.size() < n_tok) return fail(LOM_ERR_ARG, "PCD body is shorter than POINTS says");
@@ -257,4 +282,4 @@ int64_t lom_pcd_read(const char *path, float *xyz_out, float *nrm_out, size_t ca
     return (int64_t)points;
 }
 
-}  // extern "C"
+

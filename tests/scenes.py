@@ -122,7 +122,7 @@ def matrix_to_quat(R):
 
 # ---- normals for the shipped data file -----------------------------------
 
-def estimate_normals_radius(xyz, radius):
+def estimate_normals_radius(xyz, radius, details=False):
     """Restates pcl::NormalEstimation with setRadiusSearch(radius) as used by
     test/test.cpp:196-205: covariance of all points within `radius` (the point
     itself included), eigenvector of the smallest eigenvalue, flipped toward the
@@ -148,6 +148,8 @@ def estimate_normals_radius(xyz, radius):
     flip = (-(x) * nrm).sum(1) < 0  # (vp - p).n < 0, vp = 0
     nrm[flip] *= -1
     nrm[cnt < 3] = np.nan
+    if details:   # + neighbour counts and the covariance's eigenvalues (ascending): how well defined a normal is
+        return nrm.astype(np.float32), cnt, w
     return nrm.astype(np.float32)
 
 

@@ -11,19 +11,30 @@ pytestmark = pytest.mark.gpu
 
 
 def test_normals_match_the_restatement_on_the_fixture(lom, fixture_cloud):
+    """Every normal that is WELL DEFINED agrees with the numpy restatement to 1e-6: same neighbour set on both sides
+    (equal counts; the two sides decide "within the radius" on differently rounded distances, so a point on the
+    sphere can be in on one side and out on the other) and a covariance whose two smallest eigenvalues are
+    separated (gap (l1 - l0) / l2 > 1e-3: the smallest eigenvector of a nearly isotropic neighbourhood -- three or
+    four points, a line -- is not stable under rounding on either side).  The rest is counted and bounded."""
     xyz, xyzn = fixture_cloud
     sub = xyz[::3].copy()                                   # ~20k points keep the numpy side in seconds
-    ref = scenes.estimate_normals_radius(sub, 0.25)
+    ref, cnt_ref, w = scenes.estimate_normals_radius(sub, 0.25, details=True)
     got, cnt = lom.estimateNormals(sub, 0.25, with_counts=True)
     nan_ref, nan_got = np.isnan(ref).any(axis=1), np.isnan(got).any(axis=1)
-    # the two sides decide "within the radius" on differently rounded distances: a point exactly on the sphere may differ
-    assert (nan_ref != nan_got).sum() <= 3
+    assert (nan_ref != nan_got).sum() <= 3                  # a neighbour exactly on the sphere
     ok = ~nan_ref & ~nan_got
     assert ok.sum() > 0.5 * len(sub)                        # every third point only: sparser neighbourhoods
-    dots = np.abs((ref[ok].astype(np.float64) * got[ok].astype(np.float64)).sum(axis=1))
-    # planes with a clear smallest eigenvalue agree to f32 precision; nearly isotropic neighbourhoods (3-4 points,
-    # lines) have no stable normal on either side
-    assert np.mean(dots > 1 - 1e-6) > 0.97, np.mean(dots > 1 - 1e-6)
+    dots = np.abs((ref.astype(np.float64) * got.astype(np.float64)).sum(axis=1))
+    gap = (w[:, 1] - w[:, 0]) / np.maximum(w[:, 2], 1e-300)
+    same_set = cnt.astype(np.int64) == cnt_ref
+    defined = ok & same_set & (gap > 1e-3)
+    assert defined.sum() > 0.85 * ok.sum(), (defined.sum(), ok.sum())
+    assert (dots[defined] > 1 - 1e-6).all(), (np.sort(dots[defined])[:5], np.sort(gap[defined & (dots <= 1 - 1e-6)])[:5])
+    rest = ok & ~defined
+    # of the rest: different neighbour sets (boundary points) or no stable normal; still mostly the same plane
+    assert (ok & ~same_set).sum() < 0.01 * ok.sum(), (ok & ~same_set).sum()
+    assert np.mean(dots[rest] > 1 - 1e-3) > 0.5 or rest.sum() < 50
+    assert np.mean(dots[ok] > 1 - 1e-6) > 0.97
     assert np.allclose(np.linalg.norm(got[ok], axis=1), 1.0, atol=1e-5)
     # flipped towards the viewpoint (0, 0, 0)
     assert ((-sub[ok].astype(np.float64) * got[ok].astype(np.float64)).sum(axis=1) >= -1e-9).all()
@@ -60,5 +71,19 @@ def test_matching_test_protocol_with_device_normals(lom, fixture_cloud):
     xyzn = np.c_[xyz[keep], nrm[keep]].astype(np.float32)
     assert keep.sum() > 0.9 * len(xyz)
     res = scenes.run_matching_test(lom, xyz, xyzn)
-    for c in res["cases"]:
+    import json
+    import os
+
+    from tests.conftest import GOLDEN
+
+    with open(os.path.join(GOLDEN, "c1_matching_test.json")) as f:
+        golden = json.load(f)["cases"]
+    worst = (0.0, 0.0)
+    for c, gc in zip(res["cases"], golden):
         assert c["err_t_norm"] < 0.05 and c["rot_err"] < 0.01            # test.cpp:261-262
+        # and against the golden poses of the same protocol run with the restatement's normals (oracle, committed):
+        # the helper's normals differ from those in the last bits and on a few boundary points only
+        dt, dr = scenes.pose_delta(np.array(c["final_t"], np.float32), np.array(c["final_q_wxyz"], np.float32),
+                                   np.array(gc["final_t"], np.float32), np.array(gc["final_q_wxyz"], np.float32))
+        worst = (max(worst[0], dt), max(worst[1], dr))
+    assert worst[0] < 2e-3 and worst[1] < 2e-3, worst

@@ -234,11 +234,6 @@ def test_lm_optimum_matches_scipy_huber(oracle):
         # scipy's huber acts on z=(f/f_scale)^2 with cost 0.5*f_scale^2*rho(z) -> same objective
         return r
 
-    def fun_total(x):
-        # fold the prior in as extra *non-robust* residuals by pre-inverting huber is not
-        # possible in scipy, so solve the two-term problem by hand: IRLS on top of scipy
-        raise NotImplementedError
-
     # IRLS with scipy's linear loss on reweighted residuals until fixed point
     x = np.concatenate([np.zeros(3), t0])
     for _ in range(30):

@@ -77,6 +77,21 @@ def test_errors(lom, tmp_path):
         f.write(bytes(12 * 3))
     with pytest.raises(lom.LomError):
         lom.loadPCDFile(short)
+    # sizes under the file's control: a record of half a terabyte must come back as an error, not as an exception
+    # escaping the C ABI (which would abort the process)
+    huge = tmp_path / "g.pcd"
+    with open(huge, "wb") as f:
+        f.write(_header(["x", "y", "z", "blob"], [4, 4, 4, 8], list("FFFU"), [1, 1, 1, 1 << 20], 3, "binary").encode())
+        f.write(bytes(64))
+    with pytest.raises(lom.LomError) as e:
+        lom.loadPCDFile(huge)
+    assert "record size" in str(e.value)
+    longline = tmp_path / "h.pcd"
+    with open(longline, "wb") as f:
+        f.write(b"# .PCD v0.7\nFIELDS " + b"x" * 200000 + b"\n")
+    with pytest.raises(lom.LomError) as e:
+        lom.loadPCDFile(longline)
+    assert "too long" in str(e.value)
     nox = tmp_path / "f.pcd"
     nox.write_text(_header(["a", "b"], [4, 4], list("FF"), [1, 1], 1, "ascii") + "1 2\n")
     with pytest.raises(lom.LomError):
