@@ -16,15 +16,21 @@ for c in C3 C4 C5; do
   timeout -k 10 300 python3 "$ROOT/bench.py" --config $c --no-cpu-baseline > "$OUT/bench_${c}_line.json" 2> "$OUT/bench_$c.err"; echo "$c rc=$?"
 done
 # 2. kernel stats of the same commands
-run 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_default" -o kt -- python3 "$ROOT/bench.py" --no-cpu-baseline
+# (the default command itself, extras included: BENCH_rNN.json's numbers -- C2 line, C3 and C5 blocks -- must be reproducible
+#  from this one trace; then each configuration alone)
+run 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_default" -o kt -- python3 "$ROOT/bench.py" --no-cpu-baseline
+run 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_C2only" -o kt -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-extras
 run 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_C5" -o kt -- python3 "$ROOT/bench.py" --config C5 --no-cpu-baseline --steps 200
-run 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_C3" -o kt -- python3 "$ROOT/bench.py" --config C3 --no-cpu-baseline --steps 50
+run 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_C3" -o kt -- python3 "$ROOT/bench.py" --config C3 --no-cpu-baseline --no-extras --steps 50
 # 3. counters, separate passes (short runs: every dispatch is serialised under --pmc)
-B="python3 $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline"
+B="python3 $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras"
 run 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o p -- $B
 run 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o p -- $B
 run 400 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --output-format csv -d "$OUT/pmc_sq" -o p -- $B
 run 400 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum TCP_TCC_ATOMIC_WITH_RET_REQ_sum --output-format csv -d "$OUT/pmc_tcc" -o p -- $B
+B3="python3 $ROOT/bench.py --config C3 --steps 5 --warmup 1 --no-cpu-baseline --no-extras"
+run 400 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --output-format csv -d "$OUT/pmc_sq_c3" -o p -- $B3
+python3 "$ROOT/tools/collect_traffic.py" "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/traffic.json" "${LOM_COMMIT:-?}" > "$OUT/traffic_summary.txt" 2>&1
 # 4. phase stamps of k_lm
 timeout -k 10 120 python3 "$ROOT/tools/lm_debug.py" > "$OUT/lm_stamps.txt" 2>&1; echo "lm_debug rc=$?"
 # summaries
@@ -33,4 +39,8 @@ for k in k_match k_lm k_ins_claim2 k_ins_place2 k_ins_scatter2 k_ins_assign k_in
     python3 "$ROOT/tools/pmc_summary.py" "$OUT/$d" $k >> "$OUT/pmc_summary_$k.txt" 2>/dev/null
   done
 done
+for k in k_match k_lm; do python3 "$ROOT/tools/pmc_summary.py" "$OUT/pmc_sq_c3" $k > "$OUT/pmc_c3_summary_$k.txt" 2>/dev/null; done
+# the raw counter dumps are large: keep the summaries
+rm -rf "$OUT"/pmc_fetch "$OUT"/pmc_write "$OUT"/pmc_sq "$OUT"/pmc_tcc "$OUT"/pmc_sq_c3
+"$ROOT/tools/microbench/policy" > "$OUT/policy_microbench.txt" 2>&1; "$ROOT/tools/microbench/exec_skip" > "$OUT/exec_skip.txt" 2>&1
 find "$OUT" -name "*kernel_stats.csv" | head
