@@ -777,11 +777,30 @@ struct __attribute__((aligned(16))) XWord {
     unsigned long long bits, check;
 };
 
+// The pair travels as ONE 16-byte agent-coherent access each way (sc1: past this XCD's L2).  Nothing relies on the
+// access being indivisible -- a reader that catches half a pair sees check ^ bits != seq and polls again -- it only
+// halves the memory instructions of the exchange (two 8-byte atomics per word each way in round 2).
+typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void xword_store(XWord *dst, double v, unsigned long long seq)
 {
-    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
-    __hip_atomic_store(&dst->bits, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&dst->check, seq ^ b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    u64x2 w;
+    w.x = (unsigned long long)__double_as_longlong(v);
+    w.y = seq ^ w.x;
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(w) : "memory");
+}
+__device__ __forceinline__ void xword_load_issue(const XWord *src, u64x2 &r)  // result valid after xword_load_wait
+{
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(r) : "v"(src) : "memory");
+}
+template <int kN>
+__device__ __forceinline__ void xword_load_wait(u64x2 (&r)[kN])
+{
+    static_assert(kN == 4 || kN == 8, "loads in flight per lane");
+    if constexpr (kN == 4)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3])::"memory");
+    else
+        asm volatile("s_waitcnt vmcnt(0)"
+                     : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7])::"memory");
 }
 
 // a' + b' after v_permlane{32,16}_swap(a, b): lanes of the lower half (of the wave / of each pair of rows) end with
@@ -899,20 +918,19 @@ __device__ __forceinline__ void reduce_and_exchange(const double acc[28], double
         __builtin_amdgcn_s_sleep(16);
         const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
         uint32_t polls = 0;
+        const XWord *mine_src = set + (size_t)(g * kPer) * kRecWords + k;  // (a set holds kMaxLmBlocksBig records: in bounds)
         for (;;) {
-            unsigned long long cb[kPer];
+            u64x2 r[kPer];
 #pragma unroll
-            for (int u = 0; u < kPer; u++) {
-                if (!ok[u]) {
-                    const XWord *w = set + (size_t)(g * kPer + u) * kRecWords + k;
-                    vb[u] = __hip_atomic_load(&w->bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    cb[u] = __hip_atomic_load(&w->check, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
+            for (int u = 0; u < kPer; u++) xword_load_issue(mine_src + (size_t)u * kRecWords, r[u]);
+            xword_load_wait(r);
             bool all = true;
 #pragma unroll
             for (int u = 0; u < kPer; u++) {
-                if (!ok[u]) ok[u] = (cb[u] ^ vb[u]) == seq;
+                if (!ok[u]) {
+                    vb[u] = r[u].x;
+                    ok[u] = (r[u].y ^ r[u].x) == seq;
+                }
                 all = all && ok[u];
             }
             if (all) break;
