@@ -200,7 +200,7 @@ struct lom_map {
     uint32_t words_tag = 0;
     int words_pending = 0;  // words of a lom_map_read_device_words_begin not yet collected
     unsigned long long report_seq = 0, lm_seq = 0, lm_launches = 0;
-    uint32_t lm_max_blocks[3] = {0, 0, 0};  // co-resident k_lm workgroups this device admits, per variant (occupancy query, cached)
+    uint32_t lm_max_blocks[4] = {0, 0, 0, 0};  // co-resident k_lm workgroups this device admits, per variant (occupancy query, cached)
     double last_counters[4] = {0, 0, 0, 0};  // valid, cand, occ, queries of the last k_match
 
     bool profiling = false;       // this align carries event pairs

@@ -533,10 +533,18 @@ constexpr int kPairsAhead = 5;  // (k_match, k_lm) pairs enqueued before the hos
 constexpr uint32_t kMaxLmBlocks = 64;    // workgroups of k_lm (one lane of a wave watches each record)
 constexpr uint32_t kMaxLmBlocksBig = 128;  // ... of its variant for large clouds; also the size of an exchange set
 
-// cloud_matcher.cpp:48-102 for one correspondence, accumulated into the 28 sums
-__device__ __forceinline__ void accumulate_point(const float4 ra, const float4 rb, const float4 rc,
-                                                 const double q0, const double q1, const double q2, const double q3,
-                                                 const double t0, const double t1, const double t2, double acc[28])
+// The f64 residual / Jacobian arithmetic below contracts a * b + c to one FMA (the library is built with
+// -ffp-contract=off for the f32 index and distance expressions of the search, which must round like the reference's
+// x86 build; these f64 sums are compared with the oracle's to 1e-12 of their scale, not bit for bit, and the order of
+// the additions across points differs from any CPU's anyway): a third fewer instructions per point.
+#pragma clang fp contract(fast)
+struct PointTerms {
+    double J[6], r;
+};
+// cloud_matcher.cpp:48-98 for one correspondence: residual and 1x6 tangent Jacobian
+__device__ __forceinline__ void point_terms(const float4 ra, const float4 rb, const float4 rc, const double q0,
+                                            const double q1, const double q2, const double q3, const double t0,
+                                            const double t1, const double t2, PointTerms &T)
 {
     const double p[3] = {(double)ra.x, (double)ra.y, (double)ra.z};
     const double o[3] = {(double)rb.x, (double)rb.y, (double)rb.z};
@@ -552,7 +560,7 @@ __device__ __forceinline__ void accumulate_point(const float4 ra, const float4 r
     const double rp1 = (p[1] + q0 * uv1) + (q3 * uv0 - q1 * uv2);
     const double rp2 = (p[2] + q0 * uv2) + (q1 * uv1 - q2 * uv0);
     const double e0 = rp0 + t0 - o[0], e1 = rp1 + t1 - o[1], e2 = rp2 + t2 - o[2];
-    const double r = e0 * nn[0] + (e1 * nn[1] + e2 * nn[2]);
+    T.r = e0 * nn[0] + (e1 * nn[1] + e2 * nn[2]);
     // cloud_matcher.cpp:64-91: ambient d r / d q_i = (dR/dq_i p).n
     double v0, v1, v2, ja[4];
     v0 = 2.0 * q0 * p[0] + 2.0 * -q3 * p[1] + 2.0 * q2 * p[2];
@@ -572,15 +580,17 @@ __device__ __forceinline__ void accumulate_point(const float4 ra, const float4 r
     v2 = 2.0 * q1 * p[0] + 2.0 * q2 * p[1] + 2.0 * q3 * p[2];
     ja[3] = v0 * nn[0] + (v1 * nn[1] + v2 * nn[2]);
     // Ceres QuaternionManifold plus-Jacobian (4x3): ambient -> tangent
-    double J[6];
-    J[0] = ja[0] * -q1 + ja[1] * q0 + ja[2] * -q3 + ja[3] * q2;
-    J[1] = ja[0] * -q2 + ja[1] * q3 + ja[2] * q0 + ja[3] * -q1;
-    J[2] = ja[0] * -q3 + ja[1] * -q2 + ja[2] * q1 + ja[3] * q0;
-    J[3] = nn[0];  // cloud_matcher.cpp:96-98
-    J[4] = nn[1];
-    J[5] = nn[2];
-    // ceres::HuberLoss(0.15) (cloud_matcher.cpp:134); rho'' <= 0 -> plain IRLS weight rho'
-    const double s = r * r;
+    T.J[0] = ja[0] * -q1 + ja[1] * q0 + ja[2] * -q3 + ja[3] * q2;
+    T.J[1] = ja[0] * -q2 + ja[1] * q3 + ja[2] * q0 + ja[3] * -q1;
+    T.J[2] = ja[0] * -q3 + ja[1] * -q2 + ja[2] * q1 + ja[3] * q0;
+    T.J[3] = nn[0];  // cloud_matcher.cpp:96-98
+    T.J[4] = nn[1];
+    T.J[5] = nn[2];
+}
+// ceres::HuberLoss(0.15) (cloud_matcher.cpp:134); rho'' <= 0 -> plain IRLS weight rho'; then the 28 sums
+__device__ __forceinline__ void point_accumulate(const PointTerms &T, double acc[28])
+{
+    const double r = T.r, s = r * r;
     double rho0 = s, w = 1.0;
     if (s > 0.15 * 0.15) {
         const double rr = sqrt(s);
@@ -590,14 +600,24 @@ __device__ __forceinline__ void accumulate_point(const float4 ra, const float4 r
     int k = 0;
 #pragma unroll
     for (int a = 0; a < 6; a++) {
-        const double wa = w * J[a];
+        const double wa = w * T.J[a];
 #pragma unroll
-        for (int b = a; b < 6; b++) acc[k++] += wa * J[b];
+        for (int b = a; b < 6; b++) acc[k++] += wa * T.J[b];
     }
 #pragma unroll
-    for (int a = 0; a < 6; a++) acc[21 + a] += w * J[a] * r;
+    for (int a = 0; a < 6; a++) acc[21 + a] += w * T.J[a] * r;
     acc[27] += 0.5 * rho0;
 }
+// cloud_matcher.cpp:48-102 for one correspondence, accumulated into the 28 sums
+__device__ __forceinline__ void accumulate_point(const float4 ra, const float4 rb, const float4 rc,
+                                                 const double q0, const double q1, const double q2, const double q3,
+                                                 const double t0, const double t1, const double t2, double acc[28])
+{
+    PointTerms T;
+    point_terms(ra, rb, rc, q0, q1, q2, q3, t0, t1, t2, T);
+    point_accumulate(T, acc);
+}
+#pragma clang fp contract(off)
 
 // Workgroup reduction of the 28 per-lane sums through LDS in a fixed order, plus the
 // workgroup's slice of k_match's counters; one wave then writes the 256-byte record.
@@ -1123,22 +1143,32 @@ struct LmInit {
     float max_sq;       // max_correspondence_distance^2 of the searches (:139, voxel_grid.h:215)
 };
 
+// kRegPts: this lane's first points (first, first + step, ...) stay in registers for every evaluation of the solve
+template <int kRegPts>
 __device__ __forceinline__ void accumulate_all(const MatchRec *__restrict__ rec, uint32_t n, uint32_t first,
-                                               uint32_t step, const float4 ra, const float4 rb, const float4 rc,
-                                               const double *x, double acc[28])
+                                               uint32_t step, const float4 (&ra)[kRegPts], const float4 (&rb)[kRegPts],
+                                               const float4 (&rc)[kRegPts], const double *x, double acc[28])
 {
     const double q0 = x[0], q1 = x[1], q2 = x[2], q3 = x[3], t0 = x[4], t1 = x[5], t2 = x[6];
 #pragma unroll
     for (int k = 0; k < 28; k++) acc[k] = 0.0;
-    if (ra.w != 0.f) accumulate_point(ra, rb, rc, q0, q1, q2, q3, t0, t1, t2, acc);
-    for (uint32_t i = first + step; i < n; i += step) {
+    // The register points go through unconditionally and stage by stage -- residuals and Jacobians of all of them, then
+    // their sums -- so that the scheduler interleaves the independent chains (a wave alone on its SIMD issues a dependent
+    // instruction every ~9 cycles, independent ones every ~5).  A lane without a match, or beyond the cloud, holds a zero
+    // normal: every term it adds is exactly zero.
+    PointTerms T[kRegPts];
+#pragma unroll
+    for (int p = 0; p < kRegPts; p++) point_terms(ra[p], rb[p], rc[p], q0, q1, q2, q3, t0, t1, t2, T[p]);
+#pragma unroll
+    for (int p = 0; p < kRegPts; p++) point_accumulate(T[p], acc);
+    for (uint32_t i = first + (uint32_t)kRegPts * step; i < n; i += step) {
         const float4 *r4 = reinterpret_cast<const float4 *>(rec + i);
         const float4 xa = r4[0], xb = r4[1], xc = r4[2];
         if (xa.w != 0.f) accumulate_point(xa, xb, xc, q0, q1, q2, q3, t0, t1, t2, acc);
     }
 }
 
-template <int kT, int kBlocks = (int)kMaxLmBlocks>
+template <int kT, int kBlocks = (int)kMaxLmBlocks, int kRegPts = 1>
 __global__ __launch_bounds__(kT) void k_lm(const MatchRec *__restrict__ rec, uint32_t n, AlignState *state,
                                                      LmInit init, int first_outer,
                                                      const uint32_t *__restrict__ block_counters,
@@ -1161,12 +1191,17 @@ __global__ __launch_bounds__(kT) void k_lm(const MatchRec *__restrict__ rec, uin
     const uint32_t first = blockIdx.x * blockDim.x + tid, step = nb * blockDim.x;
     // start-up loads issued together (one memory round trip, not three): this lane's first point --
     // it stays in registers for every evaluation of the solve --, the pose, the chain's stop flags
-    float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra, rc = ra;
-    if (first < n) {
-        const float4 *r4 = reinterpret_cast<const float4 *>(rec + first);
-        ra = r4[0];
-        rb = r4[1];
-        rc = r4[2];
+    float4 ra[kRegPts], rb[kRegPts], rc[kRegPts];
+#pragma unroll
+    for (int p = 0; p < kRegPts; p++) {
+        ra[p] = rb[p] = rc[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const uint32_t i = first + (uint32_t)p * step;
+        if (i < n) {
+            const float4 *r4 = reinterpret_cast<const float4 *>(rec + i);
+            ra[p] = r4[0];
+            rb[p] = r4[1];
+            rc[p] = r4[2];
+        }
     }
     float x0 = 0.f;
     if (tid < 7) {
@@ -1193,7 +1228,7 @@ __global__ __launch_bounds__(kT) void k_lm(const MatchRec *__restrict__ rec, uin
     for (int ev = 0; action == LM_EVAL; ev++) {
         double acc[28];
         LM_STAMP(0);
-        accumulate_all(rec, n, first, step, ra, rb, rc, s_x, acc);
+        accumulate_all<kRegPts>(rec, n, first, step, ra, rb, rc, s_x, acc);
         LM_STAMP(1);
         seq++;
         XWord *set = xrec + (size_t)(seq & 1) * kMaxLmBlocksBig * kRecWords;
@@ -1646,16 +1681,21 @@ constexpr int kDeviceLoopGaveUp = 100;
 
 // k_lm's workgroups wait for each other inside the kernel, so all of them must be resident at once:
 // the grid never exceeds what the occupancy query admits on this device.
-// Workgroup size: 512 threads, or 256 for clouds that 64 such workgroups cover (one point per lane either way):
+// Workgroup size: 256 threads for clouds that 64 such workgroups cover with one point per lane (<= 16,384 points) or
+// with TWO points per lane, both in registers for the whole solve (<= 32,768: the VLP16 scan of C2), else 512:
 // the wave-level reduction is bound by the CU's f64 issue rate, and four waves -- one per SIMD -- are through it
-// in half the time of eight; the final sum adds 8 partial sums instead of 16.
+// in half the time of eight; the final sum adds 8 partial sums instead of 16; two register points per lane are
+// accumulated stage by stage so that their independent chains interleave (1.4k cycles for the two against 0.95k for
+// one).  C2 (profiles/r03_*): k_lm 18.9 -> 17.8 us per launch against 512 threads with one point per lane; eight
+// points per lane (C3 on 64 workgroups of 256) lose: 24.4-25.5 against 22.4 us.
 // Clouds beyond what 64 workgroups of 512 cover with two points per lane (C3, C4 on one GPU) take up to 128 workgroups:
 // the accumulation halves, the gather reads twice as many records (on C2-sized clouds that trade loses).
 constexpr uint32_t kLmSmallThreads = 256;
-enum LmShape { kLmSmall = 0, kLmMid = 1, kLmBig = 2 };
+enum LmShape { kLmSmall = 0, kLmMid = 1, kLmBig = 2, kLmSmall2 = 3 };
 static LmShape lm_shape(uint32_t n)
 {
     if (n <= kMaxLmBlocks * kLmSmallThreads) return kLmSmall;
+    if (n <= 2u * kMaxLmBlocks * kLmSmallThreads) return kLmSmall2;  // 256 threads, two points per lane in registers
     return n <= 2u * kMaxLmBlocks * (uint32_t)kEvalThreads ? kLmMid : kLmBig;
 }
 
@@ -1667,6 +1707,11 @@ static int lm_block_limit(lom_map *m, LmShape shape, uint32_t *out)
         if (shape == kLmSmall)
             LOM_HIP(m, hipOccupancyMaxActiveBlocksPerMultiprocessor(
                            &per_cu, reinterpret_cast<const void *>(k_lm<(int)kLmSmallThreads>), (int)kLmSmallThreads, 0));
+        else if (shape == kLmSmall2)
+            LOM_HIP(m, hipOccupancyMaxActiveBlocksPerMultiprocessor(
+                           &per_cu, reinterpret_cast<const void *>(k_lm<(int)kLmSmallThreads, (int)kMaxLmBlocks, 2>),
+                           (int)kLmSmallThreads, 0));
+
         else if (shape == kLmMid)
             LOM_HIP(m, hipOccupancyMaxActiveBlocksPerMultiprocessor(
                            &per_cu, reinterpret_cast<const void *>(k_lm<kEvalThreads>), kEvalThreads, 0));
@@ -1712,8 +1757,9 @@ static int align_chained(lom_map *m, const char *d_src, size_t n, size_t stride,
     uint32_t nb_limit = 0;
     // ranks of one node keep to 64 workgroups each: a shard is an eighth of the cloud, and ranks that share a GPU
     // (tests, rehearsals) must all be resident together
-    const LmShape shape = m->p2p ? std::min(lm_shape(c.n), kLmMid) : lm_shape(c.n);
-    const uint32_t lm_threads = shape == kLmSmall ? kLmSmallThreads : (uint32_t)kEvalThreads;
+    LmShape shape = lm_shape(c.n);
+    if (m->p2p && shape == kLmBig) shape = kLmMid;
+    const uint32_t lm_threads = (shape == kLmSmall || shape == kLmSmall2) ? kLmSmallThreads : (uint32_t)kEvalThreads;
     if ((rc = lm_block_limit(m, shape, &nb_limit)) != LOM_OK) return rc;
     const uint32_t nb = std::min(std::min(std::max(1u, (c.n + lm_threads - 1) / lm_threads),
                                           shape == kLmBig ? kMaxLmBlocksBig : kMaxLmBlocks),
@@ -1756,6 +1802,9 @@ static int align_chained(lom_map *m, const char *d_src, size_t n, size_t stride,
         };
         if (shape == kLmSmall)
             launch(k_lm<(int)kLmSmallThreads>);
+        else if (shape == kLmSmall2)
+            launch(k_lm<(int)kLmSmallThreads, (int)kMaxLmBlocks, 2>);
+
         else if (shape == kLmMid)
             launch(k_lm<kEvalThreads>);
         else

@@ -13,8 +13,10 @@ import lidar_odometry_demo_amd as lom  # noqa: E402
 from lidar_odometry_demo_amd import synth  # noqa: E402
 
 boxes = synth.make_boxes()
-scan, _, _, _ = synth.make_scan(16, 1800, boxes=boxes)
-mp, mn = synth.make_map_points(500_000, boxes=boxes)
+cfg = sys.argv[1] if len(sys.argv) > 1 else "C2"
+nb, naz, nmap = {"C2": (16, 1800, 500_000), "C3": (64, 2048, 2_000_000), "C4": (128, 2048, 2_000_000)}[cfg]
+scan, _, _, _ = synth.make_scan(nb, naz, boxes=boxes)
+mp, mn = synth.make_map_points(nmap, boxes=boxes)
 g = lom.VoxelGrid(0.5, 20)
 g.addCloud(mp, mn)
 m = lom.CloudMatcher()
