@@ -12,7 +12,7 @@
 namespace lom {
 
 // ---- open-addressed voxel hash in HBM ---------------------------------------
-// One 16-byte slot per probe: a single dwordx4 load yields key, point count
+// One 16-byte slot per voxel: a single dwordx4 load yields key, point count
 // and payload slab (reference: robin_map<Indices, VoxelWithPlanes>,
 // src/voxel_grid.h:256).  Payload lives in slabs [slab][K] of packed 12-byte
 // points and, separately, 12-byte normals (normals are read once per query,
@@ -36,11 +36,27 @@ __host__ __device__ inline unsigned long long pack_key(int ix, int iy, int iz)
            (unsigned long long)(uint32_t)(iz + kIdxBias);
 }
 
-// Fibonacci hashing: top log2(cap) bits of key * 2^64/phi.  The hash never
-// influences results (reference IndicesHash, voxel_grid.h:31-38, likewise).
+// Locality-preserving hash: the 2x2x2 block of voxels that share (ix >> 1, iy >> 1, iz >> 1) -- a "brick" -- lives
+// in ONE 128-byte bucket of eight slots, so the 27 neighbours of a query (always 2x2x2 bricks) are found in eight
+// cache lines instead of 27.  Bucket = xor of three per-axis Fibonacci hashes of the brick coordinate (each axis's
+// part depends on that axis alone: k_match computes three parts per axis and query, not one hash per neighbour);
+// home slot inside the bucket = the three parity bits; on a collision kProbeStep slots further: the next bucket AND
+// the next slot inside it (stepping inside the bucket, or always to the same slot of the next, makes chains several
+// times longer: bricks of one surface occupy the same parity pattern).  Works on the biased fields of the packed key (the bias is even: parity and brick
+// grouping are those of the index).  The hash never influences results (reference IndicesHash, voxel_grid.h:31-38,
+// likewise).  shift = 64 - log2(capacity), capacity >= 1024.
+constexpr uint32_t kProbeStep = 9;
+constexpr uint32_t kAxisMul[3] = {0x9E3779B1u, 0x85EBCA77u, 0xC2B2AE3Du};
+__host__ __device__ inline uint32_t axis_hash_part(uint32_t biased_index, uint32_t mul, uint32_t parity_bit, uint32_t shift)
+{
+    return ((((biased_index >> 1) * mul) >> (shift - 29u)) << 3) | ((biased_index & 1u) << parity_bit);
+}
 __host__ __device__ inline uint32_t hash_key(unsigned long long key, uint32_t shift)
 {
-    return (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> shift);
+    const uint32_t ux = (uint32_t)(key >> 42) & 0x1FFFFFu, uy = (uint32_t)(key >> 21) & 0x1FFFFFu,
+                   uz = (uint32_t)key & 0x1FFFFFu;
+    return axis_hash_part(ux, kAxisMul[0], 2, shift) ^ axis_hash_part(uy, kAxisMul[1], 1, shift) ^
+           axis_hash_part(uz, kAxisMul[2], 0, shift);
 }
 
 // voxel_grid.h:70-72 / :166-168: static_cast<int64_t>(x / voxel_size_), f32

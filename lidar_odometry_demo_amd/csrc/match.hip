@@ -39,6 +39,7 @@ namespace lom {
 
 constexpr int kMatchThreads = 256;             // 4 waves
 constexpr int kMatchG = 16;                    // lanes per query: four queries per wave
+constexpr int kMatchRows = 4;                  // consecutive rows of a voxel per chunk: one search and 48 bytes per lane and trip
 constexpr int kGroupsPerBlock = kMatchThreads / kMatchG;
 constexpr int kMatchMinWaves = 7;              // waves per SIMD the register budget is held to (72 VGPRs)
 constexpr int kEvalThreads = 512;
@@ -64,17 +65,18 @@ struct __attribute__((aligned(8))) QStat {
 // k_match<G>: one query per group of G lanes (G = 16: four queries per wave).
 //
 //  1. probe    lane l takes neighbours b = l, l+G, ... < 27 in the reference's scan
-//              order ix, iy, iz (voxel_grid.h:175-179): one 16-byte slot load each.
+//              order ix, iy, iz (voxel_grid.h:175-179): one 16-byte slot load each.  The slot
+//              hash keeps a 2x2x2 brick of voxels in one 128-byte line (lom_internal.hpp):
+//              the 27 slots of a query lie in eight lines.
 //  2. prune    a neighbour voxel whose nearest possible coordinate is provably
 //              farther than max_dist cannot hold a point with d2 < max_sq
 //              (voxel_grid.h:186), so its points are not read.  Exact: such points
 //              never win in the reference either.  Counts stay the reference's.
-//  3. flatten  the remaining voxels' points form one candidate sequence in scan
-//              order (inclusive prefix of the counts in LDS); lane l takes
-//              candidates l, l+G, ... and finds each one's voxel by a 5-step
-//              binary search; a lane's kP candidates of a trip have their loads in
-//              flight together (issued by one asm block: left to the compiler, the
-//              first use of load 1 was scheduled ahead of the address of load 2).
+//  3. flatten  the remaining voxels' points, cut into chunks of up to four consecutive
+//              rows of one voxel, form one chunk sequence in scan order (inclusive prefix
+//              of the chunk counts in LDS); lane l takes chunks l, l+G, ... and finds each
+//              one's voxel by a 5-step binary search -- one search, one address and 48 bytes
+//              in flight (three dwordx4) per four candidates.
 //  4. select   private strict minimum per lane (candidates arrive in scan order),
 //              then the lexicographic minimum of (sq_dist, candidate ordinal) over
 //              the group == "first encountered wins" of voxel_grid.h:183-191.
@@ -161,11 +163,31 @@ __device__ __forceinline__ u32x4 load_slot(const Slot *a)
     return r;
 }
 
-// A lane's two candidate points of a trip as two 12-byte loads issued back to back and waited for together.
-// Left to the compiler, the first use of load 1 was scheduled ahead of the address computation of load 2: the
-// "two loads in flight" of round 2 were two dependent round trips (C2 / C3 / C4: 7.9 / 29.9 / 53.7 us; with this
-// block 6.8 / 28.1 / 47.7 us, profiles/r03_*).
 typedef float f32x3 __attribute__((ext_vector_type(3)));
+// Four consecutive 12-byte rows = 48 bytes from one address as three 16-byte loads in flight together.  What the
+// vector L1 charges a load instruction is, per four consecutive lanes, the 128-byte lines they touch
+// (tools/microbench/tcp_lines.hip): three instructions over a lane's 48 bytes cost 3/4 of what four 12-byte loads do.
+// The address is a multiple of 4, not of 16 unless K % 4 == 0: global_load_dwordx4 takes that on gfx950 (the driver
+// runs the memory pipeline in unaligned mode; tools/microbench/unaligned_x4.hip checks it).
+__device__ __forceinline__ void load_chunk48(const float *a, f32x3 (&r)[4])
+{
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    f32x4 v0, v1, v2;
+    asm volatile("global_load_dwordx4 %0, %3, off\n\tglobal_load_dwordx4 %1, %3, off offset:16\n\t"
+                 "global_load_dwordx4 %2, %3, off offset:32\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(v0), "=&v"(v1), "=&v"(v2)
+                 : "v"(a)
+                 : "memory");
+    r[0] = f32x3{v0.x, v0.y, v0.z};
+    r[1] = f32x3{v0.w, v1.x, v1.y};
+    r[2] = f32x3{v1.z, v1.w, v2.x};
+    r[3] = f32x3{v2.y, v2.z, v2.w};
+}
+
+// Two 12-byte loads issued back to back and waited for together (the winner's point and normal).  The loads of a
+// trip are asm blocks because, left to the compiler, the first use of load 1 was scheduled ahead of the address
+// computation of load 2: the "two loads in flight" of round 2 were two dependent round trips (C2 / C3 / C4: 7.9 / 29.9
+// / 53.7 us; issued together 6.8 / 28.1 / 47.7 us, profiles/r03_b_*).
 __device__ __forceinline__ void load_points2(const float *a, const float *b, f32x3 &ra, f32x3 &rb)
 {
     asm volatile("global_load_dwordx3 %0, %2, off\n\tglobal_load_dwordx3 %1, %3, off\n\ts_waitcnt vmcnt(0)"
@@ -215,8 +237,7 @@ __global__ __launch_bounds__(kMatchThreads, kMinWaves) void k_match(MapView map,
                                                          unsigned long long *__restrict__ stamps = nullptr,
                                                          const AlignState *state = nullptr)
 {
-    static_assert(G == 16 && kU == 2, "one query per 16-lane DPP row, two candidates per lane and trip");
-    constexpr int kP = kU;
+    static_assert(G == 16 && kU == 4, "one query per 16-lane DPP row, a chunk of four rows per lane and trip");
     struct {
         double R[9], t[3];
         float max_sq;
@@ -241,12 +262,14 @@ __global__ __launch_bounds__(kMatchThreads, kMinWaves) void k_match(MapView map,
     LOM_STAMP(0);
     constexpr int kGroups = kMatchThreads / G;
     constexpr int kSets = 2;                  // neighbours b = gl (set 0) and 16 + gl (set 1) < 27
-    // per neighbour b in scan order: .x inclusive prefix of the scanned counts (entries >= 27: never reached),
-    // .y slab * K - exclusive prefix, so that candidate c of the flattened sequence is point .y + c
-    __shared__ uint2 s_pb[kGroups][32];
+    // per neighbour b in scan order: .z inclusive prefix of the scanned CHUNKS (entries >= 27: never reached),
+    // .x slab * K - 4 * exclusive prefix, so that chunk ch of the flattened sequence starts at row .x + 4 * ch,
+    // .y count + 4 * exclusive prefix: .y - 4 * ch rows of the voxel remain from there
+    __shared__ uint4 s_pb[kGroups][32];
     __shared__ uint32_t s_cnt[kGroups][4];
     __shared__ double s_pose[12];             // [component][R row (3), t]: what the component lanes multiply with
-    __shared__ float s_gap[kGroups][12];      // per query [axis][to voxel i-1, 0, to voxel i+1]: squared pruning gaps
+    // per query [axis][neighbour index i-1, i, i+1]: .x squared pruning gap (bits), .y that index's part of the slot hash
+    __shared__ uint2 s_ax[kGroups][12];
     const int gl = threadIdx.x % G;
     const int grp = threadIdx.x / G;
     const uint32_t groups_total = gridDim.x * kGroups;
@@ -263,7 +286,6 @@ __global__ __launch_bounds__(kMatchThreads, kMinWaves) void k_match(MapView map,
                 if (c == cc && k == kk) v = kk < 3 ? P.R[cc * 3 + kk] : P.t[cc];
         s_pose[threadIdx.x] = v;
     }
-    if (gl < 3) s_gap[grp][gl * 3 + 1] = 0.f;  // the centre column of the gap table never changes
     __syncthreads();
     const float prune_sq = P.max_sq * 1.0001f;
     // Work that is the same for the 16 lanes of a query is split over them instead of repeated by each: lanes
@@ -272,22 +294,21 @@ __global__ __launch_bounds__(kMatchThreads, kMinWaves) void k_match(MapView map,
     // gap table through 12 LDS words.  Lanes 3..15 repeat component z (same instruction stream, results unused).
     const int comp = gl < 2 ? gl : 2;
     const double *my_pose = s_pose + comp * 4;
-    // this lane's two neighbours (scan order ix, iy, iz): key and hash of a neighbour follow from the centre's
-    // by ADDING a lane constant -- pack_key is a sum of shifted fields, and the Fibonacci hash multiplies by a
-    // constant modulo 2^64, so hash(key0 + d) = (key0 * phi + d * phi) >> shift.  One 64-bit multiply per query
-    // instead of two, no per-neighbour packing.
-    constexpr unsigned long long kPhi = 0x9E3779B97F4A7C15ull;
-    unsigned long long dkey[kSets], dprod[kSets];
-    const float *gap_x[kSets], *gap_y[kSets], *gap_z[kSets];
+    const uint32_t my_mul = comp == 0 ? kAxisMul[0] : comp == 1 ? kAxisMul[1] : kAxisMul[2];
+    const uint32_t my_parity_bit = 2u - (uint32_t)comp;
+    // this lane's two neighbours (scan order ix, iy, iz): the key of a neighbour follows from the centre's by ADDING a
+    // lane constant (pack_key is a sum of shifted fields); its home slot is the xor of three per-axis parts
+    // (lom_internal.hpp, hash_key) that the component lanes leave in LDS next to the pruning gaps.
+    unsigned long long dkey[kSets];
+    const uint2 *ax_x[kSets], *ax_y[kSets], *ax_z[kSets];
 #pragma unroll
     for (int s = 0; s < kSets; s++) {
         const int b = gl + s * G;
         const int dx = b / 9 - 1, dy = (b / 3) % 3 - 1, dz = b % 3 - 1;
         dkey[s] = (unsigned long long)(((long long)dx << 42) + ((long long)dy << 21) + (long long)dz);
-        dprod[s] = dkey[s] * kPhi;
-        gap_x[s] = &s_gap[grp][0 + (b < 27 ? dx + 1 : 1)];
-        gap_y[s] = &s_gap[grp][3 + (b < 27 ? dy + 1 : 1)];
-        gap_z[s] = &s_gap[grp][6 + (b < 27 ? dz + 1 : 1)];
+        ax_x[s] = &s_ax[grp][0 + (b < 27 ? dx + 1 : 1)];
+        ax_y[s] = &s_ax[grp][3 + (b < 27 ? dy + 1 : 1)];
+        ax_z[s] = &s_ax[grp][6 + (b < 27 ? dz + 1 : 1)];
     }
 
     for (uint32_t q = blockIdx.x * kGroups + grp; q < n; q += groups_total) {
@@ -301,8 +322,10 @@ __global__ __launch_bounds__(kMatchThreads, kMinWaves) void k_match(MapView map,
         float gm2, gp2;
         axis_gaps(qc, ic, map.voxel_size, gm2, gp2);
         if (gl < 3) {
-            s_gap[grp][gl * 3 + 0] = gm2;
-            s_gap[grp][gl * 3 + 2] = gp2;
+            const uint32_t u = (uint32_t)(ic + kIdxBias);  // biased index of this axis (garbage if !okc: not used then)
+            s_ax[grp][gl * 3 + 0] = make_uint2(__float_as_uint(gm2), axis_hash_part(u - 1u, my_mul, my_parity_bit, map.shift));
+            s_ax[grp][gl * 3 + 1] = make_uint2(0u, axis_hash_part(u, my_mul, my_parity_bit, map.shift));
+            s_ax[grp][gl * 3 + 2] = make_uint2(__float_as_uint(gp2), axis_hash_part(u + 1u, my_mul, my_parity_bit, map.shift));
         }
         const int icc = okc ? ic : (int)0x80000000;  // out of range / not finite
         const float qx = __uint_as_float(row_lane<0>(__float_as_uint(qc)));
@@ -321,7 +344,6 @@ __global__ __launch_bounds__(kMatchThreads, kMinWaves) void k_match(MapView map,
         const bool safe = (uint32_t)(ix + (kIdxBias - 2)) < kInner && (uint32_t)(iy + (kIdxBias - 2)) < kInner &&
                           (uint32_t)(iz + (kIdxBias - 2)) < kInner;
         const unsigned long long key0 = inr ? pack_key(ix, iy, iz) : 0ull;
-        const unsigned long long prod0 = key0 * kPhi;
         unsigned long long key[kSets];
         uint32_t h[kSets];
         bool act[kSets];
@@ -336,8 +358,9 @@ __global__ __launch_bounds__(kMatchThreads, kMinWaves) void k_match(MapView map,
                          nz < kIdxBias;
             }
             key[s] = act[s] ? key0 + dkey[s] : 0ull;
-            h[s] = act[s] ? ((uint32_t)((prod0 + dprod[s]) >> map.shift) & map.mask) : 0u;
-            lower[s] = *gap_x[s] + (*gap_y[s] + *gap_z[s]);
+            const uint2 ex = *ax_x[s], ey = *ax_y[s], ez = *ax_z[s];
+            h[s] = act[s] ? ((ex.y ^ ey.y ^ ez.y) & map.mask) : 0u;
+            lower[s] = __uint_as_float(ex.x) + (__uint_as_float(ey.x) + __uint_as_float(ez.x));
         }
         u32x4 raw[kSets];
         load_slots2(map.table + h[0], map.table + h[1], raw[0], raw[1]);
@@ -357,7 +380,7 @@ __global__ __launch_bounds__(kMatchThreads, kMinWaves) void k_match(MapView map,
                         break;
                     }
                     if (k == kEmptyKey) break;
-                    hh = (hh + 1) & map.mask;
+                    hh = (hh + kProbeStep) & map.mask;
                     r = load_slot(map.table + hh);
                 }
             }
@@ -369,72 +392,74 @@ __global__ __launch_bounds__(kMatchThreads, kMinWaves) void k_match(MapView map,
         // occupied voxels (<= 27) above bit 26, stored points (<= 27 K, K < 2^16) below: one row sum for both sets
         const uint32_t tot = row_sum((cnt[0] + cnt[1]) | (((cnt[0] ? 1u : 0u) + (cnt[1] ? 1u : 0u)) << 26));
         const uint32_t n_cand = tot & ((1u << 26) - 1u), n_occ = tot >> 26;
-        float best = INFINITY, bpx = 0.f, bpy = 0.f, bpz = 0.f;
-        uint32_t best_c = 0xFFFFFFFFu, best_idx = 0;
-        uint32_t T;  // points actually read
+        // best starts at max_sq: "d2 < best" then implies voxel_grid.h:186's d2 < max_sq, and NaN never wins
+        float best = P.max_sq;
+        uint32_t best_c = 0xFFFFFFFFu, best_pi0 = 0;
         {
-            // both sets' counts in one register (16 voxels x K < 2^16 each): ONE row scan, one broadcast
-            uint32_t run0 = 0;
-            if (map.K <= 2048u) {
-                const uint32_t inc = row_scan_inclusive(scan_cnt[0] | (scan_cnt[1] << 16));
+            // chunks of up to four consecutive points of one voxel: nch chunks per scanned voxel.  Both sets'
+            // chunk counts in one register (16 voxels x K / 4 < 2^16 each): ONE row scan, one broadcast
+            uint32_t nch[kSets];
+#pragma unroll
+            for (int s = 0; s < kSets; s++) nch[s] = (scan_cnt[s] + 3u) >> 2;
+            atomicAdd(&s_cnt[grp][3], scan_cnt[0] + scan_cnt[1]);  // points actually read (after the exact pruning)
+            uint32_t Tc;  // chunks of this query
+            if (map.K <= 16380u) {
+                const uint32_t inc = row_scan_inclusive(nch[0] | (nch[1] << 16));
                 const uint32_t last = row_last(inc);
                 const uint32_t tot0 = last & 0xFFFFu, inc0 = inc & 0xFFFFu, inc1 = tot0 + (inc >> 16);
-                s_pb[grp][gl] = make_uint2(inc0, slab[0] * map.K - (inc0 - scan_cnt[0]));
-                s_pb[grp][gl + G] = make_uint2((gl + G < 27) ? inc1 : 0xFFFFFFFFu, slab[1] * map.K - (inc1 - scan_cnt[1]));
-                T = tot0 + (last >> 16);
+                const uint32_t ex0 = (inc0 - nch[0]) << 2, ex1 = (inc1 - nch[1]) << 2;
+                s_pb[grp][gl] = make_uint4(slab[0] * map.K - ex0, scan_cnt[0] + ex0, inc0, 0u);
+                s_pb[grp][gl + G] =
+                    make_uint4(slab[1] * map.K - ex1, scan_cnt[1] + ex1, (gl + G < 27) ? inc1 : 0xFFFFFFFFu, 0u);
+                Tc = tot0 + (last >> 16);
             } else {
+                uint32_t run0 = 0;
 #pragma unroll
                 for (int s = 0; s < kSets; s++) {
-                    const uint32_t inc = row_scan_inclusive(scan_cnt[s]);
+                    const uint32_t inc = row_scan_inclusive(nch[s]);
                     const int b = gl + s * G;
-                    s_pb[grp][b] = make_uint2((b < 27) ? run0 + inc : 0xFFFFFFFFu, slab[s] * map.K - (run0 + inc - scan_cnt[s]));
+                    const uint32_t ex = (run0 + inc - nch[s]) << 2;
+                    s_pb[grp][b] = make_uint4(slab[s] * map.K - ex, scan_cnt[s] + ex, (b < 27) ? run0 + inc : 0xFFFFFFFFu, 0u);
                     run0 += row_last(inc);
                 }
-                T = run0;
+                Tc = run0;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             LOM_STAMP(3);  // prefix in LDS
-            // Binary search of a candidate's voxel: the first two of its five levels compare with three values read once
-            // per query, the last reads the entry and its successor's base together -- three dependent LDS round trips
-            // per candidate instead of six.
-            const uint2 *pb = s_pb[grp];
-            const uint32_t p7 = pb[7].x, p15 = pb[15].x, p23 = pb[23].x;
-            // lane l takes candidates l, l + 16, ... of the flattened sequence (scan order: strict minimum per lane,
-            // first wins); kP candidates per lane and trip, compared in ascending order, as one by one
-            for (uint32_t c0 = gl; c0 < T; c0 += G * kP) {
-                f32x3 pt[kP];
-                uint32_t pi[kP];
-                const float *ad[kP];
+            // Binary search of a chunk's voxel: the first two of its five levels compare with three values read once
+            // per query, the last reads the entry and its successor together -- three dependent LDS round trips
+            // per chunk of four candidates.
+            const uint4 *pb = s_pb[grp];
+            const uint32_t p7 = pb[7].z, p15 = pb[15].z, p23 = pb[23].z;
+            // lane l takes chunks l, l + 16, ... of the flattened sequence; a chunk's four points are consecutive rows:
+            // one address, four 12-byte loads in flight, compared in ascending order (strict minimum per lane: first
+            // wins).  Rows of a chunk beyond the voxel's count are read (they exist: the slab, the next one, or the
+            // padding behind the last) and not compared.
+            for (uint32_t ch = gl; ch < Tc; ch += G) {
+                // smallest b with prefix[b] > ch
+                uint32_t b = (p15 <= ch) ? 16u : 0u;
+                b += ((b ? p23 : p7) <= ch) ? 8u : 0u;
+                b += (pb[b + 3].z <= ch) ? 4u : 0u;
+                b += (pb[b + 1].z <= ch) ? 2u : 0u;
+                const uint4 e = pb[b];
+                const uint2 nx = *reinterpret_cast<const uint2 *>(&pb[b + 1]);
+                const bool up = e.z <= ch;
+                const uint32_t c0 = ch << 2;
+                const uint32_t pi0 = (up ? nx.x : e.x) + c0;   // first row of the chunk
+                const uint32_t nv = (up ? nx.y : e.y) - c0;    // rows of the voxel from there on (>= 1)
+                f32x3 pt[4];
+                load_chunk48(map.pts + (size_t)pi0 * 3, pt);
 #pragma unroll
-                for (int u = 0; u < kP; u++) {
-                    const uint32_t c = c0 + (uint32_t)(u * G);
-                    const uint32_t cs = c < T ? c : c0;  // beyond the end: re-read this lane's first (not compared)
-                    // smallest b with prefix[b] > cs
-                    uint32_t b = (p15 <= cs) ? 16u : 0u;
-                    b += ((b ? p23 : p7) <= cs) ? 8u : 0u;
-                    b += (pb[b + 3].x <= cs) ? 4u : 0u;
-                    b += (pb[b + 1].x <= cs) ? 2u : 0u;
-                    const uint2 e = pb[b];
-                    const uint32_t next_base = pb[b + 1].y;
-                    pi[u] = ((e.x <= cs) ? next_base : e.y) + cs;
-                    ad[u] = map.pts + (size_t)pi[u] * 3;
-                }
-                load_points2(ad[0], ad[1], pt[0], pt[1]);
-#pragma unroll
-                for (int u = 0; u < kP; u++) {
-                    const uint32_t c = c0 + (uint32_t)(u * G);
+                for (int u = 0; u < 4; u++) {
                     const f32x3 a = pt[u];
                     const float dx = qx - a.x, dy = qy - a.y, dz = qz - a.z;
                     const float d2 = dx * dx + (dy * dy + dz * dz);  // voxel_grid.h:184 f32 squaredNorm
-                    if (c < T && d2 < P.max_sq && d2 < best) {  // :186-187 strict
+                    if ((u == 0 || nv > (uint32_t)u) && d2 < best) {  // :186-187 strict
                         best = d2;
-                        best_c = c;
-                        best_idx = pi[u];
-                        bpx = a.x;
-                        bpy = a.y;
-                        bpz = a.z;
+                        best_c = c0 + (uint32_t)u;
+                        best_pi0 = pi0;
                     }
                 }
             }
@@ -449,22 +474,21 @@ __global__ __launch_bounds__(kMatchThreads, kMinWaves) void k_match(MapView map,
         const uint32_t w_c = (uint32_t)keyv;
         const bool valid = w_c != 0xFFFFFFFFu;
         LOM_STAMP(5);  // group minimum known
-        // the lane that scanned the winner holds its point in registers and writes the record
+        // the lane that scanned the winner reads its point again together with the normal (two loads, one round
+        // trip: keeping the point in registers through the candidate loop cost three selects per candidate)
         if (valid ? (best_c == w_c) : (gl == 0)) {
             int32_t idx = -1;
-            float n0 = 0.f, n1 = 0.f, n2 = 0.f;
+            f32x3 wp = {0.f, 0.f, 0.f}, wn = {0.f, 0.f, 0.f};
             if (valid) {
-                const size_t pi = best_idx;
+                const size_t pi = (size_t)best_pi0 + (best_c & 3u);
                 idx = (int32_t)pi;
-                n0 = map.nrm[pi * 3 + 0];  // voxel_grid.h:197-198
-                n1 = map.nrm[pi * 3 + 1];
-                n2 = map.nrm[pi * 3 + 2];
+                load_points2(map.pts + pi * 3, map.nrm + pi * 3, wp, wn);  // voxel_grid.h:197-198
             }
             out_idx[q] = idx;
             float4 *rec = reinterpret_cast<float4 *>(out_rec + q);
             rec[0] = make_float4(s0, s1, s2, valid ? 1.f : 0.f);
-            rec[1] = make_float4(bpx, bpy, bpz, n0);
-            rec[2] = make_float4(n1, n2, 0.f, 0.f);
+            rec[1] = make_float4(wp.x, wp.y, wp.z, wn.x);
+            rec[2] = make_float4(wn.y, wn.z, 0.f, 0.f);
             if (out_stat) {
                 QStat st;
                 st.sq_dist = valid ? best : 0.f;
@@ -476,7 +500,6 @@ __global__ __launch_bounds__(kMatchThreads, kMinWaves) void k_match(MapView map,
             atomicAdd(&s_cnt[grp][0], valid ? 1u : 0u);
             atomicAdd(&s_cnt[grp][1], n_cand);
             atomicAdd(&s_cnt[grp][2], n_occ);
-            atomicAdd(&s_cnt[grp][3], T);  // candidates actually read (after the exact pruning)
         }
         LOM_STAMP(6);  // winner's normal loaded, record stored
         stamper.first_done();
@@ -1475,9 +1498,9 @@ static int launch_match(ScanCtx &c, const float t[3], const float q[4], float ma
         };
         QStat *st = (stats && !chained) ? (QStat *)m->scan_stats.p : (QStat *)nullptr;
         if (chained)
-            launch(k_match<kMatchG, 2, kMatchMinWaves, false, true>, st, (const AlignState *)m->align_state.p);
+            launch(k_match<kMatchG, kMatchRows, kMatchMinWaves, false, true>, st, (const AlignState *)m->align_state.p);
         else
-            launch(k_match<kMatchG, 2, kMatchMinWaves>, st, (const AlignState *)nullptr);
+            launch(k_match<kMatchG, kMatchRows, kMatchMinWaves>, st, (const AlignState *)nullptr);
         LOM_HIP(m, hipGetLastError());
         if (m->profiling) LOM_HIP(m, hipEventRecord(e1, m->stream));
     }
@@ -2287,7 +2310,7 @@ int lom_debug_match_stamps(lom_map *m, const float *d_src, size_t n, size_t stri
     PoseArgs P;
     pose_args(t, q, max_dist, P);
     for (int rep = 0; rep < 3; rep++)  // the last launch's stamps are kept (warm caches, like an align)
-        hipLaunchKernelGGL((k_match<kMatchG, 2, kMatchMinWaves, true>), dim3(nb), dim3(kMatchThreads), 0, m->stream, view_of(m),
+        hipLaunchKernelGGL((k_match<kMatchG, kMatchRows, kMatchMinWaves, true>), dim3(nb), dim3(kMatchThreads), 0, m->stream, view_of(m),
                            (const char *)d_src, stride, (uint32_t)n, P, (int32_t *)m->scan_idx.p,
                            (MatchRec *)m->scan_on.p, (QStat *)nullptr, d_block_counters(m), d_st);
     hipError_t e = hipMemcpyAsync(stamps_out, d_st, (size_t)nb * 64, hipMemcpyDeviceToHost, m->stream);

@@ -222,7 +222,7 @@ __device__ inline uint32_t claim_slot(Slot *table, uint32_t mask, uint32_t shift
             const unsigned long long prev = atomicCAS(&table[h].key, kEmptyKey, key);
             if (prev == kEmptyKey || prev == key) return h;
         }
-        h = (h + 1) & mask;
+        h = (h + kProbeStep) & mask;
     }
 }
 
@@ -797,11 +797,13 @@ static void slabs_free(Slabs &s)
     s = Slabs();
 }
 
+// k_match reads a chunk of four consecutive 12-byte rows from any live row on: the rows behind the last slab exist
+constexpr size_t kRowPadBytes = 64;
 static int slabs_alloc(lom_map *m, uint32_t cap, Slabs &s)
 {
     const size_t pb = (size_t)cap * m->K * 3 * sizeof(float);
     if (hipMalloc(&s.key, (size_t)cap * 8) != hipSuccess || hipMalloc(&s.count, (size_t)cap * 4) != hipSuccess ||
-        hipMalloc(&s.pts, pb) != hipSuccess || hipMalloc(&s.nrm, pb) != hipSuccess) {
+        hipMalloc(&s.pts, pb + kRowPadBytes) != hipSuccess || hipMalloc(&s.nrm, pb + kRowPadBytes) != hipSuccess) {
         (void)hipGetLastError();
         slabs_free(s);
         return set_error(m, LOM_ERR_OOM, "hipMalloc(slabs)");
@@ -1096,12 +1098,15 @@ static int add_points_device(lom_map *m, const char *d_xyz, const char *d_nrm, s
     if (sync_status && (!validated_on_host || multi_launch)) {
         if ((rc = map_status(m)) != LOM_OK) return rc;
     }
-    // keep the table dense enough to stay cache-resident: load factor in (1/16, 1/2] (measured on C2/C3:
-    // 2 slots per voxel costs the search 5-10 %, 4..16 are equal within noise).  Only a batch that made the
-    // table grow far beyond its content (a bulk insert into few voxels) is worth the look at the host.
+    // Table size after a bulk insert: ~16 slots per voxel (load factor in (1/64, 1/16]).  With the brick-local slot hash
+    // (lom_internal.hpp) the lines a search touches are those of the occupied bricks whatever the capacity, and the
+    // bricks of one surface collide in whole parity patterns, so chains get long early: on the 2M-point map of C3 the
+    // longest chain among a query's 27 look-ups averages 2.4 slots at 4 slots per voxel, 1.6 at 8, 1.3 at 16 (what the
+    // Fibonacci hash of rounds 1-2 had at 4), and k_match takes 29.9 / - / 25.3 us.  Only a batch that made the table grow
+    // far beyond that (a bulk insert into few voxels) is worth the look at the host.
     if (allow_shrink && N > kOnePassMax && (uint64_t)m->cap >= 16ull * std::max<uint32_t>(m->min_cap, 1u)) {
         if ((rc = refresh_nvox(m)) != LOM_OK) return rc;
-        const uint32_t target = std::max(m->min_cap, next_pow2(4ull * m->n_vox));
+        const uint32_t target = std::max(m->min_cap, next_pow2(16ull * m->n_vox));
         if (m->cap > 4 * target) {
             if ((rc = rehash(m, target)) != LOM_OK) return rc;
         }
@@ -1511,8 +1516,8 @@ int lom_profile_insert(lom_map *m, const float *d_xyz, const float *d_nrm, size_
     if (e != hipSuccess) return set_error(m, LOM_ERR_HIP, "lom_profile_insert", e);
     *total_us_out = (double)ms * 1e3;
     if ((rc = map_status(m)) != LOM_OK) return rc;
-    // what lom_map_add_points_device does after a bulk insert: keep the table's load factor in (1/16, 1/2]
-    const uint32_t target = std::max(m->min_cap, next_pow2(4ull * m->n_vox));
+    // what lom_map_add_points_device does after a bulk insert: ~16 slots per voxel
+    const uint32_t target = std::max(m->min_cap, next_pow2(16ull * m->n_vox));
     if (m->cap > 4 * target) return rehash(m, target);
     return LOM_OK;
 }

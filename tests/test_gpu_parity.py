@@ -209,6 +209,29 @@ def test_large_cap_voxels(lom, oracle):
         assert m.stats["cand_total"] == om.stats["cand_total"]
 
 
+def test_lattice_of_equal_parities(lom, oracle):
+    """Every voxel index even: all voxels share one home position inside their table bucket (the slot hash places a
+    voxel by the parities of its index, lom_internal.hpp) -- the probe sequence has to spread them over the table;
+    then a second batch at odd indices.  Map and pairs against the oracle."""
+    g, og = _both(lom, oracle, 0.5, 4)
+    ax = np.arange(-24, 24, dtype=np.float32)                        # 48^3 = 110,592 voxels, index = 2 * k
+    pts = np.stack(np.meshgrid(ax, ax, ax, indexing="ij"), -1).reshape(-1, 3) + np.float32(0.1)
+    rng = np.random.default_rng(5)
+    pts = np.ascontiguousarray(pts[rng.permutation(len(pts))])
+    nrm = scenes._unit(rng.standard_normal(pts.shape)).astype(np.float32)
+    g.addCloud(pts, nrm)
+    og.addCloud(pts, nrm)
+    assert g.size() == og.size() == 48 ** 3
+    _assert_same_map(g, og)
+    odd = np.ascontiguousarray(pts[::5] + np.float32(0.5))
+    g.addCloudWithoutNormals(odd)
+    og.addCloudWithoutNormals(odd)
+    _assert_same_map(g, og)
+    q = rng.uniform(-12, 12, (4000, 3)).astype(np.float32)
+    for d in (0.3, 1.0):
+        _assert_same_pairs(g.findMatchingPairs(q, lom.Pose3D(), d), og.findMatchingPairs(q, oracle.Pose3D(), d))
+
+
 def test_more_than_a_million_voxels(lom, oracle):
     """A map beyond 16 x 65536 voxels: the cleanup's multi-launch scan (its in-kernel scan covers 1,048,576), table
     growth while inserting, bulk inserts of more than 65536 points, a second batch over the first; bytewise against
