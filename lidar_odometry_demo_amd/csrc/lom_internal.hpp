@@ -236,6 +236,7 @@ struct lom_map {
     lom::DeviceBuf gather;
 
     // run-time switches: environment read ONCE at lom_map_create, afterwards lom_map_set_option only
+    int opt_match_lanes = 0;  // LOM_OPT_MATCH_LANES: 8 selects k_match<8>, anything else the 16-lane form
     bool opt_host_lm = false;       // LOM_OPT_HOST_LM / LOM_HOST_LM=1
     bool opt_debug_lm = false;      // LOM_OPT_DEBUG_LM_STAMPS / LOM_DEBUG_LM=1
     bool opt_debug_timing = false;  // LOM_OPT_DEBUG_TIMING / LOM_DEBUG_TIMING=1

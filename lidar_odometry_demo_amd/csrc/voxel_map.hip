@@ -1256,6 +1256,7 @@ int lom_scan_create(lom_map *map, lom_scan **out)
     c->device = map->device;
     c->parent = map;
     c->opt_host_lm = map->opt_host_lm;
+    c->opt_match_lanes = map->opt_match_lanes;
     c->opt_debug_lm = map->opt_debug_lm;
     c->opt_debug_timing = map->opt_debug_timing;
     c->patience_ticks = map->patience_ticks;
@@ -1320,6 +1321,7 @@ int lom_map_create(float voxel_size, size_t max_points, size_t capacity_hint, in
     m->K = (uint32_t)max_points;
     // the environment is looked at here and nowhere on the align path (lom_map_set_option changes the switches later)
     m->opt_host_lm = getenv("LOM_HOST_LM") != nullptr;
+    if (const char *e = getenv("LOM_MATCH_LANES")) m->opt_match_lanes = atoi(e) == 8 ? 8 : (atoi(e) == 16 ? 16 : 0);
     m->opt_debug_lm = getenv("LOM_DEBUG_LM") != nullptr;
     m->opt_debug_timing = getenv("LOM_DEBUG_TIMING") != nullptr;
     if (handle_setup(m) != LOM_OK) {
@@ -1409,6 +1411,10 @@ int lom_map_set_option(lom_map *m, int option, int64_t value)
         return LOM_OK;
     case LOM_OPT_DEBUG_LM_STAMPS: m->opt_debug_lm = value != 0; return LOM_OK;
     case LOM_OPT_DEBUG_TIMING: m->opt_debug_timing = value != 0; return LOM_OK;
+    case LOM_OPT_MATCH_LANES:
+        if (value != 0 && value != 8 && value != 16) return set_error(m, LOM_ERR_ARG, "LOM_OPT_MATCH_LANES: 0, 8 or 16");
+        m->opt_match_lanes = (int)value;
+        return LOM_OK;
     case LOM_OPT_TEST_GIVE_UP_AT_OUTER:
         if (value < -1 || value >= 35) return LOM_ERR_ARG;
         m->test_give_up_outer = (int)value;

@@ -16,8 +16,8 @@ pass() {
   rm -rf "$OUT/raw_$name"
 }
 pass sq SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU
-pass sq2 SQ_BUSY_CYCLES SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_INST_LEVEL_VMEM
-pass ta TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum
+
+
 pass tcp TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_GATE_EN1_sum
-pass tcc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_BUSY_sum
+
 grep "rc=" "$OUT/log.txt"
