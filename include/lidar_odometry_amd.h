@@ -280,7 +280,6 @@ typedef enum {
                                           a device-to-device align outlasts both (see lom_comm_attach_p2p). */
     LOM_OPT_DEBUG_LM_STAMPS = 3,       /* 1: print k_lm's phase stamps after every align (stderr) */
     LOM_OPT_DEBUG_TIMING = 4,          /* 1: print host launch / wait times per evaluation (stderr) */
-    LOM_OPT_MATCH_LANES = 5,           /* lanes per query of the correspondence search: 0 = by cloud size (default), 8, 16 */
     LOM_OPT_TEST_GIVE_UP_AT_OUTER = 100, /* k: the k_lm of outer iteration k of the NEXT align behaves as if its
                                           workgroups had timed out waiting (one shot; -1 = off) */
     LOM_OPT_TEST_GRID_GIVE_UP = 101,   /* b >= 0: in the NEXT map-maintenance call with an in-kernel scan, workgroups

@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblidar_odometry_amd.so")
+LIB_PATH = os.environ.get("LOM_LIB_PATH") or os.path.join(_HERE, "liblidar_odometry_amd.so")  # LOM_LIB_PATH: A/B builds (tools/)
 NSUMS = 32
 COMM_ID_BYTES = 128
 
@@ -132,7 +132,6 @@ EXPORTED = [
 
 # lom_option / counters of include/lidar_odometry_amd.h
 OPT_HOST_LM, OPT_DEVICE_PATIENCE_TICKS, OPT_DEBUG_LM_STAMPS, OPT_DEBUG_TIMING = 1, 2, 3, 4
-OPT_MATCH_LANES = 5
 OPT_TEST_GIVE_UP_AT_OUTER, OPT_TEST_GRID_GIVE_UP, OPT_TEST_FORCE_HOST_REDO = 100, 101, 102
 OPT_TEST_GRID_GIVE_UP_MATCHING_DS, OPT_TEST_GRID_GIVE_UP_UPDATE_DS, OPT_TEST_GRID_GIVE_UP_KEYFRAME = 103, 104, 105
 COUNTER_GRID_REDOS = 0

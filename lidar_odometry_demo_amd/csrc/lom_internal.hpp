@@ -36,27 +36,15 @@ __host__ __device__ inline unsigned long long pack_key(int ix, int iy, int iz)
            (unsigned long long)(uint32_t)(iz + kIdxBias);
 }
 
-// Locality-preserving hash: the 2x2x2 block of voxels that share (ix >> 1, iy >> 1, iz >> 1) -- a "brick" -- lives
-// in ONE 128-byte bucket of eight slots, so the 27 neighbours of a query (always 2x2x2 bricks) are found in eight
-// cache lines instead of 27.  Bucket = xor of three per-axis Fibonacci hashes of the brick coordinate (each axis's
-// part depends on that axis alone: k_match computes three parts per axis and query, not one hash per neighbour);
-// home slot inside the bucket = the three parity bits; on a collision kProbeStep slots further: the next bucket AND
-// the next slot inside it (stepping inside the bucket, or always to the same slot of the next, makes chains several
-// times longer: bricks of one surface occupy the same parity pattern).  Works on the biased fields of the packed key (the bias is even: parity and brick
-// grouping are those of the index).  The hash never influences results (reference IndicesHash, voxel_grid.h:31-38,
-// likewise).  shift = 64 - log2(capacity), capacity >= 1024.
-constexpr uint32_t kProbeStep = 9;
-constexpr uint32_t kAxisMul[3] = {0x9E3779B1u, 0x85EBCA77u, 0xC2B2AE3Du};
-__host__ __device__ inline uint32_t axis_hash_part(uint32_t biased_index, uint32_t mul, uint32_t parity_bit, uint32_t shift)
-{
-    return ((((biased_index >> 1) * mul) >> (shift - 29u)) << 3) | ((biased_index & 1u) << parity_bit);
-}
+// Fibonacci hashing: top log2(cap) bits of key * 2^64/phi.  The hash never
+// influences results (reference IndicesHash, voxel_grid.h:31-38, likewise).
+// (Round 3 tried a brick-local hash -- the 2x2x2 block of voxels sharing (ix >> 1, iy >> 1, iz >> 1) in ONE 128-byte
+// bucket, so that a query's 27 slots lie in eight lines: half the L2 requests, but the bricks of one surface collide
+// in whole parity patterns (chains 2.4 slots against 1.4 at equal load), the three per-axis hash parts have to travel
+// through LDS, and at equal table size the probe phase of C2 took 2.4 us against 1.5: DESIGN.md section 5.)
 __host__ __device__ inline uint32_t hash_key(unsigned long long key, uint32_t shift)
 {
-    const uint32_t ux = (uint32_t)(key >> 42) & 0x1FFFFFu, uy = (uint32_t)(key >> 21) & 0x1FFFFFu,
-                   uz = (uint32_t)key & 0x1FFFFFu;
-    return axis_hash_part(ux, kAxisMul[0], 2, shift) ^ axis_hash_part(uy, kAxisMul[1], 1, shift) ^
-           axis_hash_part(uz, kAxisMul[2], 0, shift);
+    return (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> shift);
 }
 
 // voxel_grid.h:70-72 / :166-168: static_cast<int64_t>(x / voxel_size_), f32
@@ -236,7 +224,7 @@ struct lom_map {
     lom::DeviceBuf gather;
 
     // run-time switches: environment read ONCE at lom_map_create, afterwards lom_map_set_option only
-    int opt_match_lanes = 0;  // LOM_OPT_MATCH_LANES: 8 selects k_match<8>, anything else the 16-lane form
+    uint32_t table_slots_per_voxel = 16;  // after a bulk insert (LOM_TABLE_SLOTS_PER_VOXEL at create)
     bool opt_host_lm = false;       // LOM_OPT_HOST_LM / LOM_HOST_LM=1
     bool opt_debug_lm = false;      // LOM_OPT_DEBUG_LM_STAMPS / LOM_DEBUG_LM=1
     bool opt_debug_timing = false;  // LOM_OPT_DEBUG_TIMING / LOM_DEBUG_TIMING=1

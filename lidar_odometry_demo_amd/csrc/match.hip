@@ -40,7 +40,6 @@ namespace lom {
 constexpr int kMatchThreads = 256;             // 4 waves
 constexpr int kMatchG = 16;                    // lanes per query: four queries per wave
 constexpr int kMatchRows = 4;                  // consecutive rows of a voxel per chunk: one search and 48 bytes per lane and trip
-constexpr int kGroupsPerBlock = kMatchThreads / kMatchG;
 constexpr int kMatchMinWaves = 7;              // waves per SIMD the register budget is held to (72 VGPRs)
 constexpr int kEvalThreads = 512;
 
@@ -65,9 +64,7 @@ struct __attribute__((aligned(8))) QStat {
 // k_match<G>: one query per group of G lanes (G = 16: four queries per wave).
 //
 //  1. probe    lane l takes neighbours b = l, l+G, ... < 27 in the reference's scan
-//              order ix, iy, iz (voxel_grid.h:175-179): one 16-byte slot load each.  The slot
-//              hash keeps a 2x2x2 brick of voxels in one 128-byte line (lom_internal.hpp):
-//              the 27 slots of a query lie in eight lines.
+//              order ix, iy, iz (voxel_grid.h:175-179): one 16-byte slot load each.
 //  2. prune    a neighbour voxel whose nearest possible coordinate is provably
 //              farther than max_dist cannot hold a point with d2 < max_sq
 //              (voxel_grid.h:186), so its points are not read.  Exact: such points
@@ -130,6 +127,13 @@ __device__ __forceinline__ unsigned long long row_min_step(unsigned long long k)
         ((unsigned long long)row_dpp<kCtrl>((uint32_t)(k >> 32)) << 32) | row_dpp<kCtrl>((uint32_t)k);
     return o < k ? o : k;
 }
+__device__ __forceinline__ unsigned long long row_min64(unsigned long long k)
+{
+    k = row_min_step<kDppXor1>(k);
+    k = row_min_step<kDppXor2>(k);
+    k = row_min_step<kDppHalfMirror>(k);
+    return row_min_step<kDppMirror>(k);
+}
 // lane kLane (0..15) of the row, to every lane of the row (ds_swizzle bit mode: and 0x10, or kLane)
 template <int kLane>
 __device__ __forceinline__ uint32_t row_lane(uint32_t v)
@@ -138,49 +142,6 @@ __device__ __forceinline__ uint32_t row_lane(uint32_t v)
 }
 // lane 15 of the row, to every lane of the row (ds_swizzle bit mode: and 0x10, or 0x0F)
 __device__ __forceinline__ uint32_t row_last(uint32_t v) { return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x1F0); }
-
-// ---- the same for a query group of G = 16 lanes (one DPP row) or G = 8 (half a row) ----
-// lane kLane of the group, to every lane of the group (ds_swizzle bit mode: keep the group bits, or in kLane)
-template <int G, int kLane>
-__device__ __forceinline__ uint32_t grp_lane(uint32_t v)
-{
-    return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, (0x1F & ~(G - 1)) | (kLane << 5));
-}
-template <int G>
-__device__ __forceinline__ uint32_t grp_last(uint32_t v) { return grp_lane<G, G - 1>(v); }
-// inclusive scan over the group's lanes.  G = 8: a row shift by 1 / 2 brings lanes 7 / 6, 7 of the lower half into
-// lanes 8 / 8, 9 of the upper: masked off (m1 = lane of the group >= 1, m2 = >= 2, as all-ones words); the shift by 4
-// writes banks 1 and 3 only (bank_mask 0b1010: lanes 4..7 and 12..15), the others add the old value 0.
-template <int G>
-__device__ __forceinline__ uint32_t grp_scan_inclusive(uint32_t v, uint32_t m1, uint32_t m2)
-{
-    if constexpr (G == 16) {
-        return row_scan_inclusive(v);
-    } else {
-        v += row_dpp<0x111>(v) & m1;
-        v += row_dpp<0x112>(v) & m2;
-        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xA, false);
-        return v;
-    }
-}
-template <int G>
-__device__ __forceinline__ uint32_t grp_sum(uint32_t v)
-{
-    v += row_dpp<kDppXor1>(v);
-    v += row_dpp<kDppXor2>(v);
-    v += row_dpp<kDppHalfMirror>(v);  // pairs the two quads of a half
-    if constexpr (G == 16) v += row_dpp<kDppMirror>(v);  // pairs the two halves
-    return v;
-}
-template <int G>
-__device__ __forceinline__ unsigned long long grp_min64(unsigned long long k)
-{
-    k = row_min_step<kDppXor1>(k);
-    k = row_min_step<kDppXor2>(k);
-    k = row_min_step<kDppHalfMirror>(k);
-    if constexpr (G == 16) k = row_min_step<kDppMirror>(k);
-    return k;
-}
 
 template <int kCtrl>
 __device__ __forceinline__ double dpp_f64(double v)  // the value of the DPP partner lane
@@ -280,7 +241,15 @@ __global__ __launch_bounds__(kMatchThreads, kMinWaves) void k_match(MapView map,
                                                          unsigned long long *__restrict__ stamps = nullptr,
                                                          const AlignState *state = nullptr)
 {
-    static_assert((G == 16 || G == 8) && kU == 4, "one query per 16-lane DPP row or half row, a chunk of four rows per lane and trip");
+    static_assert(G == 16 && kU == 4, "one query per 16-lane DPP row, a chunk of four rows per lane and trip");
+    constexpr uint32_t kRowsLog2 = 2;  // rows per chunk
+    // the first query's source point is on its way before anything else: the chained form's pose comes through a
+    // scalar-cache miss of its own, and the LDS tables below need a barrier -- one memory round trip instead of two
+    // ahead of the first probe (the loop fetches the next query's point the same way, behind the current one's work)
+    constexpr int kGroups0 = kMatchThreads / G;
+    const uint32_t q_first = blockIdx.x * kGroups0 + threadIdx.x / G;
+    f32x3 sp_next = {0.f, 0.f, 0.f};
+    if (q_first < n) sp_next = *reinterpret_cast<const f32x3 *>(src + (size_t)q_first * stride);
     struct {
         double R[9], t[3];
         float max_sq;
@@ -288,12 +257,16 @@ __global__ __launch_bounds__(kMatchThreads, kMinWaves) void k_match(MapView map,
     if constexpr (kChained) {
         typedef const __attribute__((address_space(4))) AlignState *ConstState;
         ConstState cs = (ConstState)(state);
-        if (cs->finished | cs->error) return;
+        // pose and stop flags in ONE scalar round trip (the flags first and the pose behind the branch were two)
 #pragma unroll
         for (int i = 0; i < 9; i++) P.R[i] = cs->P.R[i];
 #pragma unroll
         for (int i = 0; i < 3; i++) P.t[i] = cs->P.t[i];
         P.max_sq = cs->P.max_sq;
+        const int stop = cs->finished | cs->error;
+        asm volatile("" ::"s"(P.max_sq), "s"(stop), "s"(P.R[0]), "s"(P.R[1]), "s"(P.R[2]), "s"(P.R[3]), "s"(P.R[4]), "s"(P.R[5]),
+                     "s"(P.R[6]), "s"(P.R[7]), "s"(P.R[8]), "s"(P.t[0]), "s"(P.t[1]), "s"(P.t[2]));  // all loaded before the branch
+        if (stop) return;
     } else {
 #pragma unroll
         for (int i = 0; i < 9; i++) P.R[i] = Parg.R[i];
@@ -304,15 +277,14 @@ __global__ __launch_bounds__(kMatchThreads, kMinWaves) void k_match(MapView map,
     Stamper<kStamp> stamper;
     LOM_STAMP(0);
     constexpr int kGroups = kMatchThreads / G;
-    constexpr int kSets = 32 / G;             // neighbours b = gl + G * set < 27
+    constexpr int kSets = 2;                  // neighbours b = gl (set 0) and 16 + gl (set 1) < 27
     // per neighbour b in scan order: .z inclusive prefix of the scanned CHUNKS (entries >= 27: never reached),
     // .x slab * K - 4 * exclusive prefix, so that chunk ch of the flattened sequence starts at row .x + 4 * ch,
     // .y count + 4 * exclusive prefix: .y - 4 * ch rows of the voxel remain from there
     __shared__ uint4 s_pb[kGroups][32];
     __shared__ uint32_t s_cnt[kGroups][4];
     __shared__ double s_pose[12];             // [component][R row (3), t]: what the component lanes multiply with
-    // per query [axis][neighbour index i-1, i, i+1]: .x squared pruning gap (bits), .y that index's part of the slot hash
-    __shared__ uint2 s_ax[kGroups][12];
+    __shared__ float s_gap[kGroups][12];      // per query [axis][to voxel i-1, 0, to voxel i+1]: squared pruning gaps
     const int gl = threadIdx.x % G;
     const int grp = threadIdx.x / G;
     const uint32_t groups_total = gridDim.x * kGroups;
@@ -331,35 +303,33 @@ __global__ __launch_bounds__(kMatchThreads, kMinWaves) void k_match(MapView map,
     }
     __syncthreads();
     const float prune_sq = P.max_sq * 1.0001f;
-    const uint32_t m1 = gl >= 1 ? 0xFFFFFFFFu : 0u, m2 = gl >= 2 ? 0xFFFFFFFFu : 0u;  // grp_scan_inclusive<8>
     // Work that is the same for the lanes of a query is split over them instead of repeated by each: lanes
-    // 0, 1, 2 of a group prepare the x, y, z component (f64 transform, f32 cast, truncating index, the two
+    // 0, 1, 2 of a row prepare the x, y, z component (f64 transform, f32 cast, truncating index, the two
     // pruning gaps of that axis) and hand the results to the row -- values through ds_swizzle broadcasts, the
-    // gap table through 12 LDS words.  Lanes 3.. repeat component z (same instruction stream, results unused).
+    // gap table through 12 LDS words.  Lanes 3..15 repeat component z (same instruction stream, results unused).
     const int comp = gl < 2 ? gl : 2;
     const double *my_pose = s_pose + comp * 4;
-    const uint32_t my_mul = comp == 0 ? kAxisMul[0] : comp == 1 ? kAxisMul[1] : kAxisMul[2];
-    const uint32_t my_parity_bit = 2u - (uint32_t)comp;
-    // this lane's two neighbours (scan order ix, iy, iz): the key of a neighbour follows from the centre's by ADDING a
-    // lane constant (pack_key is a sum of shifted fields); its home slot is the xor of three per-axis parts
-    // (lom_internal.hpp, hash_key) that the component lanes leave in LDS next to the pruning gaps.
-    // (per set: the key offset, and the byte offsets of its three table entries packed into one word)
-    unsigned long long dkey[kSets];
-    uint32_t ax_off[kSets];
+    // this lane's neighbours (scan order ix, iy, iz): key and hash of a neighbour follow from the centre's by ADDING a lane
+    // constant -- pack_key is a sum of shifted fields, and the Fibonacci hash multiplies by a constant modulo 2^64, so
+    // hash(key0 + d) = (key0 * phi + d * phi) >> shift.  One 64-bit multiply per query, no per-neighbour packing.
+    constexpr unsigned long long kPhi = 0x9E3779B97F4A7C15ull;
+    unsigned long long dkey[kSets], dprod[kSets];
+    const float *gap_x[kSets], *gap_y[kSets], *gap_z[kSets];
 #pragma unroll
     for (int s = 0; s < kSets; s++) {
         const int b = gl + s * G;
         const int dx = b / 9 - 1, dy = (b / 3) % 3 - 1, dz = b % 3 - 1;
         dkey[s] = (unsigned long long)(((long long)dx << 42) + ((long long)dy << 21) + (long long)dz);
-        const uint32_t ox = 8u * (uint32_t)(0 + (b < 27 ? dx + 1 : 1)), oy = 8u * (uint32_t)(3 + (b < 27 ? dy + 1 : 1)),
-                       oz = 8u * (uint32_t)(6 + (b < 27 ? dz + 1 : 1));
-        ax_off[s] = ox | (oy << 8) | (oz << 16);
+        dprod[s] = dkey[s] * kPhi;
+        gap_x[s] = &s_gap[grp][0 + (b < 27 ? dx + 1 : 1)];
+        gap_y[s] = &s_gap[grp][3 + (b < 27 ? dy + 1 : 1)];
+        gap_z[s] = &s_gap[grp][6 + (b < 27 ? dz + 1 : 1)];
     }
-    const char *ax_base = reinterpret_cast<const char *>(&s_ax[grp][0]);
+    if (gl < 3) s_gap[grp][gl * 3 + 1] = 0.f;  // the centre column of the gap table never changes (own group, own wave)
 
     for (uint32_t q = blockIdx.x * kGroups + grp; q < n; q += groups_total) {
-        const float *sp = reinterpret_cast<const float *>(src + (size_t)q * stride);
-        const float s0 = sp[0], s1 = sp[1], s2 = sp[2];
+        const float s0 = sp_next.x, s1 = sp_next.y, s2 = sp_next.z;
+        if (q + groups_total < n) sp_next = *reinterpret_cast<const f32x3 *>(src + (size_t)(q + groups_total) * stride);
         const double p0 = (double)s0, p1 = (double)s1, p2 = (double)s2;
         // voxel_grid.h:220-223: R*p + t in f64 (Eigen order a0 + (a1 + a2)), cast to f32 -- this lane's component
         const float qc = (float)((my_pose[0] * p0 + (my_pose[1] * p1 + my_pose[2] * p2)) + my_pose[3]);
@@ -368,17 +338,15 @@ __global__ __launch_bounds__(kMatchThreads, kMinWaves) void k_match(MapView map,
         float gm2, gp2;
         axis_gaps(qc, ic, map.voxel_size, gm2, gp2);
         if (gl < 3) {
-            const uint32_t u = (uint32_t)(ic + kIdxBias);  // biased index of this axis (garbage if !okc: not used then)
-            s_ax[grp][gl * 3 + 0] = make_uint2(__float_as_uint(gm2), axis_hash_part(u - 1u, my_mul, my_parity_bit, map.shift));
-            s_ax[grp][gl * 3 + 1] = make_uint2(0u, axis_hash_part(u, my_mul, my_parity_bit, map.shift));
-            s_ax[grp][gl * 3 + 2] = make_uint2(__float_as_uint(gp2), axis_hash_part(u + 1u, my_mul, my_parity_bit, map.shift));
+            s_gap[grp][gl * 3 + 0] = gm2;
+            s_gap[grp][gl * 3 + 2] = gp2;
         }
         const int icc = okc ? ic : (int)0x80000000;  // out of range / not finite
-        const float qx = __uint_as_float(grp_lane<G, 0>(__float_as_uint(qc)));
-        const float qy = __uint_as_float(grp_lane<G, 1>(__float_as_uint(qc)));
-        const float qz = __uint_as_float(grp_lane<G, 2>(__float_as_uint(qc)));
-        const int ix = (int)grp_lane<G, 0>((uint32_t)icc), iy = (int)grp_lane<G, 1>((uint32_t)icc),
-                  iz = (int)grp_lane<G, 2>((uint32_t)icc);
+        const float qx = __uint_as_float(row_lane<0>(__float_as_uint(qc)));
+        const float qy = __uint_as_float(row_lane<1>(__float_as_uint(qc)));
+        const float qz = __uint_as_float(row_lane<2>(__float_as_uint(qc)));
+        const int ix = (int)row_lane<0>((uint32_t)icc), iy = (int)row_lane<1>((uint32_t)icc),
+                  iz = (int)row_lane<2>((uint32_t)icc);
         const bool inr = ix != (int)0x80000000 && iy != (int)0x80000000 && iz != (int)0x80000000;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -390,88 +358,79 @@ __global__ __launch_bounds__(kMatchThreads, kMinWaves) void k_match(MapView map,
         const bool safe = (uint32_t)(ix + (kIdxBias - 2)) < kInner && (uint32_t)(iy + (kIdxBias - 2)) < kInner &&
                           (uint32_t)(iz + (kIdxBias - 2)) < kInner;
         const unsigned long long key0 = inr ? pack_key(ix, iy, iz) : 0ull;
+        const unsigned long long prod0 = key0 * kPhi;
         uint32_t cnt[kSets], scan_cnt[kSets], slab[kSets];
-        // two sets per pass, their first slots in flight together (G = 8: two passes; four loads in flight per lane
-        // would need a fifth of the register file more)
+        unsigned long long key[kSets];
+        uint32_t h[kSets];
+        bool act[kSets];
+        float lower[kSets];
 #pragma unroll
-        for (int s0 = 0; s0 < kSets; s0 += 2) {
-            unsigned long long key[2];
-            uint32_t h[2];
-            bool act[2];
-            float lower[2];
-#pragma unroll
-            for (int j = 0; j < 2; j++) {
-                const int s = s0 + j;
-                const int b = gl + s * G;
-                act[j] = inr && b < 27;
-                if (act[j] && !safe) {  // the outermost index layers: neighbours beyond the range cannot exist
-                    const int nx = ix + (b / 9 - 1), ny = iy + ((b / 3) % 3 - 1), nz = iz + (b % 3 - 1);
-                    act[j] = nx > -kIdxBias && nx < kIdxBias && ny > -kIdxBias && ny < kIdxBias && nz > -kIdxBias &&
-                             nz < kIdxBias;
-                }
-                key[j] = act[j] ? key0 + dkey[s] : 0ull;
-                const uint2 ex = *reinterpret_cast<const uint2 *>(ax_base + (ax_off[s] & 0xFFu)),
-                            ey = *reinterpret_cast<const uint2 *>(ax_base + ((ax_off[s] >> 8) & 0xFFu)),
-                            ez = *reinterpret_cast<const uint2 *>(ax_base + (ax_off[s] >> 16));
-                h[j] = act[j] ? ((ex.y ^ ey.y ^ ez.y) & map.mask) : 0u;
-                lower[j] = __uint_as_float(ex.x) + (__uint_as_float(ey.x) + __uint_as_float(ez.x));
+        for (int s = 0; s < kSets; s++) {
+            const int b = gl + s * G;
+            act[s] = inr && b < 27;
+            if (act[s] && !safe) {  // the outermost index layers: neighbours beyond the range cannot exist
+                const int nx = ix + (b / 9 - 1), ny = iy + ((b / 3) % 3 - 1), nz = iz + (b % 3 - 1);
+                act[s] = nx > -kIdxBias && nx < kIdxBias && ny > -kIdxBias && ny < kIdxBias && nz > -kIdxBias &&
+                         nz < kIdxBias;
             }
-            u32x4 raw[2];
-            load_slots2(map.table + h[0], map.table + h[1], raw[0], raw[1]);
+            key[s] = act[s] ? key0 + dkey[s] : 0ull;
+            h[s] = act[s] ? ((uint32_t)((prod0 + dprod[s]) >> map.shift) & map.mask) : 0u;
+            lower[s] = *gap_x[s] + (*gap_y[s] + *gap_z[s]);
+        }
+        // both sets' first slots in flight together
+        u32x4 raw[kSets];
+        load_slots2(map.table + h[0], map.table + h[1], raw[0], raw[1]);
 #pragma unroll
-            for (int j = 0; j < 2; j++) {
-                const int s = s0 + j;
-                cnt[s] = 0;
-                slab[s] = 0;
-                if (act[j]) {
-                    u32x4 r = raw[j];
-                    uint32_t hh = h[j];
-                    for (uint32_t probe = 0; probe <= map.mask; probe++) {
-                        const unsigned long long k = ((unsigned long long)r.y << 32) | r.x;
-                        if (k == key[j]) {
-                            cnt[s] = r.z;
-                            slab[s] = r.w;
-                            break;
-                        }
-                        if (k == kEmptyKey) break;
-                        hh = (hh + kProbeStep) & map.mask;
-                        r = load_slot(map.table + hh);
+        for (int s = 0; s < kSets; s++) {
+            cnt[s] = 0;
+            slab[s] = 0;
+            if (act[s]) {
+                u32x4 r = raw[s];
+                uint32_t hh = h[s];
+                for (uint32_t probe = 0; probe <= map.mask; probe++) {
+                    const unsigned long long k = ((unsigned long long)r.y << 32) | r.x;
+                    if (k == key[s]) {
+                        cnt[s] = r.z;
+                        slab[s] = r.w;
+                        break;
                     }
+                    if (k == kEmptyKey) break;
+                    hh = (hh + 1) & map.mask;
+                    r = load_slot(map.table + hh);
                 }
-                // a neighbour voxel whose nearest face is provably farther than max_dist is not read
-                scan_cnt[s] = (lower[j] > prune_sq) ? 0u : cnt[s];
             }
+            // a neighbour voxel whose nearest face is provably farther than max_dist is not read
+            scan_cnt[s] = (lower[s] > prune_sq) ? 0u : cnt[s];
         }
         LOM_STAMP(2);  // 27 slots probed
         // ---- group-wide prefix over the neighbours in scan order ----
-        // occupied voxels (<= 27) above bit 26, stored points (<= 27 K, K < 2^16) below: one group sum for all sets
+        // occupied voxels (<= 27) above bit 26, stored points (<= 27 K, K < 2^16) below: one row sum for both sets
         uint32_t mine = 0;
 #pragma unroll
         for (int s = 0; s < kSets; s++) mine += cnt[s] | ((cnt[s] ? 1u : 0u) << 26);
-        const uint32_t tot = grp_sum<G>(mine);
+        const uint32_t tot = row_sum(mine);
         const uint32_t n_cand = tot & ((1u << 26) - 1u), n_occ = tot >> 26;
         // best starts at max_sq: "d2 < best" then implies voxel_grid.h:186's d2 < max_sq, and NaN never wins
         float best = P.max_sq;
         uint32_t best_c = 0xFFFFFFFFu, best_pi0 = 0;
+        uint32_t T;                       // points actually read
         {
             // chunks of up to four consecutive points of one voxel: nch chunks per scanned voxel
             uint32_t nch[kSets], read = 0;
 #pragma unroll
             for (int s = 0; s < kSets; s++) {
-                nch[s] = (scan_cnt[s] + 3u) >> 2;
+                nch[s] = (scan_cnt[s] + ((1u << kRowsLog2) - 1u)) >> kRowsLog2;
                 read += scan_cnt[s];
             }
-            atomicAdd(&s_cnt[grp][3], read);  // points actually read (after the exact pruning)
             uint32_t Tc = 0;  // chunks of this query
             if (map.K <= 16380u) {
-                // two sets' chunk counts in one register (G voxels x K / 4 < 2^16 each): one group scan and one
-                // broadcast per pair of sets
+                // both sets' chunk counts in one register (16 voxels x K / 4 < 2^16 each): ONE row scan, one broadcast
 #pragma unroll
                 for (int s = 0; s < kSets; s += 2) {
-                    const uint32_t inc = grp_scan_inclusive<G>(nch[s] | (nch[s + 1] << 16), m1, m2);
-                    const uint32_t last = grp_last<G>(inc);
+                    const uint32_t inc = row_scan_inclusive(nch[s] | (nch[s + 1] << 16));
+                    const uint32_t last = row_last(inc);
                     const uint32_t tot_a = last & 0xFFFFu, inc_a = Tc + (inc & 0xFFFFu), inc_b = Tc + tot_a + (inc >> 16);
-                    const uint32_t ex_a = (inc_a - nch[s]) << 2, ex_b = (inc_b - nch[s + 1]) << 2;
+                    const uint32_t ex_a = (inc_a - nch[s]) << kRowsLog2, ex_b = (inc_b - nch[s + 1]) << kRowsLog2;
                     const int b_a = gl + s * G, b_b = b_a + G;
                     s_pb[grp][b_a] = make_uint4(slab[s] * map.K - ex_a, scan_cnt[s] + ex_a, (b_a < 27) ? inc_a : 0xFFFFFFFFu, 0u);
                     s_pb[grp][b_b] =
@@ -481,13 +440,16 @@ __global__ __launch_bounds__(kMatchThreads, kMinWaves) void k_match(MapView map,
             } else {
 #pragma unroll
                 for (int s = 0; s < kSets; s++) {
-                    const uint32_t inc = grp_scan_inclusive<G>(nch[s], m1, m2);
+                    const uint32_t inc = row_scan_inclusive(nch[s]);
                     const int b = gl + s * G;
-                    const uint32_t ex = (Tc + inc - nch[s]) << 2;
+                    const uint32_t ex = (Tc + inc - nch[s]) << kRowsLog2;
                     s_pb[grp][b] = make_uint4(slab[s] * map.K - ex, scan_cnt[s] + ex, (b < 27) ? Tc + inc : 0xFFFFFFFFu, 0u);
-                    Tc += grp_last<G>(inc);
+                    Tc += row_last(inc);
                 }
             }
+            // points actually read (after the exact pruning): one more row sum (an LDS atomic per lane instead cost the
+            // kernel's tail 0.3 us: sixteen lanes on one word)
+            T = row_sum(read);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -531,7 +493,7 @@ __global__ __launch_bounds__(kMatchThreads, kMinWaves) void k_match(MapView map,
         LOM_STAMP(4);  // candidates scanned
         // lexicographic min over the group; d2 >= 0 so its bit pattern orders like the value
         unsigned long long keyv = ((unsigned long long)__float_as_uint(best) << 32) | best_c;
-        keyv = grp_min64<G>(keyv);
+        keyv = row_min64(keyv);
         const uint32_t w_c = (uint32_t)keyv;
         const bool valid = w_c != 0xFFFFFFFFu;
         LOM_STAMP(5);  // group minimum known
@@ -561,6 +523,7 @@ __global__ __launch_bounds__(kMatchThreads, kMinWaves) void k_match(MapView map,
             atomicAdd(&s_cnt[grp][0], valid ? 1u : 0u);
             atomicAdd(&s_cnt[grp][1], n_cand);
             atomicAdd(&s_cnt[grp][2], n_occ);
+            atomicAdd(&s_cnt[grp][3], T);  // candidates actually read (after the exact pruning)
         }
         LOM_STAMP(6);  // winner's normal loaded, record stored
         stamper.first_done();
@@ -1468,13 +1431,11 @@ static void pose_args(const float t[3], const float q[4], float max_dist, PoseAr
 }
 
 constexpr uint32_t kMaxMatchBlocks = 256u * (uint32_t)kMatchMinWaves;  // one resident round: kMatchMinWaves workgroups of 4 waves per CU
-constexpr int kMatch8MinWaves = 5;  // the 8-lanes-per-query variant: 94 VGPRs
-static uint32_t match_grid(uint32_t n, int lanes = kMatchG)
+static uint32_t match_grid(uint32_t n)
 {
-    const uint32_t per_block = (uint32_t)(kMatchThreads / lanes);
+    const uint32_t per_block = (uint32_t)(kMatchThreads / kMatchG);
     const uint32_t need = (n + per_block - 1) / per_block;
-    const uint32_t cap = lanes == 8 ? 256u * (uint32_t)kMatch8MinWaves : kMaxMatchBlocks;
-    return std::max(1u, std::min(need, cap));
+    return std::max(1u, std::min(need, kMaxMatchBlocks));
 }
 
 constexpr uint32_t kMaxEvalBlocks = 64;  // records per launch (the host polls this many words)
@@ -1526,11 +1487,7 @@ static int launch_match(ScanCtx &c, const float t[3], const float q[4], float ma
     PoseArgs P;
     std::memset(&P, 0, sizeof P);
     if (!chained) pose_args(t, q, max_dist, P);
-    // 8 lanes per query: two thirds of the VALU instructions per query, 94 VGPRs (5 waves per SIMD), two rounds of slot
-    // loads.  Measured in the align loop (bench.py, LOM_MATCH_LANES): C2 +4 %, C3 the same, C4 (248k points) -2.5 %:
-    // chosen from 196,608 points on unless the option says otherwise.
-    const int lanes = m->opt_match_lanes ? m->opt_match_lanes : (c.n >= 196608u ? 8 : kMatchG);
-    c.match_blocks = c.n ? match_grid(c.n, lanes) : 0;
+    c.match_blocks = c.n ? match_grid(c.n) : 0;
     server_stop(m);  // the previous outer iteration's evaluation server leaves before the new search
     const double t_launch = now_s();
     if (c.n) {
@@ -1565,12 +1522,7 @@ static int launch_match(ScanCtx &c, const float t[3], const float q[4], float ma
                                (unsigned long long *)nullptr, as);
         };
         QStat *st = (stats && !chained) ? (QStat *)m->scan_stats.p : (QStat *)nullptr;
-        if (lanes == 8) {
-            if (chained)
-                launch(k_match<8, kMatchRows, kMatch8MinWaves, false, true>, st, (const AlignState *)m->align_state.p);
-            else
-                launch(k_match<8, kMatchRows, kMatch8MinWaves>, st, (const AlignState *)nullptr);
-        } else if (chained)
+        if (chained)
             launch(k_match<kMatchG, kMatchRows, kMatchMinWaves, false, true>, st, (const AlignState *)m->align_state.p);
         else
             launch(k_match<kMatchG, kMatchRows, kMatchMinWaves>, st, (const AlignState *)nullptr);

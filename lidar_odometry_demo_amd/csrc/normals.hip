@@ -116,7 +116,7 @@ __global__ __launch_bounds__(kNrmThreads) void k_normals(MapView map, const char
                         break;
                     }
                     if (sl.key == kEmptyKey) break;
-                    h = (h + kProbeStep) & map.mask;
+                    h = (h + 1) & map.mask;
                 }
             }
         }

@@ -222,7 +222,7 @@ __device__ inline uint32_t claim_slot(Slot *table, uint32_t mask, uint32_t shift
             const unsigned long long prev = atomicCAS(&table[h].key, kEmptyKey, key);
             if (prev == kEmptyKey || prev == key) return h;
         }
-        h = (h + kProbeStep) & mask;
+        h = (h + 1) & mask;
     }
 }
 
@@ -1098,16 +1098,14 @@ static int add_points_device(lom_map *m, const char *d_xyz, const char *d_nrm, s
     if (sync_status && (!validated_on_host || multi_launch)) {
         if ((rc = map_status(m)) != LOM_OK) return rc;
     }
-    // Table size after a bulk insert: ~16 slots per voxel (load factor in (1/64, 1/16]).  With the brick-local slot hash
-    // (lom_internal.hpp) the lines a search touches are those of the occupied bricks whatever the capacity, and the
-    // bricks of one surface collide in whole parity patterns, so chains get long early: on the 2M-point map of C3 the
-    // longest chain among a query's 27 look-ups averages 2.4 slots at 4 slots per voxel, 1.6 at 8, 1.3 at 16 (what the
-    // Fibonacci hash of rounds 1-2 had at 4), and k_match takes 29.9 / - / 25.3 us.  Only a batch that made the table grow
-    // far beyond that (a bulk insert into few voxels) is worth the look at the host.
+    // Table size after a bulk insert: 16..32 slots per voxel (LOM_TABLE_SLOTS_PER_VOXEL at create).  The search's probe
+    // phase pays for every collision with a dependent round trip, and a longer table costs nothing but memory: k_match on
+    // C2 / C3 / C4 with 4 slots per voxel (rounds 1-2) 7.5 / 25.1 / 43.2 us, 8: 7.5 / 24.0 / 41.1, 16: 7.2 / 23.9 / 40.7,
+    // 32: 7.2 / 23.8 / 40.6, 64: 7.2 / 23.4 / 40.8 (same box, tools/ab_match.py).
     if (allow_shrink && N > kOnePassMax && (uint64_t)m->cap >= 16ull * std::max<uint32_t>(m->min_cap, 1u)) {
         if ((rc = refresh_nvox(m)) != LOM_OK) return rc;
-        const uint32_t target = std::max(m->min_cap, next_pow2(16ull * m->n_vox));
-        if (m->cap > 4 * target) {
+        const uint32_t target = std::max(m->min_cap, next_pow2((uint64_t)m->table_slots_per_voxel * m->n_vox));
+        if (m->cap > target) {
             if ((rc = rehash(m, target)) != LOM_OK) return rc;
         }
     }
@@ -1256,7 +1254,6 @@ int lom_scan_create(lom_map *map, lom_scan **out)
     c->device = map->device;
     c->parent = map;
     c->opt_host_lm = map->opt_host_lm;
-    c->opt_match_lanes = map->opt_match_lanes;
     c->opt_debug_lm = map->opt_debug_lm;
     c->opt_debug_timing = map->opt_debug_timing;
     c->patience_ticks = map->patience_ticks;
@@ -1321,7 +1318,7 @@ int lom_map_create(float voxel_size, size_t max_points, size_t capacity_hint, in
     m->K = (uint32_t)max_points;
     // the environment is looked at here and nowhere on the align path (lom_map_set_option changes the switches later)
     m->opt_host_lm = getenv("LOM_HOST_LM") != nullptr;
-    if (const char *e = getenv("LOM_MATCH_LANES")) m->opt_match_lanes = atoi(e) == 8 ? 8 : (atoi(e) == 16 ? 16 : 0);
+    if (const char *e = getenv("LOM_TABLE_SLOTS_PER_VOXEL")) m->table_slots_per_voxel = (uint32_t)std::min(256, std::max(2, atoi(e)));
     m->opt_debug_lm = getenv("LOM_DEBUG_LM") != nullptr;
     m->opt_debug_timing = getenv("LOM_DEBUG_TIMING") != nullptr;
     if (handle_setup(m) != LOM_OK) {
@@ -1411,10 +1408,6 @@ int lom_map_set_option(lom_map *m, int option, int64_t value)
         return LOM_OK;
     case LOM_OPT_DEBUG_LM_STAMPS: m->opt_debug_lm = value != 0; return LOM_OK;
     case LOM_OPT_DEBUG_TIMING: m->opt_debug_timing = value != 0; return LOM_OK;
-    case LOM_OPT_MATCH_LANES:
-        if (value != 0 && value != 8 && value != 16) return set_error(m, LOM_ERR_ARG, "LOM_OPT_MATCH_LANES: 0, 8 or 16");
-        m->opt_match_lanes = (int)value;
-        return LOM_OK;
     case LOM_OPT_TEST_GIVE_UP_AT_OUTER:
         if (value < -1 || value >= 35) return LOM_ERR_ARG;
         m->test_give_up_outer = (int)value;
@@ -1523,8 +1516,8 @@ int lom_profile_insert(lom_map *m, const float *d_xyz, const float *d_nrm, size_
     *total_us_out = (double)ms * 1e3;
     if ((rc = map_status(m)) != LOM_OK) return rc;
     // what lom_map_add_points_device does after a bulk insert: ~16 slots per voxel
-    const uint32_t target = std::max(m->min_cap, next_pow2(16ull * m->n_vox));
-    if (m->cap > 4 * target) return rehash(m, target);
+    const uint32_t target = std::max(m->min_cap, next_pow2((uint64_t)m->table_slots_per_voxel * m->n_vox));
+    if (m->cap > target) return rehash(m, target);
     return LOM_OK;
 }
 

@@ -23,8 +23,6 @@ for name, (nb, naz, nmap) in {"C2": (16, 1800, 500_000), "C5m": (16, 1800, 500_0
     if nmap not in maps:
         mp, mn = synth.make_map_points(nmap, boxes=boxes)
         g = lom.VoxelGrid(0.5, 20)
-        if os.environ.get("LOM_AB_LANES"):
-            g.setOption(lom.capi.OPT_MATCH_LANES, int(os.environ["LOM_AB_LANES"]))
         g.addCloud(mp, mn)
         maps[nmap] = g
     d = torch.from_numpy(scan).to("cuda:0")

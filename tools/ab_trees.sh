@@ -1,0 +1,12 @@
+#!/bin/bash
+# same-box A/B of two trees: bench C2 (no extras) alternating old/new
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+mkdir -p $R/gpurun_out/r03c
+for i in 1 2 3; do
+  for t in old new; do
+    if [ $t = old ]; then D=$R/_ab_old; else D=$R; fi
+    (cd $D && timeout -k 10 200 python bench.py --no-cpu-baseline --no-extras 2>/dev/null) > $R/gpurun_out/r03c/ab_$t.json
+    python3 -c "
+import json; d=json.load(open('$R/gpurun_out/r03c/ab_$t.json')); r=d['roofline']; print('$t', round(d['ms_per_step'],4), 'k_match', round(r['avg_launch_us'],2), 'k_lm', d.get('kernels',{}).get('k_lm',{}).get('avg_launch_us') if isinstance(d.get('kernels'),dict) else '')"
+  done
+done
