@@ -210,9 +210,8 @@ def test_large_cap_voxels(lom, oracle):
 
 
 def test_lattice_of_equal_parities(lom, oracle):
-    """Every voxel index even: all voxels share one home position inside their table bucket (the slot hash places a
-    voxel by the parities of its index, lom_internal.hpp) -- the probe sequence has to spread them over the table;
-    then a second batch at odd indices.  Map and pairs against the oracle."""
+    """A regular lattice: every voxel index even (then a second batch at odd indices) -- keys that differ in few bits
+    are what a multiplicative slot hash has to spread over the table.  Map and pairs against the oracle."""
     g, og = _both(lom, oracle, 0.5, 4)
     ax = np.arange(-24, 24, dtype=np.float32)                        # 48^3 = 110,592 voxels, index = 2 * k
     pts = np.stack(np.meshgrid(ax, ax, ax, indexing="ij"), -1).reshape(-1, 3) + np.float32(0.1)
