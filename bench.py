@@ -284,9 +284,10 @@ def match_roofline(n_queries, alg_per_launch, req_per_launch, avg_us, traffic, t
         "hbm_measured_gbs": (traffic / (avg_us * 1e-6) / 1e9 if traffic else None),
         "hbm_measured_frac": (traffic / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS if traffic else None),
         "kernel_only_mcorr_s": n_queries / (avg_us * 1e-6) / 1e6,
-        "limited_by": "latency and VALU issue, not HBM: the map (payload + table) is L2 / Infinity-Cache resident, a query is "
-                      "a chain of dependent round trips (source point, 27 slots, candidates, winner's normal); SQ counters in "
-                      "profiles/ (waves 60-70 % in s_waitcnt; on the 2M-point map VALU issue ~80 % of the SIMD cycles)",
+        "limited_by": "the length of the dependent chain per query, not HBM: the map (payload + table) is L2 / Infinity-Cache "
+                      "resident, a query is source point -> 27 slots -> chunks of candidate rows -> winner's point and normal; "
+                      "counters in profiles/ (waves 60-70 % in s_waitcnt; on the 2M-point map ~100 VALU instructions and ~70 "
+                      "vector-L1 tag accesses per query, each cut by 11-17 % in round 3 with the time unmoved: DESIGN.md section 5)",
     }
     if req_per_launch:
         roof["cache_level"] = {
