@@ -83,7 +83,7 @@ void lom_map_destroy(lom_map *m);
 const char *lom_last_error(const lom_map *m); /* NULL handle: error of the last failed create */
 
 int lom_map_clear(lom_map *m, float voxel_size);            /* setVoxelSize, :61-66 (clears) */
-int lom_map_set_max_points(lom_map *m, size_t max_points);  /* setMaxPoints, :56-59; only while empty */
+int lom_map_set_max_points(lom_map *m, size_t max_points);  /* setMaxPoints, :56-59; at any time: stored voxels keep what they hold (:86-90) */
 /* addCloud (:77-93) when nrm != NULL, addCloudWithoutNormals (:95-110) when nrm == NULL.
  * Deterministic: a voxel keeps the first max_points points in call/input order. */
 int lom_map_add_points(lom_map *m, const float *xyz, const float *nrm, size_t n, size_t stride_bytes);

@@ -139,7 +139,8 @@ struct lom_map {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     float voxel_size = 0.5f;
-    uint32_t K = 10;
+    uint32_t K = 10;          // row stride of the slabs: the largest max_points_ the stored voxels have seen
+    uint32_t max_points = 10; // max_points_ (voxel_grid.h:253): what an insert fills a voxel up to; <= K
 
     // hash table
     lom::Slot *d_table = nullptr;

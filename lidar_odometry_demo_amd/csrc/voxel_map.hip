@@ -562,9 +562,9 @@ __global__ __launch_bounds__(kThreads) void k_ins_place2(Slot *table, uint32_t n
                                                          const uint32_t *__restrict__ pt_m, uint32_t *bkt_cnt,
                                                          uint32_t *bkt_head, const uint32_t *__restrict__ bkt_old,
                                                          const uint32_t *__restrict__ items, const char *xyz,
-                                                         const char *nrm, size_t stride, uint32_t K, float *pts,
-                                                         float *nrm_out, uint32_t *slab_count, uint32_t *n_vox_dev,
-                                                         uint32_t seq, const uint32_t *words)
+                                                         const char *nrm, size_t stride, uint32_t K, uint32_t cap_points,
+                                                         float *pts, float *nrm_out, uint32_t *slab_count,
+                                                         uint32_t *n_vox_dev, uint32_t seq, const uint32_t *words)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -583,8 +583,10 @@ __global__ __launch_bounds__(kThreads) void k_ins_place2(Slot *table, uint32_t n
         const uint32_t old = bkt_old[h];
         const uint32_t slab = table[h].slab;
         const uint32_t m = pt_m[i];
-        if (old < K) {
-            const uint32_t room = K - old;
+        // voxel_grid.h:86,89-90: a voxel takes points while size() < max_points_ (cap_points; the row stride K is at least
+        // that, and a voxel filled under a larger max_points_ keeps what it holds)
+        const uint32_t room = cap_points > old ? cap_points - old : 0u;
+        if (room) {
             const uint32_t *it = items + pt_off[i];
             uint32_t rank = 0;
             for (uint32_t j = 0; j < m && rank < room; j++) rank += it[j] < i;
@@ -598,8 +600,7 @@ __global__ __launch_bounds__(kThreads) void k_ins_place2(Slot *table, uint32_t n
             }
         }
         if (is_head) {
-            const uint32_t want = old + m;
-            const uint32_t nc = want < K ? want : K;
+            const uint32_t nc = old + (m < room ? m : room);
             table[h].count = nc;
             slab_count[slab] = nc;
         }
@@ -1090,7 +1091,7 @@ static int add_points_device(lom_map *m, const char *d_xyz, const char *d_nrm, s
     }
     hipLaunchKernelGGL(k_ins_scatter2, g, b, 0, m->stream, N, pt_slot, pt_pos, boff, bcnt, items, pt_off, pt_m, seq, words);
     hipLaunchKernelGGL(k_ins_place2, g, b, 0, m->stream, m->d_table, N, pt_slot, pt_off, pt_m, bcnt, bhead, bold, items,
-                       d_xyz, d_nrm, stride, m->K, m->d_pts, m->d_nrm, m->d_slab_count, d_nvox(m), seq, words);
+                       d_xyz, d_nrm, stride, m->K, m->max_points, m->d_pts, m->d_nrm, m->d_slab_count, d_nvox(m), seq, words);
     LOM_HIP(m, hipGetLastError());
     m->table_clean = false;
     m->n_vox_ub = (uint32_t)std::min<uint64_t>(worst, 0xFFFFFFFFull);
@@ -1316,6 +1317,7 @@ int lom_map_create(float voxel_size, size_t max_points, size_t capacity_hint, in
     m->device = device;
     m->voxel_size = voxel_size;
     m->K = (uint32_t)max_points;
+    m->max_points = m->K;
     // the environment is looked at here and nowhere on the align path (lom_map_set_option changes the switches later)
     m->opt_host_lm = getenv("LOM_HOST_LM") != nullptr;
     if (const char *e = getenv("LOM_TABLE_SLOTS_PER_VOXEL")) m->table_slots_per_voxel = (uint32_t)std::min(256, std::max(2, atoi(e)));
@@ -1447,31 +1449,75 @@ int lom_map_clear(lom_map *m, float voxel_size)
     return LOM_OK;
 }
 
+// rows of every live slab from stride K0 to stride K1 > K0 (setMaxPoints raised on a map that holds voxels)
+__global__ void k_restride(const float *pts0, const float *nrm0, const uint32_t *slab_count, uint32_t n_vox, uint32_t K0,
+                           uint32_t K1, float *pts1, float *nrm1)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t slab = (uint32_t)(i / K0), row = (uint32_t)(i % K0);
+    if (slab >= n_vox || row >= slab_count[slab]) return;
+    const size_t src = ((size_t)slab * K0 + row) * 3, dst = ((size_t)slab * K1 + row) * 3;
+    store3(pts1 + dst, load3(pts0 + src));
+    store3(nrm1 + dst, load3(nrm0 + src));
+}
+
 int lom_map_set_max_points(lom_map *m, size_t max_points)
 {
     if (!m || max_points == 0 || max_points > 65535) return LOM_ERR_ARG;
-    if (max_points == m->K) return LOM_OK;
+    if (m->parent) return set_error(m, LOM_ERR_ARG, "a scan context cannot change its keyframe");
     LOM_HIP(m, hipSetDevice(m->device));
     {
-        const int rcn = refresh_nvox(m);
+        const int rcn = refresh_nvox(m);  // also resolves a pending insert: it was made under the old value
         if (rcn != LOM_OK) return rcn;
     }
-    if (m->n_vox != 0) return set_error(m, LOM_ERR_STATE, "max_points can only change while the map is empty");
-    LOM_HIP(m, hipSetDevice(m->device));
-    LOM_HIP(m, hipStreamSynchronize(m->stream));
-    Slabs s{m->d_slab_key, m->d_slab_count, m->d_pts, m->d_nrm};
-    slabs_free(s);
-    Slabs alt{m->alt_key, m->alt_count, m->alt_pts, m->alt_nrm};
-    slabs_free(alt);
-    m->alt_key = nullptr;
-    m->alt_count = nullptr;
-    m->alt_pts = m->alt_nrm = nullptr;
-    m->alt_cap = 0;
-    m->d_slab_key = nullptr;
-    m->d_slab_count = nullptr;
-    m->d_pts = m->d_nrm = nullptr;
-    m->slab_cap = 0;
-    m->K = (uint32_t)max_points;
+    // voxel_grid.h:56-59: max_points_ = max_points, nothing else -- stored voxels keep what they hold, and :86-90
+    // appends to a voxel only while size() < max_points_.  The row stride K follows the largest value seen while
+    // voxels exist (a raise re-strides the slabs); an empty map starts over with stride = max_points.
+    if (m->n_vox == 0 && max_points != m->K) {
+        LOM_HIP(m, hipStreamSynchronize(m->stream));
+        Slabs s{m->d_slab_key, m->d_slab_count, m->d_pts, m->d_nrm};
+        slabs_free(s);
+        Slabs alt{m->alt_key, m->alt_count, m->alt_pts, m->alt_nrm};
+        slabs_free(alt);
+        m->alt_key = nullptr;
+        m->alt_count = nullptr;
+        m->alt_pts = m->alt_nrm = nullptr;
+        m->alt_cap = 0;
+        m->d_slab_key = nullptr;
+        m->d_slab_count = nullptr;
+        m->d_pts = m->d_nrm = nullptr;
+        m->slab_cap = 0;
+        m->K = (uint32_t)max_points;
+    } else if (max_points > m->K) {
+        if ((uint64_t)m->slab_cap > 0x7FFFFFFFull / max_points) return set_error(m, LOM_ERR_OOM, "map too large");
+        m->mutations++;
+        const uint32_t K0 = m->K, K1 = (uint32_t)max_points;
+        const size_t pb = (size_t)m->slab_cap * K1 * 3 * sizeof(float);
+        float *p1 = nullptr, *n1 = nullptr;
+        if (hipMalloc(&p1, pb + kRowPadBytes) != hipSuccess || hipMalloc(&n1, pb + kRowPadBytes) != hipSuccess) {
+            (void)hipGetLastError();
+            if (p1) (void)hipFree(p1);
+            return set_error(m, LOM_ERR_OOM, "hipMalloc(slabs)");
+        }
+        const size_t work = (size_t)m->n_vox * K0;
+        hipLaunchKernelGGL(k_restride, dim3(blocks_for(work)), dim3(kThreads), 0, m->stream, m->d_pts, m->d_nrm,
+                           m->d_slab_count, m->n_vox, K0, K1, p1, n1);
+        LOM_HIP(m, hipGetLastError());
+        LOM_HIP(m, hipStreamSynchronize(m->stream));
+        (void)hipFree(m->d_pts);
+        (void)hipFree(m->d_nrm);
+        m->d_pts = p1;
+        m->d_nrm = n1;
+        // the cleanup's second set of slabs has the old stride: it is allocated again when needed
+        Slabs alt{m->alt_key, m->alt_count, m->alt_pts, m->alt_nrm};
+        slabs_free(alt);
+        m->alt_key = nullptr;
+        m->alt_count = nullptr;
+        m->alt_pts = m->alt_nrm = nullptr;
+        m->alt_cap = 0;
+        m->K = K1;
+    }
+    m->max_points = (uint32_t)max_points;
     return LOM_OK;
 }
 

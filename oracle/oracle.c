@@ -188,7 +188,8 @@ void orc_transform_points(const orc_pose *pose, const float *xyz_in, const float
 
 struct orc_map {
     float voxel_size; /* voxel_grid.h:254 */
-    size_t K;         /* max_points_, voxel_grid.h:253 */
+    size_t K;         /* row stride of the payload arrays: the largest max_points_ a stored voxel has seen */
+    size_t max_points; /* max_points_, voxel_grid.h:253 (<= K) */
     size_t n_vox, cap_vox;
     int64_t *keys;   /* 3 per voxel: Indices{ix,iy,iz}, voxel_grid.h:20-23 */
     uint32_t *count; /* points_with_normals.size() */
@@ -281,6 +282,7 @@ orc_map *orc_map_create(float voxel_size, size_t max_points)
     if (!m) return NULL;
     m->voxel_size = voxel_size;
     m->K = max_points;
+    m->max_points = max_points;
     if (map_rehash(m, 4096) != ORC_OK) {
         free(m);
         return NULL;
@@ -311,21 +313,45 @@ int orc_map_clear(orc_map *m, float voxel_size)
 
 int orc_map_set_max_points(orc_map *m, size_t max_points)
 {
-    /* voxel_grid.h:56-59.  The payload stride is K, so a change is only
-     * supported while the map is empty (the reference's callers set it once,
-     * lidar_odometry.cpp:18-19). */
+    /* voxel_grid.h:56-59: max_points_ = max_points, nothing else -- stored voxels keep what they hold, and
+     * :86-90 appends to a voxel only while size() < max_points_.  The payload stride K follows the largest
+     * value seen while voxels exist (a raise re-strides the arrays); an empty map starts over. */
     if (!m || max_points == 0) return ORC_ERR_ARG;
-    if (max_points == m->K) return ORC_OK;
-    if (m->n_vox != 0) return ORC_ERR_ARG;
-    m->K = max_points;
-    free(m->pts);
-    free(m->nrm);
-    free(m->keys);
-    free(m->count);
-    m->pts = m->nrm = NULL;
-    m->keys = NULL;
-    m->count = NULL;
-    m->cap_vox = 0;
+    if (m->n_vox == 0) {
+        if (max_points != m->K) {
+            free(m->pts);
+            free(m->nrm);
+            free(m->keys);
+            free(m->count);
+            m->pts = m->nrm = NULL;
+            m->keys = NULL;
+            m->count = NULL;
+            m->cap_vox = 0;
+            m->K = max_points;
+        }
+        m->max_points = max_points;
+        return ORC_OK;
+    }
+    if (max_points > m->K) {
+        const size_t oldK = m->K, newK = max_points;
+        float *p = (float *)malloc(m->cap_vox * newK * 3 * sizeof(float));
+        float *nn = (float *)malloc(m->cap_vox * newK * 3 * sizeof(float));
+        if (!p || !nn) {
+            free(p);
+            free(nn);
+            return ORC_ERR_OOM;
+        }
+        for (size_t v = 0; v < m->n_vox; v++) {
+            memcpy(p + v * newK * 3, m->pts + v * oldK * 3, (size_t)m->count[v] * 3 * sizeof(float));
+            memcpy(nn + v * newK * 3, m->nrm + v * oldK * 3, (size_t)m->count[v] * 3 * sizeof(float));
+        }
+        free(m->pts);
+        free(m->nrm);
+        m->pts = p;
+        m->nrm = nn;
+        m->K = newK;
+    }
+    m->max_points = max_points;
     return ORC_OK;
 }
 
@@ -362,7 +388,7 @@ int orc_map_add_points(orc_map *m, const float *xyz, const float *nrm, size_t n,
             m->keys[3 * v + 2] = iz;
             m->count[v] = 0;
             map_index_put(m, v);
-        } else if (m->count[v] >= K) { /* :89 size() < max_points_ */
+        } else if (m->count[v] >= m->max_points) { /* :89 size() < max_points_ */
             continue;
         }
         const size_t j = m->count[v]++;

@@ -271,13 +271,53 @@ def test_out_of_range_rejected_and_nothing_inserted(lom):
 def test_set_voxel_size_clears_and_set_max_points(lom):
     g = lom.VoxelGrid(0.5, 1)
     g.addCloudWithoutNormals(scenes.UNIQUE_POINTS)
-    with pytest.raises(lom.LomError):
-        g.setMaxPoints(5)                      # only while empty
     g.setVoxelSize(0.25)                       # voxel_grid.h:61-66
     assert g.size() == 0 and g.pointCount() == 0
     g.setMaxPoints(5)
     g.addCloudWithoutNormals(np.repeat(scenes.UNIQUE_POINTS, 7, axis=0))
     assert g.size() == 7 and g.pointCount() == 35
+
+
+def test_set_max_points_on_a_map_that_holds_voxels(lom, oracle):
+    """voxel_grid.h:56-59 sets max_points_ and nothing else: stored voxels keep what they hold, and :86-90 appends
+    to a voxel only while size() < max_points_.  Raise (the slabs are re-strided), lower below what voxels already
+    hold, raise again, with inserts, a cleanup and searches in between -- map, pairs and an align against the oracle."""
+    rng = np.random.default_rng(31)
+    g, og = _both(lom, oracle, 0.5, 3)
+    centers = rng.uniform(-4, 4, (30, 3))
+
+    def batch(n):
+        pts = (centers[rng.integers(0, len(centers), n)] + rng.normal(0, 0.5, (n, 3))).astype(np.float32)
+        nrm = scenes._unit(rng.standard_normal((n, 3))).astype(np.float32)
+        g.addCloud(pts, nrm)
+        og.addCloud(pts, nrm)
+        _assert_same_map(g, og)
+
+    batch(4000)
+    full3 = g.pointCount()
+    for k in (9, 2, 2, 6, 40, 1):
+        g.setMaxPoints(k)
+        og.setMaxPoints(k)
+        _assert_same_map(g, og)                      # the call itself changes nothing
+        before = g.pointCount()
+        batch(3000)
+        if k <= 3:
+            assert g.pointCount() - before <= 3000   # only new voxels (and those below k) take points
+        if k == 6:
+            c = np.array((0.5, -0.5, 0.2), np.float32)
+            g.radiusCleanup(c, 4.0)
+            og.radiusCleanup(c, 4.0)
+            _assert_same_map(g, og)
+    assert g.pointCount() > full3
+    q = (centers[rng.integers(0, len(centers), 1500)] + rng.normal(0, 0.5, (1500, 3))).astype(np.float32)
+    pose = ((0.02, -0.03, 0.01), scenes.angle_axis_q(0.01, (0, 0, 1)))
+    for d in (0.3, 1.0):
+        _assert_same_pairs(g.findMatchingPairs(q, lom.Pose3D(*pose), d), og.findMatchingPairs(q, oracle.Pose3D(*pose), d))
+    m, om = lom.CloudMatcher(), oracle.CloudMatcher()
+    p = m.align(g, q, lom.Pose3D(*pose))
+    r = om.align(og, q, oracle.Pose3D(*pose))
+    dt, dr = scenes.pose_delta(p.translation, p.rotation, r.translation, r.rotation)
+    assert dt < POSE_TOL_M and dr < POSE_TOL_RAD and m.stats["outer_iterations"] == om.stats["outer_iterations"]
 
 
 def test_radius_cleanup_parity(lom, oracle, fixture_cloud):

@@ -173,6 +173,33 @@ def test_set_voxel_size_clears(oracle):
     assert g.size() == 0 and g.pointCount() == 0
 
 
+def test_set_max_points_at_any_time_against_a_model_of_the_header(oracle):
+    """voxel_grid.h:56-59 (`max_points_ = max_points`) and :79-92 (a new voxel always takes its first point, an
+    existing one only while `size() < max_points_`), restated here as a dict of lists and run beside the oracle
+    through raises and drops of the limit on a map that holds voxels.  Voxel order = order of first appearance."""
+    rng = np.random.default_rng(8)
+    g = oracle.VoxelGrid(0.5, 2)
+    model, order, limit = {}, [], 2
+    centers = rng.uniform(-3, 3, (12, 3))
+    for k in (None, 5, 1, 1, 3, 30, 2):
+        if k is not None:
+            g.setMaxPoints(k)
+            limit = k
+        pts = (centers[rng.integers(0, len(centers), 700)] + rng.normal(0, 0.4, (700, 3))).astype(np.float32)
+        g.addCloudWithoutNormals(pts)
+        for p in pts:
+            key = tuple(int(np.float32(c) / np.float32(0.5)) for c in p)  # :70-72 f32 division, truncation
+            if key not in model:
+                model[key] = [p]
+                order.append(key)
+            elif len(model[key]) < limit:
+                model[key].append(p)
+        want = np.concatenate([np.stack(model[key]) for key in order])
+        assert g.size() == len(order)
+        assert g.getCloudWithoutNormals().tobytes() == want.astype(np.float32).tobytes()
+    assert max(len(v) for v in model.values()) > 5 and min(len(v) for v in model.values()) >= 1
+
+
 def test_zero_normals_are_valid_matches(oracle):
     # Appendix A.12: addCloudWithoutNormals stores (0,0,0) normals; matches stay valid
     g = oracle.VoxelGrid(0.5, 20)
