@@ -348,7 +348,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
-                    help="default run only: skip the short C3 block and the 200-frame C5 block attached as extra_configs")
+                    help="default run only: skip the short C3 / C4 blocks and the 200-frame C5 block attached as extra_configs")
     ap.add_argument("--config", choices=["C2", "C3", "C4", "C5"], default="C2",
                     help="C2 = BASELINE.json configs[1] (the bench line; weak-scaled with --gpus N); C3 = configs[2], "
                          "single GPU only; C4 = configs[3], 128x2048 scan range-sharded over --gpus N ranks (any N "
@@ -699,9 +699,21 @@ def main():
             try:
                 w3 = build_workload(1, 0, "C3")
                 extras["C3"] = align_block(lom, torch, w3, dev, steps=max(20, args.steps // 4))
-                del w3
             except Exception as e:  # noqa: BLE001  (an extra must not cost the line)
+                w3 = None
                 extras["C3"] = {"error": repr(e)[:300]}
+            try:
+                # C4 on this one GPU: the same 2M-point map, the 128-beam scan (the N > 1 run shards this scan)
+                from lidar_odometry_demo_amd import synth
+                scan4, _, _, _ = synth.make_scan(128, 2048, boxes=synth.make_boxes())
+                w4 = (dict(w3, scan=scan4, shard=scan4,
+                           name=f"C4 (BASELINE configs[3]) on one GPU: 128x2048 scan ({len(scan4)} returns) vs 2M-pt map, "
+                                f"voxel 0.5 m, cap 20") if w3 is not None else build_workload(1, 0, "C4"))
+                extras["C4"] = align_block(lom, torch, w4, dev, steps=max(20, args.steps // 4), warmup_aligns=100)
+                del w4
+            except Exception as e:  # noqa: BLE001
+                extras["C4"] = {"error": repr(e)[:300]}
+            w3 = None
             try:
                 c5 = streaming(args, lom, steps=200, warmup=10, cpu_frames=0)
                 extras["C5"] = {"workload": c5["config"]["workload"], "frames": 200, "ms_per_frame": c5["ms_per_step"],
