@@ -902,7 +902,7 @@ __device__ __forceinline__ void reduce_and_exchange(const double acc[28], double
                                                     uint32_t n_match_blocks, XWord *set, uint32_t nb,
                                                     unsigned long long seq, unsigned long long timeout_ticks,
                                                     double *s_tot, int *s_failed, const int32_t *chain_error,
-                                                    unsigned long long *dbg = nullptr)
+                                                    const uint4 pre, unsigned long long *dbg = nullptr)
 {
 #define RX_STAMP(k)                                                     \
     if (dbg && blockIdx.x == 0 && threadIdx.x == 0) {                   \
@@ -936,26 +936,46 @@ __device__ __forceinline__ void reduce_and_exchange(const double acc[28], double
 #pragma unroll
         for (int k = 0; k < 7; k++) dst[k] = s2[k];
     }
-    if (wave == kT / 64 - 1) {  // the workgroup's slice of k_match's counters
-        unsigned long long c0 = 0, c1 = 0, c2 = 0;
+    if (wave == kT / 64 - 1) {  // the workgroup's slice of k_match's counters (first evaluation of a launch only)
+        // the slice of a workgroup is at most one block per lane when k_lm runs 28 workgroups or more: the caller
+        // then loaded this lane's block with the kernel's start-up loads (`pre`); counts are exact in f64, and the
+        // wave sum is the permlane-swap / DPP fold of the residual sums (36 LDS-crossbar shuffles in round 2)
+        double d0 = 0.0, d1 = 0.0, d2 = 0.0;
         if (n_match_blocks) {
             const uint32_t chunk = (n_match_blocks + gridDim.x - 1) / gridDim.x;
-            const uint32_t lo = blockIdx.x * chunk;
-            const uint32_t hi = min(lo + chunk, n_match_blocks);
-            for (uint32_t b = lo + lane; b < hi; b += 64) {
-                const uint4 r = *reinterpret_cast<const uint4 *>(block_counters + (size_t)b * 4);
-                c0 += r.x;
-                c1 += r.y;
-                c2 += r.z;
+            if (chunk <= 64u) {
+                uint4 r = pre;
+                if constexpr (kT != 256) {  // (the 512-thread shapes have no registers to spare for the early load)
+                    const uint32_t b = blockIdx.x * chunk + (uint32_t)lane;
+                    r = make_uint4(0u, 0u, 0u, 0u);
+                    if ((uint32_t)lane < chunk && b < n_match_blocks) r = *reinterpret_cast<const uint4 *>(block_counters + (size_t)b * 4);
+                }
+                d0 = (double)r.x;
+                d1 = (double)r.y;
+                d2 = (double)r.z;
+            } else {
+                const uint32_t lo = blockIdx.x * chunk;
+                const uint32_t hi = min(lo + chunk, n_match_blocks);
+                unsigned long long c0 = 0, c1 = 0, c2 = 0;
+                for (uint32_t b = lo + lane; b < hi; b += 64) {
+                    const uint4 r = *reinterpret_cast<const uint4 *>(block_counters + (size_t)b * 4);
+                    c0 += r.x;
+                    c1 += r.y;
+                    c2 += r.z;
+                }
+                d0 = (double)c0;
+                d1 = (double)c1;
+                d2 = (double)c2;
             }
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) {
-                c0 += __shfl_xor(c0, d, 64);
-                c1 += __shfl_xor(c1, d, 64);
-                c2 += __shfl_xor(c2, d, 64);
-            }
+            // rows after the two swaps: 0 = d0, 1 = d2, 2 = d1, 3 = nothing; four butterflies finish each row
+            double v = swap_add<16>(swap_add<32>(d0, d1), swap_add<32>(d2, 0.0));
+            v += dpp_f64<kDppXor1>(v);
+            v += dpp_f64<kDppXor2>(v);
+            v += dpp_f64<kDppHalfMirror>(v);
+            v += dpp_f64<kDppMirror>(v);
+            d0 = v;
         }
-        if (lane < 3) xword_store(mine + 28 + lane, (double)(lane == 0 ? c0 : (lane == 1 ? c1 : c2)), seq);
+        if (lane == 0 || lane == 16 || lane == 32) xword_store(mine + 28 + (lane == 0 ? 0 : (lane == 32 ? 1 : 2)), d0, seq);
     }
     __syncthreads();
     if (tid < 28) {  // the eight waves' totals, in wave order
@@ -1251,6 +1271,14 @@ __global__ __launch_bounds__(kT) void k_lm(const MatchRec *__restrict__ rec, uin
             rc[p] = r4[2];
         }
     }
+    // ... and, in the last wave, this lane's block of k_match's counters (reduce_and_exchange folds them)
+    uint4 cnt_pre = make_uint4(0u, 0u, 0u, 0u);
+    if (kT == 256 && wave == kT / 64 - 1 && n_match_blocks) {
+        const uint32_t chunk = (n_match_blocks + nb - 1) / nb;
+        const uint32_t b = blockIdx.x * chunk + (uint32_t)lane;
+        if (chunk <= 64u && (uint32_t)lane < chunk && b < n_match_blocks)
+            cnt_pre = *reinterpret_cast<const uint4 *>(block_counters + (size_t)b * 4);
+    }
     float x0 = 0.f;
     if (tid < 7) {
         if (first_outer)
@@ -1281,7 +1309,7 @@ __global__ __launch_bounds__(kT) void k_lm(const MatchRec *__restrict__ rec, uin
         seq++;
         XWord *set = xrec + (size_t)(seq & 1) * kMaxLmBlocksBig * kRecWords;
         reduce_and_exchange<kT, kBlocks>(acc, s_acc, s_part, block_counters, counters_from, set, nb, seq, timeout_ticks,
-                            s_tot, &s_failed, &state->error,
+                            s_tot, &s_failed, &state->error, cnt_pre,
                             (dbg_stamps && first_outer && ev == 1) ? dbg_stamps + 32 : nullptr);
         counters_from = 0;
         if (px.nranks > 1 && wave == 0 && !s_failed) {
