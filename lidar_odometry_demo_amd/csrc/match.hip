@@ -1286,7 +1286,24 @@ __global__ __launch_bounds__(kT) void k_lm(const MatchRec *__restrict__ rec, uin
         else
             x0 = tid < 4 ? state->pose_q[tid] : state->pose_t[tid - 4];
     }
-    if (!first_outer && (state->finished | state->error)) return;  // chained launch after the end
+    // the previous outer iteration's tallies, read now (scalar loads, with everything else that starts the kernel) for
+    // workgroup 0's write-back at the very end: read there they were one more memory round trip on the critical path
+    typedef const __attribute__((address_space(4))) AlignState *ConstState;
+    struct {
+        int32_t outer_done, lm_iterations, evaluations;
+        double valid_total, cand_total, occ_total, queries_total;
+    } prev = {0, 0, 0, 0.0, 0.0, 0.0, 0.0};
+    if (!first_outer) {
+        ConstState cs = (ConstState)state;
+        prev.outer_done = cs->outer_done;
+        prev.lm_iterations = cs->lm_iterations;
+        prev.evaluations = cs->evaluations;
+        prev.valid_total = cs->valid_total;
+        prev.cand_total = cs->cand_total;
+        prev.occ_total = cs->occ_total;
+        prev.queries_total = cs->queries_total;
+        if (cs->finished | cs->error) return;  // chained launch after the end
+    }
     if (tid < 7) s_x[tid] = (double)x0;  // cloud_matcher.cpp:122-131
     if (tid == 0) s_failed = test_give_up;  // LOM_OPT_TEST_GIVE_UP_AT_OUTER: this launch behaves as if its waits had timed out
     __syncthreads();
@@ -1364,7 +1381,7 @@ __global__ __launch_bounds__(kT) void k_lm(const MatchRec *__restrict__ rec, uin
     if (blockIdx.x != 0 || tid != 0) return;
     // ---- end of the outer iteration (workgroup 0, one lane) ----
     const LmShared &S = s_lm;
-    const int outer = first_outer ? 0 : state->outer_done;
+    const int outer = prev.outer_done;
     float pq[4], pt[3];
     for (int a = 0; a < 4; a++) pq[a] = (float)S.x[a];      // :161-164
     for (int a = 0; a < 3; a++) pt[a] = (float)S.x[4 + a];  // :165-167
@@ -1380,14 +1397,14 @@ __global__ __launch_bounds__(kT) void k_lm(const MatchRec *__restrict__ rec, uin
     st.finished = finished;
     st.error = 0;
     st.outer_done = outer + 1;
-    st.lm_iterations = (first_outer ? 0 : state->lm_iterations) + S.recorded;
-    st.evaluations = (first_outer ? 0 : state->evaluations) + S.evaluations;
+    st.lm_iterations = prev.lm_iterations + S.recorded;
+    st.evaluations = prev.evaluations + S.evaluations;
     st.pad = 0;
     st.valid_last = counters[0];
-    st.valid_total = (first_outer ? 0.0 : state->valid_total) + counters[0];
-    st.cand_total = (first_outer ? 0.0 : state->cand_total) + counters[1];
-    st.occ_total = (first_outer ? 0.0 : state->occ_total) + counters[2];
-    st.queries_total = (first_outer ? 0.0 : state->queries_total) + counters[3];
+    st.valid_total = prev.valid_total + counters[0];
+    st.cand_total = prev.cand_total + counters[1];
+    st.occ_total = prev.occ_total + counters[2];
+    st.queries_total = prev.queries_total + counters[3];
     st.final_cost = S.cost;
     st.last_step_norm = S.last_step_norm;
     *state = st;
