@@ -1002,7 +1002,8 @@ __device__ __forceinline__ void reduce_and_exchange(const double acc[28], double
         // no head start 0.1724 ms per align, s_sleep 8 / 12 / 16 / 20 / 24 -> 0.1668 / 0.1657 / 0.1645 /
         // 0.1650 / 0.1650; again after the round-2 reduction: 4 / 8 / 12 / 16 / 24 -> 0.1580 / 0.1562 / 0.1545 /
         // 0.1539 / 0.1548; round 3 (256-thread workgroups, two points per lane): 4 / 8 / 12 / 16 / 20 / 24 / 32 ->
-        // 0.1349 / 0.1333 / 0.1315 / 0.1312 / 0.1325 / 0.1343 / 0.1366.
+        // 0.1349 / 0.1333 / 0.1315 / 0.1312 / 0.1325 / 0.1343 / 0.1366; at the end of round 3: 10 / 13 / 16 / 20 ->
+        // 0.1355 / 0.1342 / 0.1332 / 0.1328.
         __builtin_amdgcn_s_sleep(16);
         const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
         uint32_t polls = 0;
