@@ -231,6 +231,35 @@ def test_lattice_of_equal_parities(lom, oracle):
         _assert_same_pairs(g.findMatchingPairs(q, lom.Pose3D(), d), og.findMatchingPairs(q, oracle.Pose3D(), d))
 
 
+@pytest.mark.parametrize("slots", [2, 64])
+def test_table_size_never_changes_results(lom, oracle, monkeypatch, slots):
+    """LOM_TABLE_SLOTS_PER_VOXEL (read at create) sizes the slot table after a bulk insert: 2 slots per voxel means long
+    probe chains in the search and in later inserts, 64 a table mostly empty.  Map, pairs and an align against the
+    oracle either way."""
+    monkeypatch.setenv("LOM_TABLE_SLOTS_PER_VOXEL", str(slots))
+    rng = np.random.default_rng(91)
+    g, og = _both(lom, oracle, 0.25, 6)
+    centers = rng.uniform(-8, 8, (400, 3))
+    pts = (centers[rng.integers(0, len(centers), 90000)] + rng.normal(0, 0.6, (90000, 3))).astype(np.float32)   # bulk: > 65536
+    nrm = scenes._unit(rng.standard_normal(pts.shape)).astype(np.float32)
+    g.addCloud(pts, nrm)
+    og.addCloud(pts, nrm)
+    _assert_same_map(g, og)
+    more = np.ascontiguousarray(pts[::9] + np.float32(0.3))          # a small batch into the (possibly dense) table
+    g.addCloudWithoutNormals(more)
+    og.addCloudWithoutNormals(more)
+    _assert_same_map(g, og)
+    q = (centers[rng.integers(0, len(centers), 6000)] + rng.normal(0, 0.7, (6000, 3))).astype(np.float32)
+    pose = ((0.03, -0.02, 0.01), scenes.angle_axis_q(0.015, (0, 0, 1)))
+    for d in (0.3, 1.0):
+        _assert_same_pairs(g.findMatchingPairs(q, lom.Pose3D(*pose), d), og.findMatchingPairs(q, oracle.Pose3D(*pose), d))
+    m, om = lom.CloudMatcher(), oracle.CloudMatcher()
+    p = m.align(g, q, lom.Pose3D(*pose))
+    r = om.align(og, q, oracle.Pose3D(*pose))
+    dt, dr = scenes.pose_delta(p.translation, p.rotation, r.translation, r.rotation)
+    assert dt < POSE_TOL_M and dr < POSE_TOL_RAD and m.stats["outer_iterations"] == om.stats["outer_iterations"]
+
+
 def test_more_than_a_million_voxels(lom, oracle):
     """A map beyond 16 x 65536 voxels: the cleanup's multi-launch scan (its in-kernel scan covers 1,048,576), table
     growth while inserting, bulk inserts of more than 65536 points, a second batch over the first; bytewise against
