@@ -1007,8 +1007,16 @@ __device__ __forceinline__ void reduce_and_exchange(const double acc[28], double
         __builtin_amdgcn_s_sleep(16);
         const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
         uint32_t polls = 0;
+        // a patience shorter than the head start just slept (16 x 64 cycles, > 0.4 us = 40 ticks of 10 ns) cannot be
+        // met whatever the first poll finds: the wait counts as timed out -- which is what makes a 1-tick patience a
+        // deterministic way to force the give-up path (tests), not a race against the other workgroups' stores
+        if (timeout_ticks < 40ull) {
+            *s_failed = 1;
+#pragma unroll
+            for (int u = 0; u < kPer; u++) ok[u] = true;
+        }
         const XWord *mine_src = set + (size_t)(g * kPer) * kRecWords + k;  // (a set holds kMaxLmBlocksBig records: in bounds)
-        for (;;) {
+        for (; timeout_ticks >= 40ull;) {
             u64x2 r[kPer];
 #pragma unroll
             for (int u = 0; u < kPer; u++) xword_load_issue(mine_src + (size_t)u * kRecWords, r[u]);
@@ -1791,6 +1799,9 @@ static LmShape lm_shape(uint32_t n)
 {
     if (n <= kMaxLmBlocks * kLmSmallThreads) return kLmSmall;
     if (n <= 2u * kMaxLmBlocks * kLmSmallThreads) return kLmSmall2;  // 256 threads, two points per lane in registers
+    // (for C3's 124k points 128 workgroups of 256 threads with four points per lane in registers -- no point re-read
+    // per evaluation -- measured the same as 512 threads with one: align 0.2315-0.2324 against 0.2314-0.2335 ms on one
+    // box; eight per lane for C4's 248k points lose, 0.448 against 0.343 ms: AGPR spills, eight points in a row)
     return n <= 2u * kMaxLmBlocks * (uint32_t)kEvalThreads ? kLmMid : kLmBig;
 }
 
@@ -1806,7 +1817,6 @@ static int lm_block_limit(lom_map *m, LmShape shape, uint32_t *out)
             LOM_HIP(m, hipOccupancyMaxActiveBlocksPerMultiprocessor(
                            &per_cu, reinterpret_cast<const void *>(k_lm<(int)kLmSmallThreads, (int)kMaxLmBlocks, 2>),
                            (int)kLmSmallThreads, 0));
-
         else if (shape == kLmMid)
             LOM_HIP(m, hipOccupancyMaxActiveBlocksPerMultiprocessor(
                            &per_cu, reinterpret_cast<const void *>(k_lm<kEvalThreads>), kEvalThreads, 0));
