@@ -1,5 +1,8 @@
 #!/bin/bash
-# same-box A/B of two trees: bench C2 (no extras) alternating old/new
+# Same-box A/B of two trees on the GPU box: the default bench (C2, no extras) alternating old / new, three times.
+#   here:        git worktree add _ab_old <commit> && make -C _ab_old/lidar_odometry_demo_amd/csrc && cp oracle/*.so _ab_old/oracle/
+#   on the box:  gpurun -- 'bash tools/ab_trees.sh'          (_ab_old/ is git-ignored and travels with the snapshot)
+#   afterwards:  git worktree remove --force _ab_old
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $R/gpurun_out/r03c
 for i in 1 2 3; do
