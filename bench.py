@@ -321,7 +321,7 @@ def align_block(lom, torch, work, dev, steps, warmup_aligns=200):
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     grid.setProfiling(0)
-    train_us, _, train_requested, pair_us = grid.profileMatch(d_scan.data_ptr(), d_scan.shape[0], pose, 0.3, reps=50)
+    train_us, _, train_requested, pair_us = grid.profileMatch(d_scan.data_ptr(), d_scan.shape[0], pose, 0.3, reps=200)
     overhead = max(0.0, pair_us - train_us)
     prof = max(tot["profiled_launches"], 1)
     match_us = max(tot["match_kernel_ms"] * 1e3 / prof - overhead, 1e-3)
@@ -545,7 +545,7 @@ def main():
     # roofline probe for the dominant kernel, outside the timed region: a back-to-back train of
     # k_match launches at the converged pose under one HIP event pair on the library's stream
     train_us, train_bytes, train_requested, pair_us = grid.profileMatch(d_scan.data_ptr(), d_scan.shape[0], pose, 0.3,
-                                                                        reps=50)
+                                                                        reps=200)
     # PCIe-inclusive variant (scan handed over as a host buffer every step); never `value`
     t1 = time.perf_counter()
     for _ in range(max(3, args.steps // 4)):
@@ -600,7 +600,7 @@ def main():
             "event_pair_overhead_us": event_overhead_us,
             "in_loop_launches_measured": profiled,
             "train_avg_launch_us": train_us,
-            "train_note": "50 back-to-back launches at the final pose under one event pair (best case: warm caches, "
+            "train_note": "200 back-to-back launches at the final pose under one event pair (best case: warm caches, "
                           "converged pose)",
             "launches": launches,
         })

@@ -2272,7 +2272,7 @@ int lom_profile_match(lom_map *m, const float *d_src, size_t n, size_t stride, c
     if (rc == LOM_OK && pair_avg_us_out) {
         m->profiling = true;
         c.prof_used = 0;
-        const int pr = std::min(reps, 32);
+        const int pr = std::min(reps, 128);
         for (int i = 0; rc == LOM_OK && i < pr; i++) rc = launch_match(c, t, q, max_dist, false);
         m->profiling = false;
         if (rc == LOM_OK && hipStreamSynchronize(m->stream) != hipSuccess) rc = LOM_ERR_HIP;
