@@ -452,7 +452,11 @@ struct LmWave {  // registers of the wave that runs the solve, live across its e
     double n_cost, radius;
     int reuse_diag, iter;
 };
-struct LmShared {  // LDS: what is the same for all rows and not needed in every instruction
+// What is the same for all rows and not needed in every instruction.  kReg = false: ONE copy in LDS, written by lane 0
+// (the 512-thread kernels have no registers to spare); kReg = true: a copy in every lane's registers -- every lane
+// computes these values anyway, so every lane keeps them and the LDS round trips of the step go (3,850 -> 3,224 cycles
+// per step with a solve in tools/microbench/policy.hip).
+struct LmShared {
     double x[7];   // the current iterate
     double x_norm, dec, model_change;
     double cost, last_step_norm;
@@ -536,6 +540,7 @@ __device__ __forceinline__ void lmw2_pivot(double M[6], double &rhs, double &my_
 
 // lm_propose: from the current iterate, solve for steps until one is worth evaluating (LM_EVAL: the point in
 // cand[0..6] (LDS, written by lane 0), W.model_change set) or the iteration / invalid-step budgets are used up (LM_DONE)
+template <bool kReg>
 __device__ __forceinline__ int lmw2_propose(LmWave &W, LmShared &S, double *cand, int lane)
 {
     const int r = W.r;
@@ -634,7 +639,7 @@ __device__ __forceinline__ int lmw2_propose(LmWave &W, LmShared &S, double *cand
         result = LM_EVAL;
         break;
     }
-    if (lane == 0) {
+    if (kReg || lane == 0) {
         if (touched) {  // steps without a decrease were recorded on the way (rare)
             S.invalid_run = invalid_run;
             S.recorded += recorded_add;
@@ -652,6 +657,7 @@ __device__ __forceinline__ int lmw2_propose(LmWave &W, LmShared &S, double *cand
 
 // lm_begin_head: `first` = the sums of the evaluation at x (iteration 0), in LDS; x = the point, in LDS.  Returns
 // LM_DONE or LM_PROPOSE (= call lmw2_propose next; the caller does, so that the solve exists once in the kernel).
+template <bool kReg>
 __device__ __forceinline__ int lmw2_begin(LmWave &W, LmShared &S, const double *first, const double *x,
                                           const double *prior_b, int lane)
 {
@@ -676,8 +682,13 @@ __device__ __forceinline__ int lmw2_begin(LmWave &W, LmShared &S, const double *
     W.reuse_diag = 0;
     W.iter = 1;
     W.n_cost = cost;
-    if (lane < 7) S.x[lane] = x[lane];
-    if (lane == 0) {
+    if constexpr (kReg) {
+#pragma unroll
+        for (int i = 0; i < 7; i++) S.x[i] = xs[i];
+    } else if (lane < 7) {
+        S.x[lane] = x[lane];
+    }
+    if (kReg || lane == 0) {
         S.x_norm = x_norm;
         S.dec = 2.0;
         S.model_change = 0.0;
@@ -694,6 +705,7 @@ __device__ __forceinline__ int lmw2_begin(LmWave &W, LmShared &S, const double *
 
 // lm_feed_head: `sums` = the evaluation at the candidate `cand` (both in LDS).  One evaluation at the candidate
 // serves the accept test (cost) and, if accepted, the next iteration (Jacobian).  Returns LM_DONE or LM_PROPOSE.
+template <bool kReg>
 __device__ __forceinline__ int lmw2_feed(LmWave &W, LmShared &S, const double *sums, const double *cand,
                                          const double *prior_b, int lane)
 {
@@ -714,7 +726,7 @@ __device__ __forceinline__ int lmw2_feed(LmWave &W, LmShared &S, const double *s
     const bool stop = __builtin_amdgcn_readfirstlane((int)(sn <= kLmPtol * (x_norm + kLmPtol) ||             // parameter tolerance
                                                            fabs(cost_change) <= kLmFtol * W.n_cost)) != 0;  // function tolerance
     if (stop) {  // neither is recorded
-        if (lane == 0) {
+        if (kReg || lane == 0) {
             S.evaluations++;
             S.cost = W.n_cost;
         }
@@ -733,17 +745,22 @@ __device__ __forceinline__ int lmw2_feed(LmWave &W, LmShared &S, const double *s
         const double d3 = 2.0 * rel_dec - 1.0;
         W.radius = fmin(kLmMaxRadius, W.radius / fmax(1.0 / 3.0, 1.0 - d3 * d3 * d3));
         W.reuse_diag = 0;
-        if (lane < 7) S.x[lane] = cand[lane];
-        if (lane == 0) {
+        if constexpr (kReg) {
+#pragma unroll
+            for (int i = 0; i < 7; i++) S.x[i] = cs[i];
+        } else if (lane < 7) {
+            S.x[lane] = cand[lane];
+        }
+        if (kReg || lane == 0) {
             S.x_norm = cand_norm;
             S.dec = 2.0;
         }
     } else {
         W.radius /= dec;
         W.reuse_diag = 1;
-        if (lane == 0) S.dec = dec * 2.0;
+        if (kReg || lane == 0) S.dec = dec * 2.0;
     }
-    if (lane == 0) {
+    if (kReg || lane == 0) {
         S.evaluations++;
         S.recorded++;
         S.last_step_norm = sn;

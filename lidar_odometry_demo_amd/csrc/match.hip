@@ -1261,7 +1261,10 @@ __global__ __launch_bounds__(kT) void k_lm(const MatchRec *__restrict__ rec, uin
     __shared__ double s_part[kT];
     __shared__ double s_x[7];
     LmWave W;  // the solve's state: per-row part in the registers of the first wave, the rest in LDS (lm_wave.hpp)
+    // the solve's uniform state: in every lane's registers in the 256-thread shapes, one copy in LDS in the 512-thread ones
+    constexpr bool kRegState = kT == 256;
     __shared__ LmShared s_lm;
+    LmShared r_lm;
     __shared__ int s_action, s_failed;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t nb = gridDim.x;
@@ -1367,11 +1370,15 @@ __global__ __launch_bounds__(kT) void k_lm(const MatchRec *__restrict__ rec, uin
                     counters[2] = s_tot[30];
                     counters[3] = px.nranks > 1 ? s_tot[31] : (double)n;
                 }
-                a = lmw2_begin(W, s_lm, s_tot, s_x, init.prior_b, lane);
+                a = kRegState ? lmw2_begin<true>(W, r_lm, s_tot, s_x, init.prior_b, lane)
+                              : lmw2_begin<false>(W, s_lm, s_tot, s_x, init.prior_b, lane);
             } else {
-                a = lmw2_feed(W, s_lm, s_tot, s_x, init.prior_b, lane);
+                a = kRegState ? lmw2_feed<true>(W, r_lm, s_tot, s_x, init.prior_b, lane)
+                              : lmw2_feed<false>(W, s_lm, s_tot, s_x, init.prior_b, lane);
             }
-            if (a == LM_PROPOSE) a = lmw2_propose(W, s_lm, s_x, lane);  // the point of the next evaluation lands in s_x
+            // the point of the next evaluation lands in s_x
+            if (a == LM_PROPOSE)
+                a = kRegState ? lmw2_propose<true>(W, r_lm, s_x, lane) : lmw2_propose<false>(W, s_lm, s_x, lane);
             if (lane == 0) s_action = a;
         }
         LM_STAMP(4);
@@ -1389,7 +1396,7 @@ __global__ __launch_bounds__(kT) void k_lm(const MatchRec *__restrict__ rec, uin
 #undef LM_STAMP
     if (blockIdx.x != 0 || tid != 0) return;
     // ---- end of the outer iteration (workgroup 0, one lane) ----
-    const LmShared &S = s_lm;
+    const LmShared &S = kRegState ? r_lm : s_lm;
     const int outer = prev.outer_done;
     float pq[4], pt[3];
     for (int a = 0; a < 4; a++) pq[a] = (float)S.x[a];      // :161-164

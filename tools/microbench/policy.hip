@@ -1,7 +1,7 @@
 // k_lm's policy step (csrc/lm_wave.hpp: lmw_begin / lmw_feed / lmw_propose on one wave) in isolation: replays the
 // evaluations of six real solves (policy_case.h, written by make_policy_case.py from the HOST driver's run of the
 // same align), checks every point the wave proposes against the host's lm_core.hpp, and times the steps with the
-// shader clock.  build: hipcc -O3 -ffp-contract=off --offload-arch=gfx950 -I lidar_odometry_demo_amd/csrc
+// shader clock.  build: hipcc -O3 -ffp-contract=off --offload-arch=gfx950 -I lidar_odometry_demo_amd/csrc -I tools/microbench
 //        tools/microbench/policy.hip -o tools/microbench/policy
 #include <hip/hip_runtime.h>
 
@@ -36,6 +36,7 @@ __global__ __launch_bounds__(64) void k_policy(const Case *c, Out *o, int reps)
     __shared__ double s_tot[32], s_x[7];
     const int lane = threadIdx.x;
     LmWave W;
+    LmShared r_sh;  // form 3: the uniform state in every lane's registers
     for (int rep = 0; rep < reps; rep++) {
         for (int s = 0; s < kSolves; s++) {
             for (int e = 0; e < c->evals[s]; e++) {
@@ -52,9 +53,12 @@ __global__ __launch_bounds__(64) void k_policy(const Case *c, Out *o, int reps)
                         a = lmw_feed(s_lm, s_tot, lane);
                     if (a == LM_PROPOSE) a = lmw_propose(s_lm, lane);
                     if (lane < 7) s_x[lane] = s_lm.cand[lane];
+                } else if constexpr (kForm == 2) {
+                    a = e == 0 ? lmw2_begin<false>(W, s_sh, s_tot, s_x, c->prior_b, lane) : lmw2_feed<false>(W, s_sh, s_tot, s_x, c->prior_b, lane);
+                    if (a == LM_PROPOSE) a = lmw2_propose<false>(W, s_sh, s_x, lane);
                 } else {
-                    a = e == 0 ? lmw2_begin(W, s_sh, s_tot, s_x, c->prior_b, lane) : lmw2_feed(W, s_sh, s_tot, s_x, c->prior_b, lane);
-                    if (a == LM_PROPOSE) a = lmw2_propose(W, s_sh, s_x, lane);
+                    a = e == 0 ? lmw2_begin<true>(W, r_sh, s_tot, s_x, c->prior_b, lane) : lmw2_feed<true>(W, r_sh, s_tot, s_x, c->prior_b, lane);
+                    if (a == LM_PROPOSE) a = lmw2_propose<true>(W, r_sh, s_x, lane);
                 }
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                 const unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -67,10 +71,10 @@ __global__ __launch_bounds__(64) void k_policy(const Case *c, Out *o, int reps)
                 __syncthreads();
             }
             if (lane == 0) {
-                o->recorded[s] = kForm == 1 ? s_lm.recorded : s_sh.recorded;
-                o->evaluations[s] = kForm == 1 ? s_lm.evaluations : s_sh.evaluations;
-                o->last_step_norm[s] = kForm == 1 ? s_lm.last_step_norm : s_sh.last_step_norm;
-                o->cost[s] = kForm == 1 ? s_lm.cost : s_sh.cost;
+                o->recorded[s] = kForm == 1 ? s_lm.recorded : (kForm == 2 ? s_sh.recorded : r_sh.recorded);
+                o->evaluations[s] = kForm == 1 ? s_lm.evaluations : (kForm == 2 ? s_sh.evaluations : r_sh.evaluations);
+                o->last_step_norm[s] = kForm == 1 ? s_lm.last_step_norm : (kForm == 2 ? s_sh.last_step_norm : r_sh.last_step_norm);
+                o->cost[s] = kForm == 1 ? s_lm.cost : (kForm == 2 ? s_sh.cost : r_sh.cost);
             }
         }
     }
@@ -93,13 +97,15 @@ int main()
     if (hipMalloc(&dc, sizeof h) != hipSuccess || hipMalloc(&dout, sizeof ho) != hipSuccess) return 2;
     (void)hipMemcpy(dc, &h, sizeof h, hipMemcpyHostToDevice);
     int bad = 0, bad_total = 0;
-    for (int form = 1; form <= 2; form++) {
+    for (int form = 1; form <= 3; form++) {
     if (form == 1)
         hipLaunchKernelGGL(k_policy<1>, dim3(1), dim3(64), 0, 0, dc, dout, 20);
-    else
+    else if (form == 2)
         hipLaunchKernelGGL(k_policy<2>, dim3(1), dim3(64), 0, 0, dc, dout, 20);
+    else
+        hipLaunchKernelGGL(k_policy<3>, dim3(1), dim3(64), 0, 0, dc, dout, 20);
     if (hipMemcpy(&ho, dout, sizeof ho, hipMemcpyDeviceToHost) != hipSuccess) return 2;
-    printf("---- form %d (%s)\n", form, form == 1 ? "state in LDS, v_readlane broadcasts" : "state in registers, DPP broadcasts");
+    printf("---- form %d (%s)\n", form, form == 1 ? "state in LDS, v_readlane broadcasts" : (form == 2 ? "row state in registers, uniform state in LDS, DPP broadcasts" : "all state in registers, DPP broadcasts"));
     // host reference: the serial lm_core.hpp on the same sums
     bad = 0;
     double worst = 0.0;
