@@ -120,19 +120,12 @@ __device__ __forceinline__ uint32_t row_sum(uint32_t v)
     v += row_dpp<kDppMirror>(v);      // pairs the two halves
     return v;
 }
-template <int kCtrl>
-__device__ __forceinline__ unsigned long long row_min_step(unsigned long long k)
+__device__ __forceinline__ uint32_t row_min32(uint32_t v)
 {
-    const unsigned long long o =
-        ((unsigned long long)row_dpp<kCtrl>((uint32_t)(k >> 32)) << 32) | row_dpp<kCtrl>((uint32_t)k);
-    return o < k ? o : k;
-}
-__device__ __forceinline__ unsigned long long row_min64(unsigned long long k)
-{
-    k = row_min_step<kDppXor1>(k);
-    k = row_min_step<kDppXor2>(k);
-    k = row_min_step<kDppHalfMirror>(k);
-    return row_min_step<kDppMirror>(k);
+    v = min(v, row_dpp<kDppXor1>(v));
+    v = min(v, row_dpp<kDppXor2>(v));
+    v = min(v, row_dpp<kDppHalfMirror>(v));
+    return min(v, row_dpp<kDppMirror>(v));
 }
 // lane kLane (0..15) of the row, to every lane of the row (ds_swizzle bit mode: and 0x10, or kLane)
 template <int kLane>
@@ -312,19 +305,24 @@ __global__ __launch_bounds__(kMatchThreads, kMinWaves) void k_match(MapView map,
     // this lane's neighbours (scan order ix, iy, iz): key and hash of a neighbour follow from the centre's by ADDING a lane
     // constant -- pack_key is a sum of shifted fields, and the Fibonacci hash multiplies by a constant modulo 2^64, so
     // hash(key0 + d) = (key0 * phi + d * phi) >> shift.  One 64-bit multiply per query, no per-neighbour packing.
+    // (the products are kept opaque: under the 72-register budget the compiler otherwise folds prod0 + dprod back into
+    // (key0 + dkey) * phi -- two quarter-rate multiplies and a 64-bit mad per neighbour -- to save their four registers;
+    // the three gap-table addresses of a neighbour travel as byte offsets packed into one register instead)
     constexpr unsigned long long kPhi = 0x9E3779B97F4A7C15ull;
     unsigned long long dkey[kSets], dprod[kSets];
-    const float *gap_x[kSets], *gap_y[kSets], *gap_z[kSets];
+    uint32_t gap_off[kSets];
 #pragma unroll
     for (int s = 0; s < kSets; s++) {
         const int b = gl + s * G;
         const int dx = b / 9 - 1, dy = (b / 3) % 3 - 1, dz = b % 3 - 1;
         dkey[s] = (unsigned long long)(((long long)dx << 42) + ((long long)dy << 21) + (long long)dz);
         dprod[s] = dkey[s] * kPhi;
-        gap_x[s] = &s_gap[grp][0 + (b < 27 ? dx + 1 : 1)];
-        gap_y[s] = &s_gap[grp][3 + (b < 27 ? dy + 1 : 1)];
-        gap_z[s] = &s_gap[grp][6 + (b < 27 ? dz + 1 : 1)];
+        asm volatile("" : "+v"(dprod[s]));
+        const uint32_t ox = 4u * (uint32_t)(0 + (b < 27 ? dx + 1 : 1)), oy = 4u * (uint32_t)(3 + (b < 27 ? dy + 1 : 1)),
+                       oz = 4u * (uint32_t)(6 + (b < 27 ? dz + 1 : 1));
+        gap_off[s] = ox | (oy << 8) | (oz << 16);
     }
+    const char *gap_base = reinterpret_cast<const char *>(&s_gap[grp][0]);
     if (gl < 3) s_gap[grp][gl * 3 + 1] = 0.f;  // the centre column of the gap table never changes (own group, own wave)
 
     for (uint32_t q = blockIdx.x * kGroups + grp; q < n; q += groups_total) {
@@ -375,7 +373,9 @@ __global__ __launch_bounds__(kMatchThreads, kMinWaves) void k_match(MapView map,
             }
             key[s] = act[s] ? key0 + dkey[s] : 0ull;
             h[s] = act[s] ? ((uint32_t)((prod0 + dprod[s]) >> map.shift) & map.mask) : 0u;
-            lower[s] = *gap_x[s] + (*gap_y[s] + *gap_z[s]);
+            lower[s] = *reinterpret_cast<const float *>(gap_base + (gap_off[s] & 0xFFu)) +
+                       (*reinterpret_cast<const float *>(gap_base + ((gap_off[s] >> 8) & 0xFFu)) +
+                        *reinterpret_cast<const float *>(gap_base + (gap_off[s] >> 16)));
         }
         // both sets' first slots in flight together
         u32x4 raw[kSets];
@@ -449,7 +449,7 @@ __global__ __launch_bounds__(kMatchThreads, kMinWaves) void k_match(MapView map,
             }
             // points actually read (after the exact pruning): one more row sum (an LDS atomic per lane instead cost the
             // kernel's tail 0.3 us: sixteen lanes on one word)
-            T = row_sum(read);
+            T = kChained ? 0u : row_sum(read);  // (only lom_profile_match reads it: not computed inside an align)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -492,9 +492,10 @@ __global__ __launch_bounds__(kMatchThreads, kMinWaves) void k_match(MapView map,
         }
         LOM_STAMP(4);  // candidates scanned
         // lexicographic min over the group; d2 >= 0 so its bit pattern orders like the value
-        unsigned long long keyv = ((unsigned long long)__float_as_uint(best) << 32) | best_c;
-        keyv = row_min64(keyv);
-        const uint32_t w_c = (uint32_t)keyv;
+        // (as two 32-bit row minima -- the distance bits, then the ordinal among the lanes that hold that distance --:
+        // half the instructions of four 64-bit compare-and-select steps)
+        const uint32_t w_d = row_min32(__float_as_uint(best));
+        const uint32_t w_c = row_min32(__float_as_uint(best) == w_d ? best_c : 0xFFFFFFFFu);
         const bool valid = w_c != 0xFFFFFFFFu;
         LOM_STAMP(5);  // group minimum known
         // the lane that scanned the winner reads its point again together with the normal (two loads, one round
@@ -523,7 +524,7 @@ __global__ __launch_bounds__(kMatchThreads, kMinWaves) void k_match(MapView map,
             atomicAdd(&s_cnt[grp][0], valid ? 1u : 0u);
             atomicAdd(&s_cnt[grp][1], n_cand);
             atomicAdd(&s_cnt[grp][2], n_occ);
-            atomicAdd(&s_cnt[grp][3], T);  // candidates actually read (after the exact pruning)
+            if constexpr (!kChained) atomicAdd(&s_cnt[grp][3], T);  // candidates actually read (after the exact pruning)
         }
         LOM_STAMP(6);  // winner's normal loaded, record stored
         stamper.first_done();
