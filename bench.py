@@ -63,7 +63,7 @@ def build_workload(n_gpus, rank, config="C2"):
         # tests/test_gpu_parity.py::test_c3_full_size_properties); not the default bench line
         scan, ring, az, _ = synth.make_scan(64, 2048, boxes=boxes)
         map_xyz, map_nrm = synth.make_map_points(2_000_000, boxes=boxes)
-        return dict(scan=scan, shard=scan, map_xyz=map_xyz, map_nrm=map_nrm,
+        return dict(scan=scan, shard=scan, map_xyz=map_xyz, map_nrm=map_nrm, config="C3",
                     name="C3 (BASELINE configs[2]): 64x2048 scan vs 2M-pt map, voxel 0.5 m, cap 20")
     if config == "C4":
         # BASELINE.json configs[3]: 128 beams x 2048 azimuth steps (<= 262,144 returns) vs the 2M-point map
@@ -248,13 +248,13 @@ def traffic_record(config):
     """HBM-side bytes per k_match launch as last collected with rocprofv3 --pmc (tools/collect_traffic.py; FETCH_SIZE
     doubled + WRITE_SIZE, MI355X_MICROARCH.md): a constant from profiles/, NOT a measurement of this run."""
     for tag in ("r03", "r02", "r01"):
-        tpath = os.path.join(ROOT, "profiles", f"traffic_{tag}.json")
+        tpath = os.path.join(ROOT, "profiles", f"traffic_{tag}.json" if config == "C2" else f"traffic_{tag}_{config.lower()}.json")
         if os.path.exists(tpath):
             with open(tpath) as f:
                 rec = json.load(f)
             if rec.get("config", "C2") != config:
                 continue
-            return rec.get("hbm_bytes_per_launch"), (f"profiles/traffic_{tag}.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in "
+            return rec.get("hbm_bytes_per_launch"), (f"profiles/{os.path.basename(tpath)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in "
                                                        f"separate passes, collected at commit {rec.get('commit', '?')}); "
                                                        "a constant, not measured in this run")
     return None, None
@@ -333,7 +333,7 @@ def align_block(lom, torch, work, dev, steps, warmup_aligns=200):
         "value": tot["queries"] / elapsed / 1e6, "unit": "Mcorr/s", "frames_per_s": steps / elapsed,
         "outer_iterations_per_frame": tot["outer_iterations"] / steps, "evaluations_per_frame": tot["evaluations"] / steps,
         "scan_points": n, "map_points_stored": grid.pointCount(), "map_voxels": grid.size(),
-        "roofline": match_roofline(n, alg, train_requested, match_us, None, None,
+        "roofline": match_roofline(n, alg, train_requested, match_us, *traffic_record(work.get("config", "")),
                                    {"train_avg_launch_us": train_us, "event_pair_overhead_us": overhead,
                                     "in_loop_launches_measured": tot["profiled_launches"]}),
         "k_lm_avg_us": lm_us, "k_match_avg_us": match_us, "insert_chain_us": insert_us,
@@ -706,7 +706,7 @@ def main():
                 # C4 on this one GPU: the same 2M-point map, the 128-beam scan (the N > 1 run shards this scan)
                 from lidar_odometry_demo_amd import synth
                 scan4, _, _, _ = synth.make_scan(128, 2048, boxes=synth.make_boxes())
-                w4 = (dict(w3, scan=scan4, shard=scan4,
+                w4 = (dict(w3, scan=scan4, shard=scan4, config="C4",
                            name=f"C4 (BASELINE configs[3]) on one GPU: 128x2048 scan ({len(scan4)} returns) vs 2M-pt map, "
                                 f"voxel 0.5 m, cap 20") if w3 is not None else build_workload(1, 0, "C4"))
                 extras["C4"] = align_block(lom, torch, w4, dev, steps=max(20, args.steps // 4), warmup_aligns=100)

@@ -30,6 +30,9 @@ run 400 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAV
 run 400 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum TCP_TCC_ATOMIC_WITH_RET_REQ_sum --output-format csv -d "$OUT/pmc_tcc" -o p -- $B
 B3="python3 $ROOT/bench.py --config C3 --steps 5 --warmup 1 --no-cpu-baseline --no-extras"
 run 400 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --output-format csv -d "$OUT/pmc_sq_c3" -o p -- $B3
+run 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch_c3" -o p -- $B3
+run 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write_c3" -o p -- $B3
+python3 "$ROOT/tools/collect_traffic.py" "$OUT/pmc_fetch_c3" "$OUT/pmc_write_c3" "$OUT/traffic_c3.json" "${LOM_COMMIT:-?}" C3 > "$OUT/traffic_c3_summary.txt" 2>&1
 python3 "$ROOT/tools/collect_traffic.py" "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/traffic.json" "${LOM_COMMIT:-?}" > "$OUT/traffic_summary.txt" 2>&1
 # 4. phase stamps of k_lm
 timeout -k 10 120 python3 "$ROOT/tools/lm_debug.py" > "$OUT/lm_stamps.txt" 2>&1; echo "lm_debug rc=$?"
@@ -41,6 +44,6 @@ for k in k_match k_lm k_ins_claim2 k_ins_place2 k_ins_scatter2 k_ins_assign k_in
 done
 for k in k_match k_lm; do python3 "$ROOT/tools/pmc_summary.py" "$OUT/pmc_sq_c3" $k > "$OUT/pmc_c3_summary_$k.txt" 2>/dev/null; done
 # the raw counter dumps are large: keep the summaries
-rm -rf "$OUT"/pmc_fetch "$OUT"/pmc_write "$OUT"/pmc_sq "$OUT"/pmc_tcc "$OUT"/pmc_sq_c3
+rm -rf "$OUT"/pmc_fetch "$OUT"/pmc_write "$OUT"/pmc_sq "$OUT"/pmc_tcc "$OUT"/pmc_sq_c3 "$OUT"/pmc_fetch_c3 "$OUT"/pmc_write_c3
 "$ROOT/tools/microbench/policy" > "$OUT/policy_microbench.txt" 2>&1; "$ROOT/tools/microbench/exec_skip" > "$OUT/exec_skip.txt" 2>&1
 find "$OUT" -name "*kernel_stats.csv" | head
