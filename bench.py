@@ -3,6 +3,7 @@
 VLP16-shaped clouds, on N MI355X of one node.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus N --steps K --warmup W          # starts its own N rank processes (self_launch)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -51,6 +52,107 @@ def claim_stdout():
 def emit(line):
     sys.stdout.flush()
     os.write(_REAL_STDOUT if _REAL_STDOUT is not None else 1, (json.dumps(line) + "\n").encode())
+
+
+def self_launch(n, argv):
+    """`python bench.py --gpus N` without a launcher around it: this process -- which has not imported torch and has
+    made no HIP call, and never will -- starts N fresh rank processes of this same file (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* set as torch.distributed.run would set them), relays rank 0's ONE JSON line to its own stdout, and exits
+    non-zero if any rank did.  Nothing is re-executed in a process that touched the GPU.  When one rank dies the
+    others are ended by their exact pids (they would wait for it in a collective otherwise)."""
+    import signal
+    import socket
+    import subprocess
+
+    with socket.socket() as s:      # a free rendezvous port on the loopback
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOM_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", "1")
+        # rank 0's stdout is the line; the other ranks print nothing there (their stdout joins stderr)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, start_new_session=True))
+
+    def end_all():
+        for p in procs:
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, signal.SIGTERM)    # each rank is the leader of a session of its own
+                except OSError:
+                    pass
+        t_end = time.time() + 10
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, t_end - time.time()))
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(p.pid, signal.SIGKILL)
+                except OSError:
+                    pass
+
+    import threading
+
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    limit = float(os.environ.get("LOM_BENCH_LAUNCH_TIMEOUT_S", "1500"))
+    t0 = time.time()
+    rc = 0
+    try:
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+            if bad:
+                print(f"[bench] rank(s) {bad} failed; ending the others", file=sys.stderr)
+                rc = 1
+                break
+            if all(c == 0 for c in codes):
+                break
+            if time.time() - t0 > limit:
+                print(f"[bench] ranks still running after {limit:.0f} s; ending them", file=sys.stderr)
+                rc = 1
+                break
+            time.sleep(0.05)
+    finally:
+        end_all()
+    reader.join(timeout=5)
+    text = (out0[0] if out0 else b"").decode(errors="replace")
+    lines = [ln for ln in text.splitlines() if ln.startswith("{")]
+    if lines:
+        sys.stdout.write(lines[-1] + "\n")
+        sys.stdout.flush()
+    elif rc == 0:
+        print("[bench] rank 0 printed no line", file=sys.stderr)
+        rc = 1
+    return rc
+
+
+class Watchdog:
+    """A side block (the other transport, the teardown) must not cost the line: if it is not through within `seconds`,
+    `on_fire` runs (rank 0 emits the line it already holds) and the process leaves with os._exit -- a rank stuck in a
+    collective some other rank never entered cannot be brought back any other way."""
+
+    def __init__(self, seconds, on_fire):
+        import threading
+
+        self._t = threading.Timer(seconds, self._fire)
+        self._t.daemon = True
+        self._on_fire = on_fire
+        self._t.start()
+
+    def _fire(self):
+        try:
+            self._on_fire()
+        finally:
+            sys.stderr.flush()
+            os._exit(0)
+
+    def cancel(self):
+        self._t.cancel()
 
 
 def build_workload(n_gpus, rank, config="C2"):
@@ -137,6 +239,9 @@ def cpu_baseline(work, budget_s=10.0):
         if el1 > budget_s / 4 or f1 >= 500:
             break
     return {"value": queries / el / 1e6, "unit": "Mcorr/s", "cores": cores, "kind": "port",
+            "cores_note": f"{cores} search threads: the GPU box grants a 16-CPU share per GPU, whatever the affinity mask "
+                          f"({len(os.sched_getaffinity(0))} CPUs) or hardware_concurrency ({os.cpu_count()}) report; more "
+                          "threads than that share only time-slice.  The solve is single-threaded (Ceres num_threads = 1)",
             "frames_per_s": frames / el,
             "single_thread_value": q1 / el1 / 1e6, "single_thread_frames_per_s": f1 / el1,
             "sample": f"{frames} full frames of the same workload ({queries} queries, {el:.1f} s) with the search on "
@@ -260,7 +365,7 @@ def traffic_record(config):
     return None, None
 
 
-def match_roofline(n_queries, alg_per_launch, req_per_launch, avg_us, traffic, traffic_source, extra=None):
+def match_roofline(n_queries, alg_per_launch, req_per_launch, avg_us, traffic, traffic_source, extra=None, big_map=False):
     """`roofline` of the dominant kernel on the SURVEY.md 8(d) definition for EVERY configuration: algorithmic bytes per
     launch / the kernel's average launch duration against the 8 TB/s HBM peak.  Where the map is served from L2 /
     Infinity Cache that fraction can exceed 1 (the formula also counts candidates the exact pruning never reads): the
@@ -268,7 +373,13 @@ def match_roofline(n_queries, alg_per_launch, req_per_launch, avg_us, traffic, t
     achieved = alg_per_launch / (avg_us * 1e-6) / 1e9
     roof = {
         "kernel": "k_match (27-neighbour correspondence search)",
-        "bound": "hbm",
+        # what the counters say bounds the kernel (profiles/): the VLP16-sized launch is one resident round of dependent
+        # round trips into an L2 / Infinity-Cache resident map; on the 2M-point map the kernel sits at the rate the caches
+        # serve random rows at.  `peak` / `frac` stay priced against the HBM roofline (`priced_against`), as SURVEY.md 8(d)
+        # defines them.
+        "bound": ("cache bandwidth (L2 / Infinity-Cache served random rows)" if big_map
+                  else "latency (cache-resident gather: a chain of dependent round trips per query)"),
+        "priced_against": "hbm",
         "achieved": achieved,
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",
@@ -335,7 +446,7 @@ def align_block(lom, torch, work, dev, steps, warmup_aligns=200):
         "scan_points": n, "map_points_stored": grid.pointCount(), "map_voxels": grid.size(),
         "roofline": match_roofline(n, alg, train_requested, match_us, *traffic_record(work.get("config", "")),
                                    {"train_avg_launch_us": train_us, "event_pair_overhead_us": overhead,
-                                    "in_loop_launches_measured": tot["profiled_launches"]}),
+                                    "in_loop_launches_measured": tot["profiled_launches"]}, big_map=True),
         "k_lm_avg_us": lm_us, "k_match_avg_us": match_us, "insert_chain_us": insert_us,
         "pose": {"t": [float(v) for v in pose.translation], "q_wxyz": [float(v) for v in pose.rotation]},
     }
@@ -355,6 +466,9 @@ def main():
                          "incl. 1, strong scaling); C5 = configs[4], streaming LidarOdometry::processCloud "
                          "(--steps = frames)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher around us: be the launcher (before torch is imported or any HIP call is made in this process)
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
     claim_stdout()
 
     import torch
@@ -517,31 +631,6 @@ def main():
             el = float(t.item())
         block_ms.append(el / args.steps * 1e3)
 
-    # the other transport, for comparison (never `value`; a failure here must not cost the line)
-    # Opt-in (LOM_BENCH_COMPARE_EXCHANGE=1): a transport that fails on some ranks only would leave
-    # the others waiting, and the official line below must not depend on it.
-    other = None
-    if use_dist and os.environ.get("LOM_BENCH_COMPARE_EXCHANGE"):
-        alt = "rccl" if exchange == "host" else "host"
-        try:
-            detach()
-            attach(alt)
-            for _ in range(min(3, args.warmup)):
-                step()
-            fence()
-            t_alt = time.perf_counter()
-            q_alt = 0
-            for _ in range(args.steps):
-                q_alt += step()[1]["queries"]
-            fence()
-            el = time.perf_counter() - t_alt
-            t = torch.tensor([el], dtype=torch.float64, device="cpu" if one_device else dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            other = {"exchange": alt, "value": q_alt / float(t.item()) / 1e6, "unit": "Mcorr/s",
-                     "ms_per_step": float(t.item()) / args.steps * 1e3}
-        except Exception as e:  # noqa: BLE001
-            other = {"exchange": alt, "error": repr(e)[:300]}
-
     # roofline probe for the dominant kernel, outside the timed region: a back-to-back train of
     # k_match launches at the converged pose under one HIP event pair on the library's stream
     train_us, train_bytes, train_requested, pair_us = grid.profileMatch(d_scan.data_ptr(), d_scan.shape[0], pose, 0.3,
@@ -603,7 +692,7 @@ def main():
             "train_note": "200 back-to-back launches at the final pose under one event pair (best case: warm caches, "
                           "converged pose)",
             "launches": launches,
-        })
+        }, big_map=(args.config != "C2"))
         # -- the other kernels of the path
         lm_raw_us = lm_ms * 1e3 / max(lm_profiled, 1)
         lm_us = max(lm_raw_us - event_overhead_us, 1e-3) if lm_profiled else None
@@ -620,6 +709,9 @@ def main():
              "gbs": (lm_bytes / (lm_us * 1e-6) / 1e9 if lm_us else None),
              "frac_of_hbm_peak": (lm_bytes / (lm_us * 1e-6) / 1e9 / HBM_PEAK_GBS if lm_us else None),
              "evaluations_per_launch": evals_per_launch, "launches_per_step": outer / args.steps,
+             "workgroups": tot["lm_workgroups"], "cus_busy": tot["lm_workgroups"], "cus_total": 256,
+             "cus_note": "one workgroup per CU (its workgroups wait for each other: the grid is held to what is resident); "
+                         "the other CUs are free for concurrent callers (concurrent_contexts)",
              "bytes_note": "36 B per valid match and evaluation (source point, plane origin, plane normal)",
              "note": "a latency chain, not a stream: per evaluation one pass over <= 1 point per lane, a workgroup "
                      "reduction, one exchange between the workgroups through HBM and a serial 6x6 policy step on one "
@@ -673,7 +765,7 @@ def main():
                                   "store their totals into each other's HBM; host = host-driven solve, "
                                   "shared-memory exchange between the ranks' hosts; rccl = host-driven solve, "
                                   "all-gather over xGMI" if use_dist else None),
-                "other_exchange": other,
+                "other_exchange": None,
             },
             "host_breakdown_ms_per_step": {"in_launch_calls": launch_ms / args.steps,
                                            "waiting_for_results": wait_ms / args.steps},
@@ -726,12 +818,65 @@ def main():
                 extras["C5"] = {"error": repr(e)[:300]}
             extras["wall_s"] = time.perf_counter() - t_x
             line["extra_configs"] = extras
+    else:
+        line = None
+
+    # The other transports, timed in the same run for comparison (never `value`): the north_star names an RCCL
+    # all-reduce per iteration, the default is the device-to-device exchange -- both get a number.  The line is complete
+    # before this block starts and a watchdog guards it: a transport that fails or hangs on some rank costs the side
+    # figure, not the line (LOM_BENCH_NO_COMPARE=1 skips the block).
+    if use_dist and not os.environ.get("LOM_BENCH_NO_COMPARE"):
+        others = []
+
+        def fire():
+            if rank == 0:
+                others.append({"error": "watchdog: the comparison block did not finish; the ranks were ended"})
+                line["config"]["other_exchange"] = others
+                emit(line)
+            print(f"[bench] rank {rank}: comparison block timed out, leaving", file=sys.stderr)
+
+        alts = [a for a in ("rccl", "host") if a != exchange]
+        for alt in alts:
+            if alt == "rccl" and one_device:
+                others.append({"exchange": "rccl", "skipped": "LOM_BENCH_ONE_DEVICE rehearsal: RCCL refuses several ranks "
+                                                              "on one device"})
+                continue
+            dog = Watchdog(float(os.environ.get("LOM_BENCH_COMPARE_TIMEOUT_S", "120")), fire)
+            try:
+                detach()
+                attach(alt)
+                for _ in range(min(3, args.warmup)):
+                    step()
+                fence()
+                t_alt = time.perf_counter()
+                q_alt = 0
+                for _ in range(args.steps):
+                    q_alt += step()[1]["queries"]
+                fence()
+                el = time.perf_counter() - t_alt
+                t = torch.tensor([el], dtype=torch.float64, device="cpu" if one_device else dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                others.append({"exchange": alt, "value": q_alt / float(t.item()) / 1e6, "unit": "Mcorr/s",
+                               "ms_per_step": float(t.item()) / args.steps * 1e3,
+                               "what": ("host-driven solve; per residual evaluation k_eval + k_sum_records, one RCCL all-gather "
+                                        "of 32 f64 per rank, D2H copy, rank-ordered host sum" if alt == "rccl" else
+                                        "host-driven solve; the ranks' hosts exchange the 32 sums through shared memory")})
+            except Exception as e:  # noqa: BLE001
+                others.append({"exchange": alt, "error": repr(e)[:300]})
+            dog.cancel()
+        if rank == 0:
+            line["config"]["other_exchange"] = others
+
+    if rank == 0:
         emit(line)
 
     if use_dist:
+        # the line is out: a teardown that hangs (a transport left half attached above) must not turn into a failed run
+        dog = Watchdog(60.0, lambda: print(f"[bench] rank {rank}: teardown timed out, leaving", file=sys.stderr))
         detach()
         dist.barrier()
         dist.destroy_process_group()
+        dog.cancel()
 
 
 if __name__ == "__main__":

@@ -171,6 +171,20 @@ typedef struct {
 int64_t lom_match_find_pairs(lom_map *m, const float *src_xyz, size_t n, size_t stride_bytes,
                              const float t[3], const float q_wxyz[4], float max_dist,
                              lom_correspondence *out);
+/* The same search with the SQUARED threshold handed over as the reference's getCorrespondence takes it
+ * (`double max_correspondence_distance_sq`, src/voxel_grid.h:164): a stored point is accepted iff
+ * (double)(f32 squared distance) < max_dist_sq (:184-186).  lom_match_find_pairs squares its f32 argument in f32, as
+ * findMatchingPairs does (:215); callers that hold a squared threshold use this entry instead of taking a root. */
+int64_t lom_match_find_pairs_sq(lom_map *m, const float *src_xyz, size_t n, size_t stride_bytes,
+                                const float t[3], const float q_wxyz[4], double max_dist_sq,
+                                lom_correspondence *out);
+/* Parity entry for the temporal pruning bound of the align's searches (csrc/match.hip): a search at the pose
+ * (t_prev, q_prev), then the search at (t, q) with the first one's winners as upper bounds -- what outer iterations
+ * >= 2 of an align run.  The result must equal lom_match_find_pairs at (t, q) entry for entry, whatever the two poses
+ * are (a winner that has left a query's 27 voxels is found out and that query searched again at the plain bound). */
+int64_t lom_debug_find_pairs_after(lom_map *m, const float *src_xyz, size_t n, size_t stride_bytes,
+                                   const float t_prev[3], const float q_prev_wxyz[4], const float t[3],
+                                   const float q_wxyz[4], float max_dist, lom_correspondence *out);
 
 /* ---- CloudMatcher::align (src/cloud_matcher.cpp:105-178) ---------------- */
 /* Reduced normal equations produced per evaluation (f64):
@@ -199,7 +213,7 @@ typedef struct {
     int64_t profiled_launches; /* correspondence launches that carried the HIP event pair      */
     int32_t host_fallback;     /* 1: the device-resident loop gave up (its workgroups were not all
                                   resident in time) and the align was redone by the host-driven loop */
-    int32_t reserved;
+    int32_t lm_workgroups;     /* workgroups of the device-resident solve kernel (k_lm), one per CU: the CUs a solve keeps busy */
     double lm_kernel_ms;          /* HIP-event time of the k_lm launches of the device-resident loop (profiling on) */
     int64_t lm_profiled_launches; /* k_lm launches that carried the events                                        */
 } lom_align_stats;
@@ -280,6 +294,11 @@ typedef enum {
                                           a device-to-device align outlasts both (see lom_comm_attach_p2p). */
     LOM_OPT_DEBUG_LM_STAMPS = 3,       /* 1: print k_lm's phase stamps after every align (stderr) */
     LOM_OPT_DEBUG_TIMING = 4,          /* 1: print host launch / wait times per evaluation (stderr) */
+    LOM_OPT_NO_TEMPORAL_BOUND = 5,     /* 1: every correspondence search prunes at max_dist only.  Default 0: the searches
+                                          of outer iterations >= 2 of an align also prune with the previous iteration's
+                                          winner (exact, verified per query: csrc/match.hip "temporal bound"); results
+                                          are the same either way, this switch exists for A/B timing (LOM_NO_TEMPORAL=1
+                                          in the environment at create) */
     LOM_OPT_TEST_GIVE_UP_AT_OUTER = 100, /* k: the k_lm of outer iteration k of the NEXT align behaves as if its
                                           workgroups had timed out waiting (one shot; -1 = off) */
     LOM_OPT_TEST_GRID_GIVE_UP = 101,   /* b >= 0: in the NEXT map-maintenance call with an in-kernel scan, workgroups
@@ -329,6 +348,8 @@ int lom_scan_align_repeat(lom_scan *s, const float *d_src_xyz, size_t n, size_t 
                           lom_align_stats *total_or_null);
 int64_t lom_scan_find_pairs(lom_scan *s, const float *src_xyz, size_t n, size_t stride_bytes, const float t[3],
                             const float q_wxyz[4], float max_dist, lom_correspondence *out);
+int64_t lom_scan_find_pairs_sq(lom_scan *s, const float *src_xyz, size_t n, size_t stride_bytes, const float t[3],
+                               const float q_wxyz[4], double max_dist_sq, lom_correspondence *out);
 
 /* ---- multi-GPU: source points range-sharded, map replicated ------------- */
 /* One all-gather of LOM_NSUMS f64 per residual evaluation over RCCL, summed in

@@ -217,7 +217,7 @@ public:
     {
         PointCloud<PointXYZ> one;
         one.points.emplace_back(query.x(), query.y(), query.z());
-        auto v = findAll(one, Pose3D(), (float)std::sqrt(max_correspondence_distance_sq));
+        auto v = findAll(one, Pose3D(), 0.f, &max_correspondence_distance_sq);  // the squared threshold as it is (:164)
         Correspondence c = v[0];
         for (double &d : c.source_point_local) d = 0.0;  // the reference leaves it unset here
         return c;
@@ -272,15 +272,18 @@ private:
         for (size_t i = 0; i < n; i++) out->points[i] = PointXYZ(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
         return out;
     }
-    std::vector<Correspondence> findAll(const PointCloud<PointXYZ> &cloud, const Pose3D &transform, float max_dist) const
+    std::vector<Correspondence> findAll(const PointCloud<PointXYZ> &cloud, const Pose3D &transform, float max_dist,
+                                        const double *max_dist_sq = nullptr) const
     {
         std::vector<lom_correspondence> raw(cloud.points.size());
         std::vector<Correspondence> out(cloud.points.size());
         if (cloud.points.empty()) return out;
         const lom_pose p = transform.c();
         lom_scan *ctx = scan_context();
-        const int64_t rc = lom_scan_find_pairs(ctx, &cloud.points.data()->x, cloud.points.size(), sizeof(PointXYZ),
-                                               p.t, p.q, max_dist, raw.data());
+        const int64_t rc = max_dist_sq ? lom_scan_find_pairs_sq(ctx, &cloud.points.data()->x, cloud.points.size(),
+                                                                sizeof(PointXYZ), p.t, p.q, *max_dist_sq, raw.data())
+                                       : lom_scan_find_pairs(ctx, &cloud.points.data()->x, cloud.points.size(),
+                                                             sizeof(PointXYZ), p.t, p.q, max_dist, raw.data());
         if (rc < 0) throw Error((int)rc, lom_scan_last_error(ctx));
         for (size_t i = 0; i < raw.size(); i++) {
             Correspondence &c = out[i];

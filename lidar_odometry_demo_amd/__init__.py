@@ -180,11 +180,30 @@ class VoxelGrid:
             float(max_correspondence_distance), out.ctypes.data), self._h)
         return out
 
+    def findMatchingPairsSq(self, xyz, transform, max_correspondence_distance_sq):
+        """The search with the squared threshold as getCorrespondence takes it (voxel_grid.h:164: a double)."""
+        xyz = capi.xyz_array(xyz)
+        out = np.zeros(len(xyz), capi.CORR_DTYPE)
+        capi.check(capi.lib().lom_match_find_pairs_sq(
+            self._h, xyz.ctypes.data, len(xyz), 12, capi.f3(transform.translation), capi.f4(transform.rotation),
+            float(max_correspondence_distance_sq), out.ctypes.data), self._h)
+        return out
+
+    def findMatchingPairsAfter(self, xyz, previous_transform, transform, max_correspondence_distance=0.3):
+        """Parity entry: the search at `transform` with the temporal pruning bound taken from a search at
+        `previous_transform` (what outer iterations >= 2 of an align run); equals findMatchingPairs(xyz, transform)."""
+        xyz = capi.xyz_array(xyz)
+        out = np.zeros(len(xyz), capi.CORR_DTYPE)
+        capi.check(capi.lib().lom_debug_find_pairs_after(
+            self._h, xyz.ctypes.data, len(xyz), 12, capi.f3(previous_transform.translation),
+            capi.f4(previous_transform.rotation), capi.f3(transform.translation), capi.f4(transform.rotation),
+            float(max_correspondence_distance), out.ctypes.data), self._h)
+        return out
+
     def getCorrespondence(self, query, max_correspondence_distance_sq):
-        """voxel_grid.h:164-204 for a single already-transformed f32 query point."""
-        d = float(np.sqrt(np.float32(max_correspondence_distance_sq)))
-        c = self.findMatchingPairs(np.asarray(query, np.float32).reshape(1, 3), Pose3D(), d)
-        return c[0]
+        """voxel_grid.h:164-204 for a single already-transformed f32 query point; the threshold is the reference's
+        `double max_correspondence_distance_sq`, handed over as it is."""
+        return self.findMatchingPairsSq(np.asarray(query, np.float32).reshape(1, 3), Pose3D(), max_correspondence_distance_sq)[0]
 
     def profileMatch(self, d_src_ptr, n, transform, max_correspondence_distance=0.3, reps=20, stride_bytes=12):
         """(average k_match launch duration [us] over a back-to-back train under one event pair, algorithmic

@@ -49,7 +49,7 @@ class AlignStats(C.Structure):
         ("cand_total", C.c_int64), ("occ_total", C.c_int64), ("final_cost", C.c_double),
         ("last_step_norm", C.c_double), ("match_kernel_ms", C.c_double),
         ("algorithmic_bytes", C.c_double), ("host_launch_ms", C.c_double), ("host_wait_ms", C.c_double),
-        ("profiled_launches", C.c_int64), ("host_fallback", C.c_int32), ("reserved", C.c_int32),
+        ("profiled_launches", C.c_int64), ("host_fallback", C.c_int32), ("lm_workgroups", C.c_int32),
         ("lm_kernel_ms", C.c_double), ("lm_profiled_launches", C.c_int64),
     ]
 
@@ -114,7 +114,7 @@ EXPORTED = [
     "lom_map_destroy", "lom_last_error", "lom_map_clear", "lom_map_set_max_points", "lom_map_add_points",
     "lom_map_add_points_device", "lom_map_add_points_device_nowait", "lom_map_status", "lom_map_radius_cleanup", "lom_map_size", "lom_map_point_count",
     "lom_map_export", "lom_voxel_downsample", "lom_voxel_downsample_device", "lom_upload_points",
-    "lom_transform_points_device", "lom_map_get_stream", "lom_match_find_pairs", "lom_match_align", "lom_match_align_device", "lom_match_align_repeat", "lom_debug_match_stamps", "lom_debug_eval_sums", "lom_debug_lm_trace",
+    "lom_transform_points_device", "lom_map_get_stream", "lom_match_find_pairs", "lom_match_find_pairs_sq", "lom_debug_find_pairs_after", "lom_match_align", "lom_match_align_device", "lom_match_align_repeat", "lom_debug_match_stamps", "lom_debug_eval_sums", "lom_debug_lm_trace",
     "lom_map_set_profiling", "lom_profile_match", "lom_profile_insert", "lom_map_set_stream", "lom_comm_unique_id", "lom_comm_init",
     "lom_comm_finalize", "lom_comm_host_id", "lom_host_comm_create", "lom_host_comm_allreduce",
     "lom_host_comm_destroy", "lom_host_comm_allgather", "lom_comm_attach_host", "lom_comm_attach_p2p", "lom_align_with_hooks", "lom_point_time_normalize", "lom_transform_non_rigid",
@@ -127,11 +127,11 @@ EXPORTED = [
     "lom_map_set_option", "lom_map_debug_counter", "lom_odometry_set_option", "lom_odometry_debug_counter",
     "lom_frontend_set_option", "lom_host_comm_set_timeout", "lom_host_comm_abort", "lom_host_comm_last_error",
     "lom_scan_create", "lom_scan_destroy", "lom_scan_last_error", "lom_scan_set_option", "lom_scan_set_stream",
-    "lom_scan_get_stream", "lom_scan_align", "lom_scan_align_device", "lom_scan_align_repeat", "lom_scan_find_pairs",
+    "lom_scan_get_stream", "lom_scan_align", "lom_scan_align_device", "lom_scan_align_repeat", "lom_scan_find_pairs", "lom_scan_find_pairs_sq",
 ]
 
 # lom_option / counters of include/lidar_odometry_amd.h
-OPT_HOST_LM, OPT_DEVICE_PATIENCE_TICKS, OPT_DEBUG_LM_STAMPS, OPT_DEBUG_TIMING = 1, 2, 3, 4
+OPT_HOST_LM, OPT_DEVICE_PATIENCE_TICKS, OPT_DEBUG_LM_STAMPS, OPT_DEBUG_TIMING, OPT_NO_TEMPORAL_BOUND = 1, 2, 3, 4, 5
 OPT_TEST_GIVE_UP_AT_OUTER, OPT_TEST_GRID_GIVE_UP, OPT_TEST_FORCE_HOST_REDO = 100, 101, 102
 OPT_TEST_GRID_GIVE_UP_MATCHING_DS, OPT_TEST_GRID_GIVE_UP_UPDATE_DS, OPT_TEST_GRID_GIVE_UP_KEYFRAME = 103, 104, 105
 COUNTER_GRID_REDOS = 0
@@ -212,6 +212,10 @@ def lib():
     L.lom_map_get_stream.restype = vp
     L.lom_match_find_pairs.argtypes = [vp, vp, C.c_size_t, C.c_size_t, fp, fp, C.c_float, vp]
     L.lom_match_find_pairs.restype = C.c_int64
+    L.lom_match_find_pairs_sq.argtypes = [vp, vp, C.c_size_t, C.c_size_t, fp, fp, C.c_double, vp]
+    L.lom_match_find_pairs_sq.restype = C.c_int64
+    L.lom_debug_find_pairs_after.argtypes = [vp, vp, C.c_size_t, C.c_size_t, fp, fp, fp, fp, C.c_float, vp]
+    L.lom_debug_find_pairs_after.restype = C.c_int64
     L.lom_match_align.argtypes = [vp, vp, C.c_size_t, C.c_size_t, fp, fp, fp, fp, C.POINTER(AlignStats)]
     L.lom_match_align_device.argtypes = L.lom_match_align.argtypes
     L.lom_debug_match_stamps.argtypes = [vp, vp, C.c_size_t, C.c_size_t, fp, fp, C.c_float, vp, C.c_size_t,
@@ -315,6 +319,8 @@ def lib():
     L.lom_scan_align_repeat.argtypes = L.lom_match_align_repeat.argtypes
     L.lom_scan_find_pairs.argtypes = L.lom_match_find_pairs.argtypes
     L.lom_scan_find_pairs.restype = C.c_int64
+    L.lom_scan_find_pairs_sq.argtypes = L.lom_match_find_pairs_sq.argtypes
+    L.lom_scan_find_pairs_sq.restype = C.c_int64
     _lib = L
     return L
 

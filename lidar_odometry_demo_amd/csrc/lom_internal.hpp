@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdint>
 #include <mutex>
 #include <string>
@@ -133,9 +134,14 @@ struct lom_map {
     lom_map *parent = nullptr;
     // map side: calls that changed the map (their kernels run on THIS handle's stream); context side: the count its
     // stream has been ordered behind, and the event it uses for that
-    uint64_t mutations = 0, seen_mutations = ~0ull;
+    // (atomic: a context's fast path reads the parent's count while another context, or the map's own caller, settles)
+    std::atomic<uint64_t> mutations{0};
+    uint64_t seen_mutations = ~0ull;
     hipEvent_t parent_ev = nullptr;
-    std::mutex settle_mutex;  // contexts settling a pending insert of / ordering themselves behind their map
+    // Settling the map -- redoing an insert nobody has looked at yet, reading its voxel count back -- uses the MAP's
+    // stream, pinned words and scratch: whoever does it (the map's own caller, a context's first call after a change,
+    // lom_scan_create) holds this lock, so that several threads arriving together settle once.
+    std::mutex settle_mutex;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     float voxel_size = 0.5f;
@@ -177,7 +183,8 @@ struct lom_map {
     bool table_clean = true;
     // the handle's last single-pass insert, for lom_map_status() to redo should its in-kernel scan have given up
     const char *pending_xyz = nullptr, *pending_nrm = nullptr;
-    size_t pending_n = 0, pending_stride = 0;
+    std::atomic<size_t> pending_n{0};  // != 0: an unverified single-pass insert (read without the lock by the fast paths)
+    size_t pending_stride = 0;
     uint32_t pending_seq = 0, grid_resolved_seq = 0;
     uint32_t grid_redos = 0;  // calls redone with the multi-launch scan after a give-up (lom_map_debug_counter)
     // per-scan buffers of align/find_pairs
@@ -229,6 +236,7 @@ struct lom_map {
     bool opt_host_lm = false;       // LOM_OPT_HOST_LM / LOM_HOST_LM=1
     bool opt_debug_lm = false;      // LOM_OPT_DEBUG_LM_STAMPS / LOM_DEBUG_LM=1
     bool opt_debug_timing = false;  // LOM_OPT_DEBUG_TIMING / LOM_DEBUG_TIMING=1
+    bool opt_no_temporal = false;   // LOM_OPT_NO_TEMPORAL_BOUND / LOM_NO_TEMPORAL=1: every search at the plain max_dist bound
     unsigned long long patience_ticks = 5000000ull;  // bounded in-kernel waits: 50 ms of s_memrealtime (100 MHz)
     int test_grid_give_up = -1;     // LOM_OPT_TEST_GRID_GIVE_UP: first workgroup that gives up in the next in-kernel scan
     int test_give_up_outer = -1;    // LOM_OPT_TEST_GIVE_UP_AT_OUTER: k_lm of that outer iteration of the next align gives up

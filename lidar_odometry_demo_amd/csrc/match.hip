@@ -45,9 +45,11 @@ constexpr int kEvalThreads = 512;
 
 // what k_match leaves behind for the evaluations of one outer iteration: source point,
 // winner's stored point and normal, 48 bytes = three dwordx4 (coalesced for k_eval)
+// (the winner's point and the valid flag share one dwordx4: the next outer iteration's k_match reads exactly that
+// quarter back as its temporal pruning bound)
 struct __attribute__((aligned(16))) MatchRec {
-    float px, py, pz, valid;  // source_point_local (voxel_grid.h:226); valid = 1.0f / 0.0f
-    float ox, oy, oz, nx;     // plane_origin, plane_normal.x
+    float px, py, pz, nx;     // source_point_local (voxel_grid.h:226), plane_normal.x
+    float ox, oy, oz, valid;  // plane_origin; valid = 1.0f / 0.0f
     float ny, nz, pad0, pad1;
 };
 static_assert(sizeof(MatchRec) == 48, "three dwordx4");
@@ -225,7 +227,12 @@ struct Stamper<true> {
 // kChained: the pose comes from the AlignState a previous k_lm left in HBM (read through the
 // constant address space: scalar loads, like kernel arguments), and the launch does nothing once
 // the outer loop has finished -- the host enqueues several outer iterations ahead.
-template <int G, int kU, int kMinWaves, bool kStamp = false, bool kChained = false>
+// kPrev: the records of the PREVIOUS search of the same scan against the same map are still at out_rec (outer
+// iterations >= 2 of an align): the old winner's f32 distance at the new pose bounds this search's minimum from above,
+// and a neighbour voxel whose nearest face is provably farther than that cannot hold the winner -- see "temporal
+// bound" in the loop.  Exact; verified per query, with a second pass at the plain bound where the old winner has left
+// the neighbourhood.
+template <int G, int kU, int kMinWaves, bool kStamp = false, bool kChained = false, bool kPrev = kChained>
 __global__ __launch_bounds__(kMatchThreads, kMinWaves) void k_match(MapView map, const char *__restrict__ src, size_t stride,
                                                          uint32_t n, PoseArgs Parg, int32_t *__restrict__ out_idx,
                                                          MatchRec *__restrict__ out_rec,
@@ -295,7 +302,6 @@ __global__ __launch_bounds__(kMatchThreads, kMinWaves) void k_match(MapView map,
         s_pose[threadIdx.x] = v;
     }
     __syncthreads();
-    const float prune_sq = P.max_sq * 1.0001f;
     // Work that is the same for the lanes of a query is split over them instead of repeated by each: lanes
     // 0, 1, 2 of a row prepare the x, y, z component (f64 transform, f32 cast, truncating index, the two
     // pruning gaps of that axis) and hand the results to the row -- values through ds_swizzle broadcasts, the
@@ -326,9 +332,21 @@ __global__ __launch_bounds__(kMatchThreads, kMinWaves) void k_match(MapView map,
     if (gl < 3) s_gap[grp][gl * 3 + 1] = 0.f;  // the centre column of the gap table never changes (own group, own wave)
 
     for (uint32_t q = blockIdx.x * kGroups + grp; q < n; q += groups_total) {
-        const float s0 = sp_next.x, s1 = sp_next.y, s2 = sp_next.z;
+        f32x3 sp = sp_next;
+        // the previous search's {winner point, valid} of this query: not needed before the slots are back, so it is
+        // asked for here (one round trip beside theirs) rather than a query ahead (four more live registers)
+        float4 pv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (kPrev) pv = reinterpret_cast<const float4 *>(out_rec + q)[1];
         if (q + groups_total < n) sp_next = *reinterpret_cast<const f32x3 *>(src + (size_t)(q + groups_total) * stride);
-        const double p0 = (double)s0, p1 = (double)s1, p2 = (double)s2;
+        uint32_t w_d, w_c, best_pi0, best_c, n_cand, n_occ, T = 0;  // T: points actually read
+        float best;
+        // one pass; where the temporal bound (below) could not be verified, the query is done over from its source point
+        // at the plain bound -- rare, and cheaper in registers than keeping the probe's results across the scan
+        for (bool use_prev = kPrev;; use_prev = false) {
+        // (with records of a previous search the source point is not carried through the query: it is in the record
+        // already, and the rare second pass fetches it again)
+        if (kPrev && !use_prev) sp = *reinterpret_cast<const f32x3 *>(src + (size_t)q * stride);
+        const double p0 = (double)sp.x, p1 = (double)sp.y, p2 = (double)sp.z;
         // voxel_grid.h:220-223: R*p + t in f64 (Eigen order a0 + (a1 + a2)), cast to f32 -- this lane's component
         const float qc = (float)((my_pose[0] * p0 + (my_pose[1] * p1 + my_pose[2] * p2)) + my_pose[3]);
         int ic = 0;
@@ -399,21 +417,43 @@ __global__ __launch_bounds__(kMatchThreads, kMinWaves) void k_match(MapView map,
                     r = load_slot(map.table + hh);
                 }
             }
-            // a neighbour voxel whose nearest face is provably farther than max_dist is not read
-            scan_cnt[s] = (lower[s] > prune_sq) ? 0u : cnt[s];
         }
         LOM_STAMP(2);  // 27 slots probed
-        // ---- group-wide prefix over the neighbours in scan order ----
-        // occupied voxels (<= 27) above bit 26, stored points (<= 27 K, K < 2^16) below: one row sum for both sets
+        // ---- temporal bound ----
+        // The winner of the previous search (same scan, same map, the pose one solve earlier) is a stored point: if it
+        // still lies in this query's 27 voxels it is a candidate now, its distance d_prev2 -- the very f32 expression of
+        // the candidate loop -- is an upper bound of this search's minimum, and a voxel whose nearest face is provably
+        // farther than d_prev2 can hold neither the winner nor a tie with it.  Whether it still lies there is not
+        // computed but VERIFIED: with B = d_prev2 the pruned voxels' points all have d2 > B (the argument of the plain
+        // bound, B in place of max_sq, same slack), so a scan that ends with a minimum <= B has seen every candidate
+        // with d2 <= B in the reference's order and its first strict minimum is the reference's (voxel_grid.h:183-191);
+        // a scan that ends above B (the old winner left the neighbourhood, or was none) is repeated at the plain
+        // bound.  Counts (n_cand, n_occ) stay the slot counts of all 27 voxels.
+        float B = P.max_sq;
+        if constexpr (kPrev) {
+            const float ex = qx - pv.x, ey = qy - pv.y, ez = qz - pv.z;
+            const float d_prev2 = ex * ex + (ey * ey + ez * ez);
+            if (use_prev && pv.w != 0.f && d_prev2 < P.max_sq) B = d_prev2;  // (NaN: no bound)
+        }
+        // the reference's counts: occupied voxels (<= 27) above bit 26, stored points (<= 27 K, K < 2^16) below: one row
+        // sum for both sets
         uint32_t mine = 0;
 #pragma unroll
         for (int s = 0; s < kSets; s++) mine += cnt[s] | ((cnt[s] ? 1u : 0u) << 26);
         const uint32_t tot = row_sum(mine);
-        const uint32_t n_cand = tot & ((1u << 26) - 1u), n_occ = tot >> 26;
+        n_cand = tot & ((1u << 26) - 1u);
+        n_occ = tot >> 26;
+        const float bound = B * 1.0001f;
+#pragma unroll
+        for (int s = 0; s < kSets; s++) {
+            // a neighbour voxel whose nearest face is provably farther than the bound is not read
+            scan_cnt[s] = (lower[s] > bound) ? 0u : cnt[s];
+        }
+        // ---- group-wide prefix over the scanned neighbours in scan order ----
         // best starts at max_sq: "d2 < best" then implies voxel_grid.h:186's d2 < max_sq, and NaN never wins
-        float best = P.max_sq;
-        uint32_t best_c = 0xFFFFFFFFu, best_pi0 = 0;
-        uint32_t T;                       // points actually read
+        best = P.max_sq;
+        best_c = 0xFFFFFFFFu;
+        best_pi0 = 0;
         {
             // chunks of up to four consecutive points of one voxel: nch chunks per scanned voxel
             uint32_t nch[kSets], read = 0;
@@ -449,7 +489,7 @@ __global__ __launch_bounds__(kMatchThreads, kMinWaves) void k_match(MapView map,
             }
             // points actually read (after the exact pruning): one more row sum (an LDS atomic per lane instead cost the
             // kernel's tail 0.3 us: sixteen lanes on one word)
-            T = kChained ? 0u : row_sum(read);  // (only lom_profile_match reads it: not computed inside an align)
+            if constexpr (!kChained) T += row_sum(read);  // (only lom_profile_match reads it: not computed inside an align)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -494,8 +534,15 @@ __global__ __launch_bounds__(kMatchThreads, kMinWaves) void k_match(MapView map,
         // lexicographic min over the group; d2 >= 0 so its bit pattern orders like the value
         // (as two 32-bit row minima -- the distance bits, then the ordinal among the lanes that hold that distance --:
         // half the instructions of four 64-bit compare-and-select steps)
-        const uint32_t w_d = row_min32(__float_as_uint(best));
-        const uint32_t w_c = row_min32(__float_as_uint(best) == w_d ? best_c : 0xFFFFFFFFu);
+        w_d = row_min32(__float_as_uint(best));
+        w_c = row_min32(__float_as_uint(best) == w_d ? best_c : 0xFFFFFFFFu);
+        if constexpr (!kPrev) break;
+        if (!(B < P.max_sq) || w_d <= __float_as_uint(B)) break;  // plain bound, or the temporal bound verified
+        // the old winner is not among this query's candidates any more
+        // (the tables of this row are rewritten: its reads above are complete for this wave)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        }
         const bool valid = w_c != 0xFFFFFFFFu;
         LOM_STAMP(5);  // group minimum known
         // the lane that scanned the winner reads its point again together with the normal (two loads, one round
@@ -510,8 +557,11 @@ __global__ __launch_bounds__(kMatchThreads, kMinWaves) void k_match(MapView map,
             }
             out_idx[q] = idx;
             float4 *rec = reinterpret_cast<float4 *>(out_rec + q);
-            rec[0] = make_float4(s0, s1, s2, valid ? 1.f : 0.f);
-            rec[1] = make_float4(wp.x, wp.y, wp.z, wn.x);
+            if constexpr (kPrev)
+                reinterpret_cast<float *>(rec)[3] = wn.x;  // the source point is there since the first search of this scan
+            else
+                rec[0] = make_float4(sp.x, sp.y, sp.z, wn.x);
+            rec[1] = make_float4(wp.x, wp.y, wp.z, valid ? 1.f : 0.f);
             rec[2] = make_float4(wn.y, wn.z, 0.f, 0.f);
             if (out_stat) {
                 QStat st;
@@ -596,7 +646,7 @@ __device__ __forceinline__ void point_terms(const float4 ra, const float4 rb, co
 {
     const double p[3] = {(double)ra.x, (double)ra.y, (double)ra.z};
     const double o[3] = {(double)rb.x, (double)rb.y, (double)rb.z};
-    const double nn[3] = {(double)rb.w, (double)rc.x, (double)rc.y};
+    const double nn[3] = {(double)ra.w, (double)rc.x, (double)rc.y};
     // cloud_matcher.cpp:54  (rot*local_point + t - plane_origin).dot(plane_normal)
     double uv0 = q2 * p[2] - q3 * p[1];
     double uv1 = q3 * p[0] - q1 * p[2];
@@ -760,7 +810,7 @@ __global__ __launch_bounds__(kEvalThreads) void k_eval(const MatchRec *__restric
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const float4 *r4 = reinterpret_cast<const float4 *>(rec + i);
         const float4 ra = r4[0], rb = r4[1], rc = r4[2];
-        if (ra.w != 0.f) accumulate_point(ra, rb, rc, E.q[0], E.q[1], E.q[2], E.q[3], E.t[0], E.t[1], E.t[2], acc);
+        if (rb.w != 0.f) accumulate_point(ra, rb, rc, E.q[0], E.q[1], E.q[2], E.q[3], E.t[0], E.t[1], E.t[2], acc);
     }
     reduce_and_publish(acc, s_acc, s_cnt, block_counters, n_match_blocks, out_rec, seq, kPublishPlain);
 }
@@ -791,11 +841,11 @@ __global__ __launch_bounds__(kEvalThreads) void k_eval_server(const MatchRec *__
         double acc[28];
 #pragma unroll
         for (int k = 0; k < 28; k++) acc[k] = 0.0;
-        if (ra.w != 0.f) accumulate_point(ra, rb, rc, q0, q1, q2, q3, t0, t1, t2, acc);
+        if (rb.w != 0.f) accumulate_point(ra, rb, rc, q0, q1, q2, q3, t0, t1, t2, acc);
         for (uint32_t i = first + step; i < n; i += step) {
             const float4 *r4 = reinterpret_cast<const float4 *>(rec + i);
             const float4 xa = r4[0], xb = r4[1], xc = r4[2];
-            if (xa.w != 0.f) accumulate_point(xa, xb, xc, q0, q1, q2, q3, t0, t1, t2, acc);
+            if (xb.w != 0.f) accumulate_point(xa, xb, xc, q0, q1, q2, q3, t0, t1, t2, acc);
         }
         reduce_and_publish(acc, s_acc, s_cnt, block_counters, counters_from, out_rec, seq, kPublishHost);
         counters_from = 0;
@@ -1242,7 +1292,7 @@ __device__ __forceinline__ void accumulate_all(const MatchRec *__restrict__ rec,
     for (uint32_t i = first + (uint32_t)kRegPts * step; i < n; i += step) {
         const float4 *r4 = reinterpret_cast<const float4 *>(rec + i);
         const float4 xa = r4[0], xb = r4[1], xc = r4[2];
-        if (xa.w != 0.f) accumulate_point(xa, xb, xc, q0, q1, q2, q3, t0, t1, t2, acc);
+        if (xb.w != 0.f) accumulate_point(xa, xb, xc, q0, q1, q2, q3, t0, t1, t2, acc);
     }
 }
 
@@ -1483,13 +1533,29 @@ __global__ __launch_bounds__(64) void k_sum_records(const double *__restrict__ r
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
-static void pose_args(const float t[3], const float q[4], float max_dist, PoseArgs &P)
+// max_sq: the f32 threshold the f32 squared distances are compared with (strictly below).  findMatchingPairs forms it
+// as max_dist * max_dist in f32 (voxel_grid.h:215); getCorrespondence takes a double (:164), see threshold_f32()
+static void pose_args(const float t[3], const float q[4], float max_sq, PoseArgs &P)
 {
     float R[9];
     rotation_matrix(q, R);  // voxel_grid.h:212 transform.rotationMatrix().cast<double>()
     for (int i = 0; i < 9; i++) P.R[i] = (double)R[i];
     for (int i = 0; i < 3; i++) P.t[i] = (double)t[i];
-    P.max_sq = max_dist * max_dist;  // voxel_grid.h:215
+    P.max_sq = max_sq;
+}
+
+static inline float sq_f32(float max_dist) { return max_dist * max_dist; }  // voxel_grid.h:215
+
+// voxel_grid.h:184-186 compares the f32 squared norm, widened to double, with a double threshold: (double)d2 < max_sq.
+// For f32 d2 that is d2 < the smallest f32 that is >= max_sq (equal to max_sq where that is an f32 value itself, as
+// findMatchingPairs' always is): the kernel's f32 compare with THAT threshold decides every case the same way.
+static inline float threshold_f32(double max_sq)
+{
+    if (!(max_sq > 0.0)) return 0.f;                 // nothing is < 0 (NaN: every compare false)
+    if (max_sq >= (double)FLT_MAX) return INFINITY;  // every finite d2 passes (an infinite d2 does only below an infinite threshold: not reproduced)
+    float f = (float)max_sq;                         // round to nearest
+    if ((double)f < max_sq) f = std::nextafterf(f, INFINITY);
+    return f;
 }
 
 constexpr uint32_t kMaxMatchBlocks = 256u * (uint32_t)kMatchMinWaves;  // one resident round: kMatchMinWaves workgroups of 4 waves per CU
@@ -1513,6 +1579,9 @@ struct ScanCtx {
     size_t stride;
     uint32_t n;
     uint32_t match_blocks;
+    // the records of a previous search of THIS scan against this map are at scan_on (outer iterations >= 2 of an align):
+    // the next search may take its temporal pruning bound from them (k_match<..., kPrev>)
+    bool have_prev = false;
     int prof_used = 0;
     double launch_s = 0.0, wait_s = 0.0;  // host time inside launch calls / polling for results
 };
@@ -1542,13 +1611,13 @@ static double *d_sums(lom_map *m) { return (double *)m->results.p; }
 static void server_stop(lom_map *m);
 
 // chained: the pose comes from the AlignState in HBM (t, q unused)
-static int launch_match(ScanCtx &c, const float t[3], const float q[4], float max_dist, bool stats,
+static int launch_match(ScanCtx &c, const float t[3], const float q[4], float max_sq, bool stats,
                         bool chained = false)
 {
     lom_map *m = c.m;
     PoseArgs P;
     std::memset(&P, 0, sizeof P);
-    if (!chained) pose_args(t, q, max_dist, P);
+    if (!chained) pose_args(t, q, max_sq, P);
     c.match_blocks = c.n ? match_grid(c.n) : 0;
     server_stop(m);  // the previous outer iteration's evaluation server leaves before the new search
     const double t_launch = now_s();
@@ -1584,11 +1653,16 @@ static int launch_match(ScanCtx &c, const float t[3], const float q[4], float ma
                                (unsigned long long *)nullptr, as);
         };
         QStat *st = (stats && !chained) ? (QStat *)m->scan_stats.p : (QStat *)nullptr;
-        if (chained)
+        if (chained && m->opt_no_temporal)
+            launch(k_match<kMatchG, kMatchRows, kMatchMinWaves, false, true, false>, st, (const AlignState *)m->align_state.p);
+        else if (chained)  // (always behind a search of the same scan: launch_pair's first pair is not chained)
             launch(k_match<kMatchG, kMatchRows, kMatchMinWaves, false, true>, st, (const AlignState *)m->align_state.p);
+        else if (c.have_prev && !m->opt_no_temporal)
+            launch(k_match<kMatchG, kMatchRows, kMatchMinWaves, false, false, true>, st, (const AlignState *)nullptr);
         else
             launch(k_match<kMatchG, kMatchRows, kMatchMinWaves>, st, (const AlignState *)nullptr);
         LOM_HIP(m, hipGetLastError());
+        c.have_prev = true;
         if (m->profiling) LOM_HIP(m, hipEventRecord(e1, m->stream));
     }
     c.launch_s += now_s() - t_launch;
@@ -1745,7 +1819,7 @@ static int hook_match_eval(void *user, const float pt[3], const float pq[4], con
                            double out[LOM_NSUMS])
 {
     ScanCtx &c = *(ScanCtx *)user;
-    int rc = launch_match(c, pt, pq, 0.3f, false);  // cloud_matcher.cpp:139
+    int rc = launch_match(c, pt, pq, sq_f32(0.3f), false);  // cloud_matcher.cpp:139
     if (rc != LOM_OK) return rc;
     return launch_eval(c, q, t, true, out);
 }
@@ -1900,7 +1974,7 @@ static int align_chained(lom_map *m, const char *d_src, size_t n, size_t stride,
     int lm_events = 0;
     auto launch_pair = [&]() -> int {
         const int i = launched;
-        int r = launch_match(c, guess_t, guess_q, 0.3f, false, i > 0);
+        int r = launch_match(c, guess_t, guess_q, sq_f32(0.3f), false, i > 0);
         if (r != LOM_OK) return r;
         const double t_l = now_s();
         m->lm_seq += 8;  // a solve spends at most 5 evaluations
@@ -2005,6 +2079,7 @@ static int align_chained(lom_map *m, const char *d_src, size_t n, size_t stride,
     }
     st.host_launch_ms = c.launch_s * 1e3;
     st.host_wait_ms = c.wait_s * 1e3;
+    st.lm_workgroups = (int32_t)nb;
     if (stats) *stats = st;
     if (trace_out) {
         LOM_HIP(m, hipMemcpyAsync(trace_out, d_trace, 201 * 8, hipMemcpyDeviceToHost, m->stream));
@@ -2125,8 +2200,9 @@ using namespace lom;
 
 extern "C" {
 
-int64_t lom_match_find_pairs(lom_map *m, const float *src, size_t n, size_t stride, const float t[3],
-                             const float q[4], float max_dist, lom_correspondence *out)
+// one search (or two: first at the pose (t0, q0), then at (t, q) with the first one's records as the temporal bound)
+static int64_t find_pairs_core(lom_map *m, const float *src, size_t n, size_t stride, const float *t0, const float *q0,
+                               const float t[3], const float q[4], float max_sq, lom_correspondence *out)
 {
     if (!m || (n && (!src || !out)) || !t || !q || stride < 12 || (stride & 3)) return LOM_ERR_ARG;
     if (n >= 0x7FFFFFFFull) return LOM_ERR_ARG;
@@ -2138,7 +2214,8 @@ int64_t lom_match_find_pairs(lom_map *m, const float *src, size_t n, size_t stri
     if ((rc = stage_scan(m, src, n, stride, &d_src)) != LOM_OK) return rc;
     if ((rc = scan_buffers(m, (uint32_t)n, true)) != LOM_OK) return rc;
     ScanCtx c{m, d_src, stride, (uint32_t)n, 0};
-    if ((rc = launch_match(c, t, q, max_dist, true)) != LOM_OK) return rc;
+    if (t0 && q0 && (rc = launch_match(c, t0, q0, max_sq, true)) != LOM_OK) return rc;
+    if ((rc = launch_match(c, t, q, max_sq, true)) != LOM_OK) return rc;
     std::vector<int32_t> idx(n);
     std::vector<MatchRec> on(n);
     std::vector<QStat> st(n);
@@ -2162,6 +2239,26 @@ int64_t lom_match_find_pairs(lom_map *m, const float *src, size_t n, size_t stri
         valid += idx[i] >= 0;
     }
     return valid;
+}
+
+int64_t lom_match_find_pairs(lom_map *m, const float *src, size_t n, size_t stride, const float t[3],
+                             const float q[4], float max_dist, lom_correspondence *out)
+{
+    return find_pairs_core(m, src, n, stride, nullptr, nullptr, t, q, sq_f32(max_dist), out);
+}
+
+int64_t lom_match_find_pairs_sq(lom_map *m, const float *src, size_t n, size_t stride, const float t[3],
+                                const float q[4], double max_dist_sq, lom_correspondence *out)
+{
+    return find_pairs_core(m, src, n, stride, nullptr, nullptr, t, q, threshold_f32(max_dist_sq), out);
+}
+
+int64_t lom_debug_find_pairs_after(lom_map *m, const float *src, size_t n, size_t stride, const float t_prev[3],
+                                   const float q_prev[4], const float t[3], const float q[4], float max_dist,
+                                   lom_correspondence *out)
+{
+    if (!t_prev || !q_prev) return LOM_ERR_ARG;
+    return find_pairs_core(m, src, n, stride, t_prev, q_prev, t, q, sq_f32(max_dist), out);
 }
 
 int lom_comm_attach_p2p(lom_map *m, lom_host_comm *hc)
@@ -2270,9 +2367,11 @@ int lom_profile_match(lom_map *m, const float *d_src, size_t n, size_t stride, c
     hipEvent_t e0 = nullptr, e1 = nullptr;
     LOM_HIP(m, hipEventCreate(&e0));
     LOM_HIP(m, hipEventCreate(&e1));
-    rc = launch_match(c, t, q, max_dist, false);  // warm-up
+    // warm-up; it also leaves the records the launches behind it take their temporal bound from: the train is what the
+    // searches of outer iterations >= 2 of an align run (LOM_OPT_NO_TEMPORAL_BOUND: what the first one runs)
+    rc = launch_match(c, t, q, sq_f32(max_dist), false);
     if (rc == LOM_OK) rc = hipEventRecord(e0, m->stream) == hipSuccess ? LOM_OK : LOM_ERR_HIP;
-    for (int i = 0; rc == LOM_OK && i < reps; i++) rc = launch_match(c, t, q, max_dist, false);
+    for (int i = 0; rc == LOM_OK && i < reps; i++) rc = launch_match(c, t, q, sq_f32(max_dist), false);
     if (rc == LOM_OK) rc = hipEventRecord(e1, m->stream) == hipSuccess ? LOM_OK : LOM_ERR_HIP;
     // the same launches with one event pair EACH (what the sampled in-loop measurement of lom_match_align* does):
     // the difference to the train above is what an event pair adds to a single short kernel
@@ -2281,7 +2380,7 @@ int lom_profile_match(lom_map *m, const float *d_src, size_t n, size_t stride, c
         m->profiling = true;
         c.prof_used = 0;
         const int pr = std::min(reps, 128);
-        for (int i = 0; rc == LOM_OK && i < pr; i++) rc = launch_match(c, t, q, max_dist, false);
+        for (int i = 0; rc == LOM_OK && i < pr; i++) rc = launch_match(c, t, q, sq_f32(max_dist), false);
         m->profiling = false;
         if (rc == LOM_OK && hipStreamSynchronize(m->stream) != hipSuccess) rc = LOM_ERR_HIP;
         for (int i = 0; rc == LOM_OK && i < c.prof_used; i++) {
@@ -2345,7 +2444,7 @@ int lom_debug_eval_sums(lom_map *m, const float *src, size_t n, size_t stride, c
     ScanCtx c{m, d_src, stride, (uint32_t)n, 0};
     const bool was = m->profiling;
     m->profiling = false;
-    rc = launch_match(c, pose_t, pose_q, 0.3f, false);  // cloud_matcher.cpp:139
+    rc = launch_match(c, pose_t, pose_q, sq_f32(0.3f), false);  // cloud_matcher.cpp:139
     if (rc == LOM_OK) rc = launch_eval(c, q, t, true, out);
     server_stop(m);
     m->profiling = was;
@@ -2397,7 +2496,7 @@ int lom_debug_match_stamps(lom_map *m, const float *d_src, size_t n, size_t stri
     unsigned long long *d_st = nullptr;
     LOM_HIP(m, hipMalloc(&d_st, (size_t)nb * 64));
     PoseArgs P;
-    pose_args(t, q, max_dist, P);
+    pose_args(t, q, sq_f32(max_dist), P);
     for (int rep = 0; rep < 3; rep++)  // the last launch's stamps are kept (warm caches, like an align)
         hipLaunchKernelGGL((k_match<kMatchG, kMatchRows, kMatchMinWaves, true>), dim3(nb), dim3(kMatchThreads), 0, m->stream, view_of(m),
                            (const char *)d_src, stride, (uint32_t)n, P, (int32_t *)m->scan_idx.p,
@@ -2442,6 +2541,7 @@ int lom_match_align_repeat(lom_map *m, const float *d_src, size_t n, size_t stri
         acc.host_fallback += st.host_fallback;
         acc.lm_kernel_ms += st.lm_kernel_ms;
         acc.lm_profiled_launches += st.lm_profiled_launches;
+        acc.lm_workgroups = st.lm_workgroups;
     }
     if (total) *total = acc;
     return LOM_OK;

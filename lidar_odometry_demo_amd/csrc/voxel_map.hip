@@ -978,6 +978,7 @@ static int map_status(lom_map *m)
 // The handle's last single-pass insert has not been looked at yet (a caller that never asks for lom_map_status):
 // before anything consumes or changes the map, see whether its in-kernel scan gave up, and redo it if so.
 // Callers that check lom_map_status() themselves (the streaming path) never pay this read-back.
+static int settle_pending_locked(lom_map *m);
 int resolve_pending(lom_map *m)
 {
     if (m->parent) {
@@ -987,21 +988,32 @@ int resolve_pending(lom_map *m)
         // the context's stream behind the map's.  (Nobody changes the map while contexts are in use; several contexts
         // may arrive here together after a change, hence the lock.)
         lom_map *p = m->parent;
-        if (!p->pending_n && m->seen_mutations == p->mutations) return LOM_OK;
+        if (!p->pending_n.load(std::memory_order_acquire) && m->seen_mutations == p->mutations.load(std::memory_order_acquire))
+            return LOM_OK;
         std::lock_guard<std::mutex> lock(p->settle_mutex);
         if (p->pending_n) {
-            const int rc = resolve_pending(p);
+            const int rc = settle_pending_locked(p);
             if (rc != LOM_OK) return set_error(m, rc, p->last_error.c_str());
         }
-        if (m->seen_mutations != p->mutations) {
+        const uint64_t now = p->mutations;
+        if (m->seen_mutations != now) {
             if (!m->parent_ev) LOM_HIP(m, hipEventCreateWithFlags(&m->parent_ev, hipEventDisableTiming));
             LOM_HIP(m, hipEventRecord(m->parent_ev, p->stream));
             LOM_HIP(m, hipStreamWaitEvent(m->stream, m->parent_ev, 0));
-            m->seen_mutations = p->mutations;
+            m->seen_mutations = now;
         }
         return LOM_OK;
     }
-    if (!m->pending_n) return LOM_OK;
+    if (!m->pending_n.load(std::memory_order_acquire)) return LOM_OK;
+    // the map's own caller: contexts of this map may be settling the same insert right now
+    std::lock_guard<std::mutex> lock(m->settle_mutex);
+    return settle_pending_locked(m);
+}
+
+// the caller holds m->settle_mutex (m is a map, not a context)
+static int settle_pending_locked(lom_map *m)
+{
+    if (!m->pending_n) return LOM_OK;  // somebody else settled it while this thread waited for the lock
     int rc = read_words(m, 7, 1);
     if (rc != LOM_OK) return rc;
     const size_t n = m->pending_n;
@@ -1248,7 +1260,13 @@ int lom_scan_create(lom_map *map, lom_scan **out)
     *out = nullptr;
     if (map->parent) return set_error(map, LOM_ERR_ARG, "a scan context cannot be the keyframe of another");
     LOM_HIP(map, hipSetDevice(map->device));
-    int rc = refresh_nvox(map);  // settles a pending insert: nothing mutates the keyframe while contexts read it
+    int rc;
+    {   // settles a pending insert (nothing mutates the keyframe while contexts read it).  Under the map's settle lock:
+        // the C++ mirror's worker threads create their contexts -- and other contexts make their first call -- together.
+        std::lock_guard<std::mutex> lock(map->settle_mutex);
+        rc = settle_pending_locked(map);
+        if (rc == LOM_OK) rc = refresh_nvox(map);
+    }
     if (rc != LOM_OK) return rc;
     lom_map *c = new (std::nothrow) lom_map();
     if (!c) return set_error(map, LOM_ERR_OOM, "host allocation");
@@ -1257,6 +1275,7 @@ int lom_scan_create(lom_map *map, lom_scan **out)
     c->opt_host_lm = map->opt_host_lm;
     c->opt_debug_lm = map->opt_debug_lm;
     c->opt_debug_timing = map->opt_debug_timing;
+    c->opt_no_temporal = map->opt_no_temporal;
     c->patience_ticks = map->patience_ticks;
     if (handle_setup(c) != LOM_OK) {
         map->last_error = g_create_error;
@@ -1292,6 +1311,11 @@ int64_t lom_scan_find_pairs(lom_scan *s, const float *src, size_t n, size_t stri
 {
     return lom_match_find_pairs(reinterpret_cast<lom_map *>(s), src, n, stride, t, q, max_dist, out);
 }
+int64_t lom_scan_find_pairs_sq(lom_scan *s, const float *src, size_t n, size_t stride, const float t[3], const float q[4],
+                               double max_dist_sq, lom_correspondence *out)
+{
+    return lom_match_find_pairs_sq(reinterpret_cast<lom_map *>(s), src, n, stride, t, q, max_dist_sq, out);
+}
 
 int lom_map_create(float voxel_size, size_t max_points, size_t capacity_hint, int device, lom_map **out)
 {
@@ -1323,6 +1347,7 @@ int lom_map_create(float voxel_size, size_t max_points, size_t capacity_hint, in
     if (const char *e = getenv("LOM_TABLE_SLOTS_PER_VOXEL")) m->table_slots_per_voxel = (uint32_t)std::min(256, std::max(2, atoi(e)));
     m->opt_debug_lm = getenv("LOM_DEBUG_LM") != nullptr;
     m->opt_debug_timing = getenv("LOM_DEBUG_TIMING") != nullptr;
+    m->opt_no_temporal = getenv("LOM_NO_TEMPORAL") != nullptr;
     if (handle_setup(m) != LOM_OK) {
         lom_map_destroy(m);
         return LOM_ERR_HIP;
@@ -1410,6 +1435,7 @@ int lom_map_set_option(lom_map *m, int option, int64_t value)
         return LOM_OK;
     case LOM_OPT_DEBUG_LM_STAMPS: m->opt_debug_lm = value != 0; return LOM_OK;
     case LOM_OPT_DEBUG_TIMING: m->opt_debug_timing = value != 0; return LOM_OK;
+    case LOM_OPT_NO_TEMPORAL_BOUND: m->opt_no_temporal = value != 0; return LOM_OK;
     case LOM_OPT_TEST_GIVE_UP_AT_OUTER:
         if (value < -1 || value >= 35) return LOM_ERR_ARG;
         m->test_give_up_outer = (int)value;

@@ -512,6 +512,14 @@ static void query_one(const orc_map *m, const float query[3], double max_sq, orc
     }
 }
 
+/* voxel_grid.h:164 as the reference declares it: one f32 query already in the map frame, the SQUARED threshold a double */
+int orc_get_correspondence(const orc_map *m, const float query[3], double max_correspondence_distance_sq, orc_corr *out)
+{
+    if (!m || !query || !out) return ORC_ERR_ARG;
+    query_one(m, query, max_correspondence_distance_sq, out);
+    return out->index >= 0 ? 1 : 0;
+}
+
 typedef struct {
     const orc_map *m;
     const float *src;

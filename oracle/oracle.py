@@ -251,6 +251,18 @@ class VoxelGrid:
         return out
 
 
+    def getCorrespondence(self, query, max_correspondence_distance_sq):
+        """voxel_grid.h:164-204: one f32 query in the map frame, the squared threshold a double."""
+        out = np.zeros(1, CORR_DTYPE)
+        fn = lib().orc_get_correspondence
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]
+        fn.restype = C.c_int
+        rc = fn(self._h, _f3(query), float(max_correspondence_distance_sq), out.ctypes.data)
+        if rc < 0:
+            raise RuntimeError(f"oracle error {rc}")
+        return out[0]
+
+
 class CloudMatcher:
     """CPU restatement of reference src/cloud_matcher.cpp:105-178."""
 

@@ -999,3 +999,166 @@ def test_scan_contexts_align_concurrently_against_one_keyframe(lom):
         assert a.translation.tobytes() == b.translation.tobytes() and a.rotation.tobytes() == b.rotation.tobytes(), i
     for cx in ctxs:
         cx.close()
+
+
+# ---- the temporal pruning bound of the align's searches (csrc/match.hip) ---------------------------------------------
+
+@pytest.mark.parametrize("voxel,K", [(0.5, 20), (0.2, 20), (0.25, 3)])
+def test_temporal_bound_never_changes_a_search(lom, oracle, fixture_cloud, voxel, K):
+    """Outer iterations >= 2 of an align prune with the previous iteration's winner (its distance at the new pose
+    bounds the minimum from above).  lom_debug_find_pairs_after runs exactly that pair of searches for ANY two poses;
+    the second search must equal the oracle's search at the second pose entry for entry -- winner, f32 distance,
+    counts -- whether the pose moved by a millimetre (the bound is tight), not at all (ties with the old winner), by
+    metres (the old winner has left the 27 voxels: found out, searched again at the plain bound) or back again, with
+    voxels smaller than the search radius (0.2 m: the old winner may lie two voxels away) and with short voxels."""
+    _, xyzn = fixture_cloud
+    g, og = _both(lom, oracle, voxel, K)
+    g.addCloud(xyzn[:, :3], xyzn[:, 3:])
+    og.addCloud(xyzn[:, :3], xyzn[:, 3:])
+    src = np.ascontiguousarray(xyzn[::6, :3])
+    z = (0, 0, 1)
+    poses = [((0, 0, 0), (1, 0, 0, 0)),
+             ((0.001, -0.001, 0.0005), scenes.angle_axis_q(0.0002, z)),
+             ((0.02, -0.03, 0.01), scenes.angle_axis_q(0.004, z)),
+             ((0.15, 0.1, -0.05), scenes.angle_axis_q(0.02, scenes._unit((0.2, 1, 0.1)))),
+             ((1.5, -2.0, 0.3), scenes.angle_axis_q(0.3, z)),
+             ((40.0, 0.0, 0.0), (1, 0, 0, 0))]                 # nothing in reach at all: no winner to take a bound from
+    want = {i: og.findMatchingPairs(src, oracle.Pose3D(*p), 0.3) for i, p in enumerate(poses)}
+    for a, b in [(0, 0), (0, 1), (1, 0), (0, 2), (2, 3), (3, 2), (0, 4), (4, 0), (5, 0), (0, 5), (4, 4), (3, 1)]:
+        got = g.findMatchingPairsAfter(src, lom.Pose3D(*poses[a]), lom.Pose3D(*poses[b]), 0.3)
+        _assert_same_pairs(got, want[b])
+    # other gates: 5 cm (most old winners are beyond it at the new pose), 1 m (27 voxels do not cover it)
+    for d in (0.05, 1.0):
+        w = og.findMatchingPairs(src, oracle.Pose3D(*poses[2]), d)
+        _assert_same_pairs(g.findMatchingPairsAfter(src, lom.Pose3D(*poses[0]), lom.Pose3D(*poses[2]), d), w)
+        _assert_same_pairs(g.findMatchingPairsAfter(src, lom.Pose3D(*poses[4]), lom.Pose3D(*poses[2]), d), w)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_temporal_bound_randomized(lom, oracle, seed):
+    """Random maps (crowded double-width voxel around 0, duplicates: ties), random pose pairs."""
+    rng = np.random.default_rng(4100 + seed)
+    voxel, K = float(rng.choice([0.2, 0.4, 0.5, 1.0])), int(rng.choice([1, 2, 7, 20]))
+    g, og = _both(lom, oracle, voxel, K)
+    n = int(rng.integers(2000, 30000))
+    centers = rng.uniform(-6, 6, size=(int(rng.integers(3, 60)), 3))
+    pts = (centers[rng.integers(0, len(centers), n)] + rng.normal(0, rng.uniform(0.05, 0.8), (n, 3))).astype(np.float32)
+    pts[rng.random(n) < 0.05] *= np.float32(0.01)
+    pts[n // 2:n // 2 + n // 10] = pts[:n // 10]               # exact duplicates: equal distances
+    nrm = rng.standard_normal((n, 3)).astype(np.float32)
+    g.addCloud(pts, nrm)
+    og.addCloud(pts, nrm)
+    q = (pts[rng.integers(0, n, 4000)] + rng.normal(0, 0.1, (4000, 3))).astype(np.float32)
+    for _ in range(4):
+        p0 = (rng.uniform(-0.3, 0.3, 3), scenes.angle_axis_q(rng.uniform(-0.05, 0.05), scenes._unit(rng.standard_normal(3))))
+        step = float(rng.choice([0.0, 1e-3, 0.05, 0.6]))
+        p1 = (p0[0] + rng.uniform(-step, step, 3), scenes.angle_axis_q(rng.uniform(-0.05, 0.05), scenes._unit(rng.standard_normal(3))))
+        d = float(rng.choice([0.1, 0.3, 0.3, 0.7]))
+        _assert_same_pairs(g.findMatchingPairsAfter(q, lom.Pose3D(*p0), lom.Pose3D(*p1), d),
+                           og.findMatchingPairs(q, oracle.Pose3D(*p1), d))
+
+
+def test_no_temporal_switch_gives_the_same_align(lom, oracle):
+    """LOM_OPT_NO_TEMPORAL_BOUND only changes what is read: pose bits, iteration counts and candidate counts of an
+    align are the same with and without it (device-resident loop and host-driven loop)."""
+    sm = scenes.small_synth_case()
+    res = {}
+    for host in (0, 1):
+        for off in (0, 1):
+            g = lom.VoxelGrid(0.5, 20)
+            g.setOption(lom.capi.OPT_HOST_LM, host)
+            g.setOption(lom.capi.OPT_NO_TEMPORAL_BOUND, off)
+            g.addCloud(sm["map_xyz"], sm["map_nrm"])
+            m = lom.CloudMatcher()
+            p = m.align(g, sm["scan"], lom.Pose3D((0.2, -0.2, 0.0), scenes.angle_axis_q(0.01, (0, 0, 1))))
+            res[(host, off)] = (p.translation.tobytes(), p.rotation.tobytes(),
+                                tuple(m.stats[k] for k in ("outer_iterations", "lm_iterations", "evaluations", "queries",
+                                                           "cand_total", "occ_total", "valid_last")))
+    assert res[(0, 0)] == res[(0, 1)]
+    assert res[(1, 0)] == res[(1, 1)]
+    assert res[(0, 0)][2] == res[(1, 0)][2]
+
+
+# ---- getCorrespondence's squared threshold (voxel_grid.h:164: a double) ------------------------------------------------
+
+def test_squared_threshold_is_taken_as_it_is(lom, oracle):
+    """lom_match_find_pairs_sq hands the reference's `double max_correspondence_distance_sq` over without a root: a
+    stored point passes iff (double)(f32 squared distance) < max_sq (voxel_grid.h:184-186).  Thresholds that are no
+    square of an f32, exactly a candidate's squared distance (strict: rejected), the next double above it
+    (accepted), and the square root's round trip that the mirror used before (differs by an ulp for some)."""
+    rng = np.random.default_rng(12)
+    g, og = _both(lom, oracle, 0.5, 5)
+    pts = rng.uniform(-2, 2, (3000, 3)).astype(np.float32)
+    g.addCloudWithoutNormals(pts)
+    og.addCloudWithoutNormals(pts)
+    qs = rng.uniform(-2, 2, (60, 3)).astype(np.float32)
+    loose = og.findMatchingPairs(qs, oracle.Pose3D(), 2.0)
+    checked = 0
+    for q, c in zip(qs, loose):
+        if c["index"] < 0:
+            continue
+        d2 = float(c["sq_dist"])                               # the winner's f32 squared distance, exactly
+        for thr in (d2, np.nextafter(d2, np.inf), np.nextafter(d2, 0.0), d2 * (1 + 2e-8), d2 * (1 - 2e-8), 0.0899999, 0.09,
+                    float(np.float32(0.3) * np.float32(0.3)), 1e-30, 0.0, -1.0, 1e300):
+            want = og.getCorrespondence(q, thr)
+            got = g.getCorrespondence(q, thr)
+            assert got["index"] == want["index"], (q, thr)
+            assert got["sq_dist"].tobytes() == want["sq_dist"].tobytes()
+            assert got["n_cand"] == want["n_cand"] and got["n_occ"] == want["n_occ"]
+            checked += 1
+        assert g.getCorrespondence(q, d2)["index"] != c["index"]            # strict: the winner itself is rejected ...
+        assert g.getCorrespondence(q, np.nextafter(d2, np.inf))["index"] == c["index"]   # ... and passes one ulp above
+    assert checked > 300
+
+
+# ---- contexts created and first used by several threads at once, behind an insert nobody has looked at -------------------
+
+def test_contexts_created_concurrently_settle_a_pending_insert_once(lom, oracle, fixture_cloud):
+    """The C++ mirror's worker threads create their scan contexts -- and make their first call -- together.  If the
+    keyframe's last insert was only enqueued (lom_map_add_points_device_nowait) and its in-kernel scan gave up
+    (LOM_OPT_TEST_GRID_GIVE_UP), exactly ONE of them redoes it, under the map's settle lock: the map is bytewise the
+    oracle's afterwards (a second redo would fill voxels with duplicates), the redo counter says 1, and every thread's
+    search equals the oracle's."""
+    import threading
+    import torch
+
+    _, xyzn = fixture_cloud
+    xyz, nrm = np.ascontiguousarray(xyzn[:50000, :3]), np.ascontiguousarray(xyzn[:50000, 3:])
+    L = lom.capi.lib()
+    src = np.ascontiguousarray(xyz[::9])
+    for trial in range(3):
+        g, og = _both(lom, oracle, 0.25, 20)
+        og.addCloud(xyz, nrm)
+        want = og.findMatchingPairs(src, oracle.Pose3D(), 0.3)
+        d_xyz, d_nrm = torch.from_numpy(xyz).cuda(), torch.from_numpy(nrm).cuda()
+        torch.cuda.synchronize()
+        g.setOption(lom.capi.OPT_TEST_GRID_GIVE_UP, 1 + trial)
+        lom.capi.check(L.lom_map_add_points_device_nowait(g.handle, d_xyz.data_ptr(), d_nrm.data_ptr(), len(xyz), 12), g.handle)
+        n_threads = 6
+        start = threading.Barrier(n_threads)
+        errors, got = [], [None] * n_threads
+
+        def worker(i):
+            try:
+                start.wait()
+                cx = lom.ScanContext(g)                        # lom_scan_create: settles the map
+                pairs = (lom.capi.Correspondence * len(src))()
+                rc = L.lom_scan_find_pairs(cx.handle, src.ctypes.data, len(src), 12, lom.capi.f3((0, 0, 0)),
+                                           lom.capi.f4((1, 0, 0, 0)), 0.3, pairs)
+                got[i] = (rc, np.frombuffer(pairs, dtype=lom.capi.CORR_DTYPE).copy())
+                cx.close()
+            except Exception as e:  # noqa: BLE001
+                errors.append((i, repr(e)))
+
+        th = [threading.Thread(target=worker, args=(i,)) for i in range(n_threads)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not errors, errors
+        assert g.debugCounter() == 1, g.debugCounter()
+        _assert_same_map(g, og)
+        for rc, pairs in got:
+            assert rc == int((want["index"] >= 0).sum())
+            _assert_same_pairs(pairs, want)
+        del d_xyz, d_nrm

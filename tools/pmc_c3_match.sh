@@ -14,4 +14,4 @@ pass() {
   python3 "$ROOT/tools/pmc_summary.py" "$OUT/raw_$name" k_match > "$OUT/pmc_${2:-C3}_$name.txt" 2>/dev/null
   rm -rf "$OUT/raw_$name"
 }
-pass sq SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU "$2"
+pass sq SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU
