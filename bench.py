@@ -411,6 +411,21 @@ def match_roofline(n_queries, alg_per_launch, req_per_launch, avg_us, traffic, t
     return roof
 
 
+def counted_replay(lom, grid, d_scan, guess):
+    """SURVEY.md 8(d)'s algorithmic bytes need cand(q), the stored points of all occupied voxels among a query's 27
+    neighbours -- a count of the reference ALGORITHM that the product's searches do not produce (a neighbour the bound
+    prunes is not even looked up).  One untimed replay of the same align with LOM_OPT_COUNT_CANDIDATES on gives them
+    exactly: the align is a pure function of its inputs, same poses, same iterations."""
+    grid.setOption(lom.capi.OPT_COUNT_CANDIDATES, 1)
+    try:
+        _, tot = lom.align_repeat(grid, d_scan.data_ptr(), d_scan.shape[0], guess, 1)
+    finally:
+        grid.setOption(lom.capi.OPT_COUNT_CANDIDATES, 0)
+    return {"algorithmic_bytes_per_launch": tot["algorithmic_bytes"] / max(tot["match_launches"], 1),
+            "cand_total": tot["cand_total"], "occ_total": tot["occ_total"], "queries": tot["queries"],
+            "outer_iterations": tot["outer_iterations"]}
+
+
 def align_block(lom, torch, work, dev, steps, warmup_aligns=200):
     """A short block of aligns of another configuration on this GPU (the default run's extra_configs): map build,
     warm-up, `steps` aligns issued back to back from compiled code, k_match / k_lm durations from HIP events on
@@ -437,7 +452,7 @@ def align_block(lom, torch, work, dev, steps, warmup_aligns=200):
     prof = max(tot["profiled_launches"], 1)
     match_us = max(tot["match_kernel_ms"] * 1e3 / prof - overhead, 1e-3)
     lm_us = max(tot["lm_kernel_ms"] * 1e3 / max(tot["lm_profiled_launches"], 1) - overhead, 1e-3)
-    alg = tot["algorithmic_bytes"] / max(tot["match_launches"], 1)
+    alg = counted_replay(lom, grid, d_scan, guess)["algorithmic_bytes_per_launch"]
     n = int(d_scan.shape[0])
     return {
         "workload": work["name"], "steps": steps, "ms_per_step": elapsed / steps * 1e3,
@@ -603,7 +618,7 @@ def main():
     # exactly K steps, issued back to back from compiled code (the reference's callers are C++)
     pose, tot = lom.align_repeat(grid, d_scan.data_ptr(), d_scan.shape[0], guess, args.steps)
     queries, launches = tot["queries"], tot["match_launches"]
-    match_ms, alg_bytes = tot["match_kernel_ms"], tot["algorithmic_bytes"]
+    match_ms = tot["match_kernel_ms"]
     profiled = tot["profiled_launches"]
     outer, evals = tot["outer_iterations"], tot["evaluations"]
     launch_ms, wait_ms = tot["host_launch_ms"], tot["host_wait_ms"]
@@ -616,6 +631,16 @@ def main():
         elapsed = float(t.item())
     lm_ms, lm_profiled = tot["lm_kernel_ms"], tot["lm_profiled_launches"]
     valid_last = tot["valid_last"]
+    # the reference-algorithm counts of this align (all ranks take part: an align is a sequence of exchanges), untimed
+    replay = counted_replay(lom, grid, d_scan, guess)
+    # ... and what producing them costs the product: one block of K steps with the counts on (never `value`)
+    grid.setOption(lom.capi.OPT_COUNT_CANDIDATES, 1)
+    fence()
+    tc = time.perf_counter()
+    lom.align_repeat(grid, d_scan.data_ptr(), d_scan.shape[0], guess, args.steps)
+    fence()
+    counted_ms = (time.perf_counter() - tc) / args.steps * 1e3
+    grid.setOption(lom.capi.OPT_COUNT_CANDIDATES, 0)
 
     # spread: EXTRA_BLOCKS further blocks of the same K steps, each fenced like the official one (never `value`)
     block_ms = [elapsed / args.steps * 1e3]
@@ -678,7 +703,7 @@ def main():
         event_overhead_us = max(0.0, pair_us - train_us)
         in_loop_raw_us = match_ms * 1e3 / max(profiled, 1)
         in_loop_us = max(in_loop_raw_us - event_overhead_us, 1e-3) if profiled else train_us
-        alg_per_launch = alg_bytes / max(launches, 1) / n      # counters are totals over ranks after the exchange
+        alg_per_launch = replay["algorithmic_bytes_per_launch"] / n      # counters are totals over ranks after the exchange
         req_per_launch = train_requested if n == 1 else None   # counted at the final pose (the train)
         achieved = alg_per_launch / (in_loop_us * 1e-6) / 1e9
         traffic, traffic_source = traffic_record(args.config) if n == 1 else (None, None)
@@ -692,6 +717,10 @@ def main():
             "train_note": "200 back-to-back launches at the final pose under one event pair (best case: warm caches, "
                           "converged pose)",
             "launches": launches,
+            "algorithmic_bytes_from": "a counted replay of the same align outside the timed region (LOM_OPT_COUNT_CANDIDATES: "
+                                      "every query looks up all 27 slots and tallies the reference algorithm's cand(q)); the "
+                                      "timed searches do not look up a neighbour voxel that the distance bound prunes",
+            "ms_per_step_with_counts": counted_ms,
         }, big_map=(args.config != "C2"))
         # -- the other kernels of the path
         lm_raw_us = lm_ms * 1e3 / max(lm_profiled, 1)

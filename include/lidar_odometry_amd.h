@@ -299,6 +299,14 @@ typedef enum {
                                           winner (exact, verified per query: csrc/match.hip "temporal bound"); results
                                           are the same either way, this switch exists for A/B timing (LOM_NO_TEMPORAL=1
                                           in the environment at create) */
+    LOM_OPT_COUNT_CANDIDATES = 6,      /* 1: every search also produces the counts of the reference ALGORITHM -- occupied voxels
+                                          among the 27 neighbours and their stored points, per query (lom_correspondence.n_cand
+                                          / n_occ) and summed (lom_align_stats.cand_total / occ_total / algorithmic_bytes: SURVEY
+                                          8d's cand(q)) -- which takes all 27 slot loads per query.  Default 0: a neighbour voxel
+                                          that the distance bound prunes is not looked up at all (same winners, same poses: the
+                                          result cannot depend on a voxel none of whose points could win) and those fields read
+                                          0.  LOM_COUNT_CANDIDATES=1 in the environment at create.  bench.py times the default
+                                          and takes the algorithmic bytes from a counted replay of the same align. */
     LOM_OPT_TEST_GIVE_UP_AT_OUTER = 100, /* k: the k_lm of outer iteration k of the NEXT align behaves as if its
                                           workgroups had timed out waiting (one shot; -1 = off) */
     LOM_OPT_TEST_GRID_GIVE_UP = 101,   /* b >= 0: in the NEXT map-maintenance call with an in-kernel scan, workgroups

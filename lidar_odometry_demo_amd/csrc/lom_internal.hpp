@@ -78,6 +78,8 @@ struct MapView {
     uint32_t K;
     float voxel_size;
     float inv_voxel_size;  // 1 / voxel_size when that is exact (power of two), else 0
+    float prune_slack;     // 1e-4f * voxel_size (f32 product): the absolute slack of k_match's face-distance bounds, as a
+                           // kernel argument so that it lives in a scalar register
 };
 
 // pose as the kernels consume it
@@ -236,6 +238,8 @@ struct lom_map {
     bool opt_host_lm = false;       // LOM_OPT_HOST_LM / LOM_HOST_LM=1
     bool opt_debug_lm = false;      // LOM_OPT_DEBUG_LM_STAMPS / LOM_DEBUG_LM=1
     bool opt_debug_timing = false;  // LOM_OPT_DEBUG_TIMING / LOM_DEBUG_TIMING=1
+    bool opt_count = false;         // LOM_OPT_COUNT_CANDIDATES / LOM_COUNT_CANDIDATES=1: the searches also produce the reference-
+                                    // algorithm counts (occupied voxels, stored points of all 27 neighbours): 27 slot loads per query
     bool opt_no_temporal = false;   // LOM_OPT_NO_TEMPORAL_BOUND / LOM_NO_TEMPORAL=1: every search at the plain max_dist bound
     unsigned long long patience_ticks = 5000000ull;  // bounded in-kernel waits: 50 ms of s_memrealtime (100 MHz)
     int test_grid_give_up = -1;     // LOM_OPT_TEST_GRID_GIVE_UP: first workgroup that gives up in the next in-kernel scan

@@ -84,13 +84,16 @@ struct __attribute__((aligned(8))) QStat {
 // coordinates x of the neighbour voxels i-1 (gm2) and i+1 (gp2).  Coordinates with
 // (int)(x / vs) == j lie in [lo_j, hi_j] (truncation: index 0 is double width), so voxel
 // i+1 starts at (i >= 0 ? i+1 : i) * vs and voxel i-1 ends at (i <= 0 ? i-1 : i) * vs.
-__device__ __forceinline__ void axis_gaps(float q, int i, float vs, float &gm2, float &gp2)
+// (slack_vs = 1e-4 * vs comes from the caller as a wave-uniform value in a scalar register: left to the compiler it was
+// hoisted into a vector register and, under the register budget, spilled -- and the reload's s_waitcnt vmcnt(0) then
+// waited for every global load in flight, the next query's prefetch included)
+__device__ __forceinline__ void axis_gaps(float q, int i, float vs, float slack_vs, float &gm2, float &gp2)
 {
     const float fi = (float)i;
     const float face_p = ((i >= 0) ? fi + 1.f : fi) * vs;
     const float face_m = ((i <= 0) ? fi - 1.f : fi) * vs;
     // slack for the f32 rounding of x / vs at the voxel faces and of the distance itself
-    const float slack = 1e-4f * vs + 1e-6f * fabsf(q);
+    const float slack = slack_vs + 1e-6f * fabsf(q);
     const float gp = fmaxf((face_p - q) - slack, 0.f);
     const float gm = fmaxf((q - face_m) - slack, 0.f);
     gm2 = gm * gm;
@@ -228,11 +231,14 @@ struct Stamper<true> {
 // constant address space: scalar loads, like kernel arguments), and the launch does nothing once
 // the outer loop has finished -- the host enqueues several outer iterations ahead.
 // kPrev: the records of the PREVIOUS search of the same scan against the same map are still at out_rec (outer
-// iterations >= 2 of an align): the old winner's f32 distance at the new pose bounds this search's minimum from above,
-// and a neighbour voxel whose nearest face is provably farther than that cannot hold the winner -- see "temporal
-// bound" in the loop.  Exact; verified per query, with a second pass at the plain bound where the old winner has left
-// the neighbourhood.
-template <int G, int kU, int kMinWaves, bool kStamp = false, bool kChained = false, bool kPrev = kChained>
+// iterations >= 2 of an align): where the old winner still lies in the query's 27 voxels, its f32 distance at the new
+// pose bounds this search's minimum from above, and a neighbour voxel whose nearest face is provably farther than that
+// cannot hold the winner -- see "temporal bound" in the loop.  Exact.
+// kCount: the reference-algorithm counts per query (occupied voxels among the 27, their stored points: SURVEY.md 8d's
+// cand(q), the tests' n_cand / n_occ) need every one of the 27 slots.  Without them (the product's align, unless
+// LOM_OPT_COUNT_CANDIDATES asks) a neighbour voxel that the bound prunes is not even looked up: its slot is neither
+// hashed nor loaded -- the result cannot depend on whether a voxel exists whose points could not win.
+template <int G, int kU, int kMinWaves, bool kStamp = false, bool kChained = false, bool kPrev = kChained, bool kCount = true>
 __global__ __launch_bounds__(kMatchThreads, kMinWaves) void k_match(MapView map, const char *__restrict__ src, size_t stride,
                                                          uint32_t n, PoseArgs Parg, int32_t *__restrict__ out_idx,
                                                          MatchRec *__restrict__ out_rec,
@@ -249,7 +255,14 @@ __global__ __launch_bounds__(kMatchThreads, kMinWaves) void k_match(MapView map,
     constexpr int kGroups0 = kMatchThreads / G;
     const uint32_t q_first = blockIdx.x * kGroups0 + threadIdx.x / G;
     f32x3 sp_next = {0.f, 0.f, 0.f};
-    if (q_first < n) sp_next = *reinterpret_cast<const f32x3 *>(src + (size_t)q_first * stride);
+    // (without the counts the temporal bound decides which slots are loaded at all: the previous record travels with the
+    // source point, one query ahead; with them it is only needed once the slots are back)
+    constexpr bool kPrevEarly = kPrev && !kCount;
+    float4 pv_next = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q_first < n) {
+        sp_next = *reinterpret_cast<const f32x3 *>(src + (size_t)q_first * stride);
+        if constexpr (kPrevEarly) pv_next = reinterpret_cast<const float4 *>(out_rec + q_first)[1];
+    }
     struct {
         double R[9], t[3];
         float max_sq;
@@ -331,33 +344,38 @@ __global__ __launch_bounds__(kMatchThreads, kMinWaves) void k_match(MapView map,
     const char *gap_base = reinterpret_cast<const char *>(&s_gap[grp][0]);
     if (gl < 3) s_gap[grp][gl * 3 + 1] = 0.f;  // the centre column of the gap table never changes (own group, own wave)
 
+    const float slack_vs = map.prune_slack;  // 1e-4f * voxel_size
     for (uint32_t q = blockIdx.x * kGroups + grp; q < n; q += groups_total) {
         f32x3 sp = sp_next;
         // the previous search's {winner point, valid} of this query: not needed before the slots are back, so it is
         // asked for here (one round trip beside theirs) rather than a query ahead (four more live registers)
-        float4 pv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if constexpr (kPrev) pv = reinterpret_cast<const float4 *>(out_rec + q)[1];
-        if (q + groups_total < n) sp_next = *reinterpret_cast<const f32x3 *>(src + (size_t)(q + groups_total) * stride);
-        uint32_t w_d, w_c, best_pi0, best_c, n_cand, n_occ, T = 0;  // T: points actually read
-        float best;
-        // one pass; where the temporal bound (below) could not be verified, the query is done over from its source point
-        // at the plain bound -- rare, and cheaper in registers than keeping the probe's results across the scan
-        for (bool use_prev = kPrev;; use_prev = false) {
-        // (with records of a previous search the source point is not carried through the query: it is in the record
-        // already, and the rare second pass fetches it again)
-        if (kPrev && !use_prev) sp = *reinterpret_cast<const f32x3 *>(src + (size_t)q * stride);
+        float4 pv = pv_next;
+        if constexpr (kPrev && !kPrevEarly) pv = reinterpret_cast<const float4 *>(out_rec + q)[1];
+        if (q + groups_total < n) {
+            sp_next = *reinterpret_cast<const f32x3 *>(src + (size_t)(q + groups_total) * stride);
+            if constexpr (kPrevEarly) pv_next = reinterpret_cast<const float4 *>(out_rec + (q + groups_total))[1];
+        }
         const double p0 = (double)sp.x, p1 = (double)sp.y, p2 = (double)sp.z;
         // voxel_grid.h:220-223: R*p + t in f64 (Eigen order a0 + (a1 + a2)), cast to f32 -- this lane's component
         const float qc = (float)((my_pose[0] * p0 + (my_pose[1] * p1 + my_pose[2] * p2)) + my_pose[3]);
         int ic = 0;
         const bool okc = voxel_index_fast(qc, map.voxel_size, map.inv_voxel_size, ic);
         float gm2, gp2;
-        axis_gaps(qc, ic, map.voxel_size, gm2, gp2);
+        axis_gaps(qc, ic, map.voxel_size, slack_vs, gm2, gp2);
         if (gl < 3) {
             s_gap[grp][gl * 3 + 0] = gm2;
             s_gap[grp][gl * 3 + 2] = gp2;
         }
         const int icc = okc ? ic : (int)0x80000000;  // out of range / not finite
+        // temporal bound, part 1 (this lane's axis): does the old winner's own voxel index -- the expression the insert
+        // stored it under -- lie within one of the new centre's?  (lanes 3..15 repeat axis z, as above)
+        uint32_t near_c = 0u;
+        if constexpr (kPrev) {
+            const float oc = gl == 0 ? pv.x : (gl == 1 ? pv.y : pv.z);
+            int io = 0;
+            const bool oko = voxel_index_fast(oc, map.voxel_size, map.inv_voxel_size, io);
+            near_c = (okc && oko && (uint32_t)(io - ic + 1) <= 2u) ? 1u : 0u;
+        }
         const float qx = __uint_as_float(row_lane<0>(__float_as_uint(qc)));
         const float qy = __uint_as_float(row_lane<1>(__float_as_uint(qc)));
         const float qz = __uint_as_float(row_lane<2>(__float_as_uint(qc)));
@@ -368,6 +386,28 @@ __global__ __launch_bounds__(kMatchThreads, kMinWaves) void k_match(MapView map,
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         LOM_STAMP(1);  // source point loaded and transformed
+        // ---- temporal bound, part 2 ----
+        // The winner of the previous search (same scan, same map, the pose one solve earlier) is a stored point.  If its
+        // voxel index lies within one of this query's centre index on every axis it is one of this query's candidates in
+        // the reference (voxel_grid.h:175-183), so its distance d_prev2 -- the very f32 expression of the candidate loop
+        // -- is an upper bound of this search's minimum B.  A voxel whose nearest face is provably farther than B holds
+        // only points with d2 > B (the argument of the plain bound with B in place of max_sq, same slack): they can
+        // neither win nor tie, so every candidate with d2 <= B -- the old winner among them -- is scanned in the
+        // reference's order and the first strict minimum is the reference's (:183-191).  An old winner outside the 27
+        // voxels, or beyond max_dist, or none: the plain bound.  With kCount the counts (n_cand, n_occ) stay the slot
+        // counts of all 27 voxels.
+        auto temporal_bound = [&]() -> float {
+            float Bv = P.max_sq;
+            if constexpr (kPrev) {
+                const float ex = qx - pv.x, ey = qy - pv.y, ez = qz - pv.z;
+                const float d_prev2 = ex * ex + (ey * ey + ez * ez);
+                const bool near = row_min32(near_c) != 0u;  // all three axes (lanes 2..15 hold axis z)
+                if (near && pv.w != 0.f && d_prev2 < P.max_sq) Bv = d_prev2;  // (NaN: no bound)
+            }
+            return Bv;
+        };
+        float B = P.max_sq;
+        if constexpr (!kCount) B = temporal_bound();
         // ---- probe ----
         // stored indices lie in (-2^20, 2^20): a centre at least two voxels inside has all 27 neighbours in range
         const uint32_t kInner = (uint32_t)(2 * kIdxBias - 3);
@@ -394,6 +434,13 @@ __global__ __launch_bounds__(kMatchThreads, kMinWaves) void k_match(MapView map,
             lower[s] = *reinterpret_cast<const float *>(gap_base + (gap_off[s] & 0xFFu)) +
                        (*reinterpret_cast<const float *>(gap_base + ((gap_off[s] >> 8) & 0xFFu)) +
                         *reinterpret_cast<const float *>(gap_base + (gap_off[s] >> 16)));
+            if constexpr (!kCount) {  // a pruned neighbour is not looked up
+                if (lower[s] > B * 1.0001f) {
+                    act[s] = false;
+                    key[s] = 0ull;
+                    h[s] = 0u;
+                }
+            }
         }
         // both sets' first slots in flight together
         u32x4 raw[kSets];
@@ -418,31 +465,23 @@ __global__ __launch_bounds__(kMatchThreads, kMinWaves) void k_match(MapView map,
                 }
             }
         }
-        LOM_STAMP(2);  // 27 slots probed
-        // ---- temporal bound ----
-        // The winner of the previous search (same scan, same map, the pose one solve earlier) is a stored point: if it
-        // still lies in this query's 27 voxels it is a candidate now, its distance d_prev2 -- the very f32 expression of
-        // the candidate loop -- is an upper bound of this search's minimum, and a voxel whose nearest face is provably
-        // farther than d_prev2 can hold neither the winner nor a tie with it.  Whether it still lies there is not
-        // computed but VERIFIED: with B = d_prev2 the pruned voxels' points all have d2 > B (the argument of the plain
-        // bound, B in place of max_sq, same slack), so a scan that ends with a minimum <= B has seen every candidate
-        // with d2 <= B in the reference's order and its first strict minimum is the reference's (voxel_grid.h:183-191);
-        // a scan that ends above B (the old winner left the neighbourhood, or was none) is repeated at the plain
-        // bound.  Counts (n_cand, n_occ) stay the slot counts of all 27 voxels.
-        float B = P.max_sq;
-        if constexpr (kPrev) {
-            const float ex = qx - pv.x, ey = qy - pv.y, ez = qz - pv.z;
-            const float d_prev2 = ex * ex + (ey * ey + ez * ez);
-            if (use_prev && pv.w != 0.f && d_prev2 < P.max_sq) B = d_prev2;  // (NaN: no bound)
-        }
-        // the reference's counts: occupied voxels (<= 27) above bit 26, stored points (<= 27 K, K < 2^16) below: one row
-        // sum for both sets
-        uint32_t mine = 0;
+        LOM_STAMP(2);  // slots probed
+        uint32_t probed = 0;  // (lom_profile_match's tally launch: the slots this query asked for)
+        if constexpr (!kCount && !kChained)
+            if (out_stat) probed = row_sum((act[0] ? 1u : 0u) + (act[1] ? 1u : 0u));
+        if constexpr (kCount) B = temporal_bound();
+        uint32_t w_d, w_c, best_pi0, best_c, n_cand = 0, n_occ = 0, T = 0;  // T: points actually read
+        float best;
+        if constexpr (kCount) {
+            // the reference's counts: occupied voxels (<= 27) above bit 26, stored points (<= 27 K, K < 2^16) below: one
+            // row sum for both sets
+            uint32_t mine = 0;
 #pragma unroll
-        for (int s = 0; s < kSets; s++) mine += cnt[s] | ((cnt[s] ? 1u : 0u) << 26);
-        const uint32_t tot = row_sum(mine);
-        n_cand = tot & ((1u << 26) - 1u);
-        n_occ = tot >> 26;
+            for (int s = 0; s < kSets; s++) mine += cnt[s] | ((cnt[s] ? 1u : 0u) << 26);
+            const uint32_t tot = row_sum(mine);
+            n_cand = tot & ((1u << 26) - 1u);
+            n_occ = tot >> 26;
+        }
         const float bound = B * 1.0001f;
 #pragma unroll
         for (int s = 0; s < kSets; s++) {
@@ -536,13 +575,6 @@ __global__ __launch_bounds__(kMatchThreads, kMinWaves) void k_match(MapView map,
         // half the instructions of four 64-bit compare-and-select steps)
         w_d = row_min32(__float_as_uint(best));
         w_c = row_min32(__float_as_uint(best) == w_d ? best_c : 0xFFFFFFFFu);
-        if constexpr (!kPrev) break;
-        if (!(B < P.max_sq) || w_d <= __float_as_uint(B)) break;  // plain bound, or the temporal bound verified
-        // the old winner is not among this query's candidates any more
-        // (the tables of this row are rewritten: its reads above are complete for this wave)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        }
         const bool valid = w_c != 0xFFFFFFFFu;
         LOM_STAMP(5);  // group minimum known
         // the lane that scanned the winner reads its point again together with the normal (two loads, one round
@@ -555,7 +587,7 @@ __global__ __launch_bounds__(kMatchThreads, kMinWaves) void k_match(MapView map,
                 idx = (int32_t)pi;
                 load_points2(map.pts + pi * 3, map.nrm + pi * 3, wp, wn);  // voxel_grid.h:197-198
             }
-            out_idx[q] = idx;
+            if constexpr (!kChained) out_idx[q] = idx;  // (only lom_match_find_pairs reads it)
             float4 *rec = reinterpret_cast<float4 *>(out_rec + q);
             if constexpr (kPrev)
                 reinterpret_cast<float *>(rec)[3] = wn.x;  // the source point is there since the first search of this scan
@@ -563,17 +595,21 @@ __global__ __launch_bounds__(kMatchThreads, kMinWaves) void k_match(MapView map,
                 rec[0] = make_float4(sp.x, sp.y, sp.z, wn.x);
             rec[1] = make_float4(wp.x, wp.y, wp.z, valid ? 1.f : 0.f);
             rec[2] = make_float4(wn.y, wn.z, 0.f, 0.f);
-            if (out_stat) {
+            if (!kChained && out_stat) {
                 QStat st;
                 st.sq_dist = valid ? best : 0.f;
-                st.n_cand = n_cand;
-                st.n_occ = n_occ;
+                // with the counts: the reference algorithm's; without: what this launch itself read (rows) and looked up
+                // (slots) for the query -- lom_profile_match's "requested bytes"; lom_match_find_pairs reports zeros then
+                st.n_cand = kCount ? n_cand : T;
+                st.n_occ = kCount ? n_occ : probed;
                 st.pad = 0;
                 out_stat[q] = st;
             }
             atomicAdd(&s_cnt[grp][0], valid ? 1u : 0u);
-            atomicAdd(&s_cnt[grp][1], n_cand);
-            atomicAdd(&s_cnt[grp][2], n_occ);
+            if constexpr (kCount) {
+                atomicAdd(&s_cnt[grp][1], n_cand);
+                atomicAdd(&s_cnt[grp][2], n_occ);
+            }
             if constexpr (!kChained) atomicAdd(&s_cnt[grp][3], T);  // candidates actually read (after the exact pruning)
         }
         LOM_STAMP(6);  // winner's normal loaded, record stored
@@ -1582,6 +1618,7 @@ struct ScanCtx {
     // the records of a previous search of THIS scan against this map are at scan_on (outer iterations >= 2 of an align):
     // the next search may take its temporal pruning bound from them (k_match<..., kPrev>)
     bool have_prev = false;
+    bool counted = false;  // the last launch produced the reference-algorithm counts
     int prof_used = 0;
     double launch_s = 0.0, wait_s = 0.0;  // host time inside launch calls / polling for results
 };
@@ -1611,8 +1648,9 @@ static double *d_sums(lom_map *m) { return (double *)m->results.p; }
 static void server_stop(lom_map *m);
 
 // chained: the pose comes from the AlignState in HBM (t, q unused)
+// count_mode: -1 = as the handle says (LOM_OPT_COUNT_CANDIDATES), 0 / 1 = without / with the reference-algorithm counts
 static int launch_match(ScanCtx &c, const float t[3], const float q[4], float max_sq, bool stats,
-                        bool chained = false)
+                        bool chained = false, int count_mode = -1)
 {
     lom_map *m = c.m;
     PoseArgs P;
@@ -1653,15 +1691,24 @@ static int launch_match(ScanCtx &c, const float t[3], const float q[4], float ma
                                (unsigned long long *)nullptr, as);
         };
         QStat *st = (stats && !chained) ? (QStat *)m->scan_stats.p : (QStat *)nullptr;
-        if (chained && m->opt_no_temporal)
-            launch(k_match<kMatchG, kMatchRows, kMatchMinWaves, false, true, false>, st, (const AlignState *)m->align_state.p);
-        else if (chained)  // (always behind a search of the same scan: launch_pair's first pair is not chained)
-            launch(k_match<kMatchG, kMatchRows, kMatchMinWaves, false, true>, st, (const AlignState *)m->align_state.p);
-        else if (c.have_prev && !m->opt_no_temporal)
-            launch(k_match<kMatchG, kMatchRows, kMatchMinWaves, false, false, true>, st, (const AlignState *)nullptr);
-        else
-            launch(k_match<kMatchG, kMatchRows, kMatchMinWaves>, st, (const AlignState *)nullptr);
+        // (a chained launch always follows a search of the same scan: launch_pair's first pair is not chained)
+        const bool prev = (chained || c.have_prev) && !m->opt_no_temporal;
+        const bool count = count_mode < 0 ? m->opt_count : count_mode != 0;
+        const AlignState *as = chained ? (const AlignState *)m->align_state.p : (const AlignState *)nullptr;
+        constexpr int W = kMatchMinWaves;
+        if (chained) {
+            if (prev && count) launch(k_match<kMatchG, kMatchRows, W, false, true, true, true>, st, as);
+            else if (prev) launch(k_match<kMatchG, kMatchRows, W, false, true, true, false>, st, as);
+            else if (count) launch(k_match<kMatchG, kMatchRows, W, false, true, false, true>, st, as);
+            else launch(k_match<kMatchG, kMatchRows, W, false, true, false, false>, st, as);
+        } else {
+            if (prev && count) launch(k_match<kMatchG, kMatchRows, W, false, false, true, true>, st, as);
+            else if (prev) launch(k_match<kMatchG, kMatchRows, W, false, false, true, false>, st, as);
+            else if (count) launch(k_match<kMatchG, kMatchRows, W, false, false, false, true>, st, as);
+            else launch(k_match<kMatchG, kMatchRows, W, false, false, false, false>, st, as);
+        }
         LOM_HIP(m, hipGetLastError());
+        c.counted = count;
         c.have_prev = true;
         if (m->profiling) LOM_HIP(m, hipEventRecord(e1, m->stream));
     }
@@ -2050,8 +2097,8 @@ static int align_chained(lom_map *m, const char *d_src, size_t n, size_t stride,
     st.cand_total = (int64_t)rp->cand_total;
     st.occ_total = (int64_t)rp->occ_total;
     st.queries = (int64_t)rp->queries_total;
-    // B(q) = 12 + 27*16 + 12*cand(q) + 12*valid(q)
-    st.algorithmic_bytes = 444.0 * rp->queries_total + 12.0 * rp->cand_total + 12.0 * rp->valid_total;
+    // B(q) = 12 + 27*16 + 12*cand(q) + 12*valid(q) -- known only when the searches produced the counts
+    st.algorithmic_bytes = c.counted ? 444.0 * rp->queries_total + 12.0 * rp->cand_total + 12.0 * rp->valid_total : 0.0;
     st.final_cost = rp->final_cost;
     st.last_step_norm = rp->last_step_norm;
     float pq[4] = {rp->pose_q[0], rp->pose_q[1], rp->pose_q[2], rp->pose_q[3]};
@@ -2162,6 +2209,7 @@ static int align_device(lom_map *m, const char *d_src, size_t n, size_t stride, 
     lom_align_stats st;
     rc = lom_align_with_hooks(&hooks, guess_t, guess_q, out_t, out_q, &st);
     server_stop(m);
+    if (!c.counted) st.algorithmic_bytes = 0.0;  // (SURVEY.md 8d's bytes need the counts: LOM_OPT_COUNT_CANDIDATES)
     if (rc != LOM_OK) {
         if (m->last_error.empty()) set_error(m, rc, "align failed");
         // ranks of one node: a rank that leaves the loop tells its peers (they would wait for its sums otherwise)
@@ -2234,8 +2282,8 @@ static int64_t find_pairs_core(lom_map *m, const float *src, size_t n, size_t st
         o.normal[1] = on[i].ny;
         o.normal[2] = on[i].nz;
         o.sq_dist = st[i].sq_dist;
-        o.n_cand = st[i].n_cand;
-        o.n_occ = st[i].n_occ;
+        o.n_cand = c.counted ? st[i].n_cand : 0u;  // the reference-algorithm counts, or nothing (LOM_OPT_COUNT_CANDIDATES)
+        o.n_occ = c.counted ? st[i].n_occ : 0u;
         valid += idx[i] >= 0;
     }
     return valid;
@@ -2391,9 +2439,35 @@ int lom_profile_match(lom_map *m, const float *d_src, size_t n, size_t stride, c
         *pair_avg_us_out = c.prof_used ? pair_ms * 1e3 / c.prof_used : 0.0;
         c.prof_used = 0;
     }
+    // what the timed launches asked the memory system for: one more launch of the same form that tallies, per query, the
+    // rows it read and the slots it looked up (with the counts every query looks up 27 and the rows are the per-workgroup
+    // tally of the launch)
+    double scanned = 0.0, probed = 0.0;
+    const bool train_counted = c.counted;
+    if (rc == LOM_OK && requested_bytes_out) {
+        if (train_counted) {
+            std::vector<uint32_t> bc((size_t)c.match_blocks * 4);
+            if (hipMemcpyAsync(bc.data(), d_block_counters(m), bc.size() * 4, hipMemcpyDeviceToHost, m->stream) != hipSuccess ||
+                hipStreamSynchronize(m->stream) != hipSuccess)
+                rc = LOM_ERR_HIP;
+            for (uint32_t b = 0; rc == LOM_OK && b < c.match_blocks; b++) scanned += bc[(size_t)b * 4 + 3];
+        } else {
+            std::vector<QStat> qs(n);
+            if ((rc = scan_buffers(m, (uint32_t)n, true)) == LOM_OK) rc = launch_match(c, t, q, sq_f32(max_dist), true);
+            if (rc == LOM_OK && (hipMemcpyAsync(qs.data(), m->scan_stats.p, n * sizeof(QStat), hipMemcpyDeviceToHost, m->stream) != hipSuccess ||
+                                 hipStreamSynchronize(m->stream) != hipSuccess))
+                rc = LOM_ERR_HIP;
+            for (size_t i = 0; rc == LOM_OK && i < n; i++) {
+                scanned += qs[i].n_cand;
+                probed += qs[i].n_occ;
+            }
+        }
+    }
+    // the algorithmic bytes need the reference-algorithm counts: one more launch that produces them
     double sums[LOM_NSUMS];
     const double qd[4] = {q[0], q[1], q[2], q[3]}, td[3] = {t[0], t[1], t[2]};
-    if (rc == LOM_OK) rc = launch_eval(c, qd, td, true, sums);  // folds the counters of the last launch
+    if (rc == LOM_OK) rc = launch_match(c, t, q, sq_f32(max_dist), false, false, 1);
+    if (rc == LOM_OK) rc = launch_eval(c, qd, td, true, sums);  // folds the counters of that launch
     server_stop(m);
     if (rc == LOM_OK && hipStreamSynchronize(m->stream) != hipSuccess) rc = LOM_ERR_HIP;
     float ms = 0.f;
@@ -2405,13 +2479,12 @@ int lom_profile_match(lom_map *m, const float *d_src, size_t n, size_t stride, c
     *avg_us_out = (double)ms * 1e3 / reps;
     if (bytes_out) *bytes_out = 444.0 * sums[31] + 12.0 * sums[29] + 12.0 * sums[28];
     if (requested_bytes_out) {
-        // what the kernel itself asked the memory system for: pruned neighbour voxels are not scanned
-        std::vector<uint32_t> bc((size_t)c.match_blocks * 4);
-        if (hipMemcpy(bc.data(), d_block_counters(m), bc.size() * 4, hipMemcpyDeviceToHost) != hipSuccess)
-            return set_error(m, LOM_ERR_HIP, "counter readback");
-        double scanned = 0.0;
-        for (uint32_t b = 0; b < c.match_blocks; b++) scanned += bc[(size_t)b * 4 + 3];
-        *requested_bytes_out = 444.0 * sums[31] + 12.0 * scanned + 12.0 * sums[28] + 52.0 * sums[31];
+        // source point + slots looked up + rows of the scanned voxels + winner's normal + 52 B of output per query (+ 16 B
+        // of the previous record where the temporal bound is in use)
+        const double nq = sums[31];
+        const double slots = train_counted ? 27.0 * nq : probed;
+        const double prev_b = (c.have_prev && !m->opt_no_temporal) ? 16.0 * nq : 0.0;
+        *requested_bytes_out = 12.0 * nq + 16.0 * slots + 12.0 * scanned + 12.0 * sums[28] + 52.0 * nq + prev_b;
     }
     return LOM_OK;
 }

@@ -88,6 +88,7 @@ MapView view_of(const lom_map *self)
     const float inv = 1.0f / m->voxel_size;
     // power of two with a normal reciprocal: scaling by inv is exact
     v.inv_voxel_size = (std::frexp(m->voxel_size, &e) == 0.5f && std::isnormal(inv)) ? inv : 0.f;
+    v.prune_slack = 1e-4f * m->voxel_size;
     return v;
 }
 
@@ -1276,6 +1277,7 @@ int lom_scan_create(lom_map *map, lom_scan **out)
     c->opt_debug_lm = map->opt_debug_lm;
     c->opt_debug_timing = map->opt_debug_timing;
     c->opt_no_temporal = map->opt_no_temporal;
+    c->opt_count = map->opt_count;
     c->patience_ticks = map->patience_ticks;
     if (handle_setup(c) != LOM_OK) {
         map->last_error = g_create_error;
@@ -1348,6 +1350,7 @@ int lom_map_create(float voxel_size, size_t max_points, size_t capacity_hint, in
     m->opt_debug_lm = getenv("LOM_DEBUG_LM") != nullptr;
     m->opt_debug_timing = getenv("LOM_DEBUG_TIMING") != nullptr;
     m->opt_no_temporal = getenv("LOM_NO_TEMPORAL") != nullptr;
+    if (const char *e = getenv("LOM_COUNT_CANDIDATES")) m->opt_count = atoi(e) != 0;
     if (handle_setup(m) != LOM_OK) {
         lom_map_destroy(m);
         return LOM_ERR_HIP;
@@ -1436,6 +1439,7 @@ int lom_map_set_option(lom_map *m, int option, int64_t value)
     case LOM_OPT_DEBUG_LM_STAMPS: m->opt_debug_lm = value != 0; return LOM_OK;
     case LOM_OPT_DEBUG_TIMING: m->opt_debug_timing = value != 0; return LOM_OK;
     case LOM_OPT_NO_TEMPORAL_BOUND: m->opt_no_temporal = value != 0; return LOM_OK;
+    case LOM_OPT_COUNT_CANDIDATES: m->opt_count = value != 0; return LOM_OK;
     case LOM_OPT_TEST_GIVE_UP_AT_OUTER:
         if (value < -1 || value >= 35) return LOM_ERR_ARG;
         m->test_give_up_outer = (int)value;

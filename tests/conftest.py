@@ -39,3 +39,12 @@ def lom():
 
     pkg.capi.lib()
     return pkg
+
+
+@pytest.fixture
+def counted_search(monkeypatch):
+    """Handles created inside the test produce the reference-ALGORITHM counts (LOM_COUNT_CANDIDATES=1 at create =
+    LOM_OPT_COUNT_CANDIDATES: all 27 slots per query) -- for the tests that compare counters [28..30] of the reduced sums
+    or cand_total / occ_total with the oracle's.  tests/test_gpu_parity.py runs every test both ways; rank processes
+    spawned by a test inherit the variable."""
+    monkeypatch.setenv("LOM_COUNT_CANDIDATES", "1")

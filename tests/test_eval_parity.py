@@ -20,7 +20,7 @@ import pytest
 
 from tests import scenes
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("counted_search")]
 
 REL = 1e-12
 

@@ -21,6 +21,26 @@ POSE_TOL_M = 1e-4
 POSE_TOL_RAD = 1e-4
 
 
+@pytest.fixture(autouse=True, params=["product", "counted"])
+def search_mode(request, monkeypatch):
+    """Every test of this module runs twice.  "product": the handles as a caller gets them -- a neighbour voxel that the
+    distance bound prunes is not even looked up, and the reference-ALGORITHM counts (n_cand / n_occ, cand_total /
+    occ_total: SURVEY.md 8d's cand(q), measurement only -- the reference returns no such thing) read 0.  "counted":
+    LOM_COUNT_CANDIDATES=1 at create (= LOM_OPT_COUNT_CANDIDATES): all 27 slots per query, counts equal to the oracle's.
+    Winners, distances, poses and iteration counts must equal the oracle's either way."""
+    monkeypatch.setenv("LOM_COUNT_CANDIDATES", "1" if request.param == "counted" else "0")
+    return request.param
+
+
+def _counted():
+    return os.environ.get("LOM_COUNT_CANDIDATES") == "1"
+
+
+def _keys(*keys):
+    """stats keys to compare with the oracle: the reference-algorithm counts only where the product produced them"""
+    return tuple(k for k in keys if _counted() or k not in ("cand_total", "occ_total"))
+
+
 def _both(lom, oracle, voxel, K):
     return lom.VoxelGrid(voxel, K), oracle.VoxelGrid(voxel, K)
 
@@ -41,8 +61,11 @@ def _assert_same_pairs(c, oc):
     assert c["origin"].tobytes() == oc["origin"].tobytes()
     assert c["normal"].tobytes() == oc["normal"].tobytes()
     assert c["sq_dist"].tobytes() == oc["sq_dist"].tobytes()
-    assert np.array_equal(c["n_cand"], oc["n_cand"])
-    assert np.array_equal(c["n_occ"], oc["n_occ"])
+    if _counted():
+        assert np.array_equal(c["n_cand"], oc["n_cand"])
+        assert np.array_equal(c["n_occ"], oc["n_occ"])
+    else:
+        assert not c["n_cand"].any() and not c["n_occ"].any()
 
 
 # ---- reference unit tests through the product (test.cpp:26-75) -------------
@@ -206,7 +229,7 @@ def test_large_cap_voxels(lom, oracle):
         r = om.align(og, q, oracle.Pose3D(*pose))
         dt, dr = scenes.pose_delta(p.translation, p.rotation, r.translation, r.rotation)
         assert dt < 1e-4 and dr < 1e-4 and m.stats["outer_iterations"] == om.stats["outer_iterations"]
-        assert m.stats["cand_total"] == om.stats["cand_total"]
+        assert m.stats["cand_total"] == (om.stats["cand_total"] if _counted() else 0)
 
 
 def test_lattice_of_equal_parities(lom, oracle):
@@ -411,7 +434,8 @@ def test_find_pairs_parity_synth_and_golden(lom, oracle):
     _assert_same_pairs(c, og.findMatchingPairs(sm["scan"], oracle.Pose3D(), 0.3))
     idx = c["index"].astype("<i8")
     assert hashlib.sha256(idx.tobytes()).hexdigest() == gold["winner_sha256"]
-    assert int(c["n_cand"].sum()) == gold["cand_total"] and int(c["n_occ"].sum()) == gold["occ_total"]
+    if _counted():
+        assert int(c["n_cand"].sum()) == gold["cand_total"] and int(c["n_occ"].sum()) == gold["occ_total"]
     # a rotated / translated pose exercises the f64 transform + f32 cast path
     pose = (0.31, -0.2, 0.05), scenes.angle_axis_q(0.03, scenes._unit((0.1, 0.2, 1.0)))
     _assert_same_pairs(g.findMatchingPairs(sm["scan"], lom.Pose3D(*pose), 0.3),
@@ -463,7 +487,7 @@ def test_matching_test_protocol_and_golden(lom, oracle, fixture_cloud):
         dt, dr = scenes.pose_delta(c["final_t"], c["final_q_wxyz"], gcase["final_t"], gcase["final_q_wxyz"])
         assert dt < POSE_TOL_M and dr < POSE_TOL_RAD, (dt, dr)
         assert c["stats"]["outer_iterations"] == gcase["stats"]["outer_iterations"]
-        assert c["stats"]["cand_total"] == gcase["stats"]["cand_total"]
+        assert c["stats"]["cand_total"] == (gcase["stats"]["cand_total"] if _counted() else 0)
         assert c["stats"]["valid_last"] == gcase["stats"]["valid_last"]
 
 
@@ -482,7 +506,7 @@ def test_align_parity_synth(lom, oracle):
         assert dt < POSE_TOL_M and dr < POSE_TOL_RAD, (dt, dr)
         assert m.stats["outer_iterations"] == om.stats["outer_iterations"]
         assert m.stats["queries"] == om.stats["queries"]
-        assert m.stats["cand_total"] == om.stats["cand_total"]
+        assert m.stats["cand_total"] == (om.stats["cand_total"] if _counted() else 0)
     p = m.align(g, sm["scan"], lom.Pose3D())
     dt, dr = scenes.pose_delta(p.translation, p.rotation, gold["final_t"], gold["final_q_wxyz"])
     assert dt < POSE_TOL_M and dr < POSE_TOL_RAD
@@ -513,7 +537,7 @@ def test_align_parity_randomized(lom, oracle, seed):
         ref = om.align(og, scan, oracle.Pose3D(t, q))
         dt, dr = scenes.pose_delta(got.translation, got.rotation, ref.translation, ref.rotation)
         assert dt < POSE_TOL_M and dr < POSE_TOL_RAD, (seed, trial, n, voxel, dt, dr)
-        for k in ("outer_iterations", "queries", "cand_total", "occ_total", "valid_last"):
+        for k in _keys("outer_iterations", "queries", "cand_total", "occ_total", "valid_last"):
             assert m.stats[k] == om.stats[k], (seed, trial, k)
         outers.append(m.stats["outer_iterations"])
     assert min(outers) >= 5
@@ -550,7 +574,7 @@ def test_host_driven_path_matches_device_loop(lom, monkeypatch):
     host = m.align(g, sm["scan"], lom.Pose3D())
     dt, dr = scenes.pose_delta(dev.translation, dev.rotation, host.translation, host.rotation)
     assert dt < 1e-6 and dr < 1e-6, (dt, dr)
-    for k in ("outer_iterations", "lm_iterations", "evaluations", "queries", "cand_total", "occ_total", "valid_last"):
+    for k in _keys("outer_iterations", "lm_iterations", "evaluations", "queries", "cand_total", "occ_total", "valid_last"):
         assert m.stats[k] == dev_stats[k], k
 
 
@@ -569,7 +593,7 @@ def test_evaluation_server_timeout_recovery(lom, monkeypatch):
     got = m.align(g, sm["scan"], lom.Pose3D())
     assert got.translation.tobytes() == ref.translation.tobytes()
     assert got.rotation.tobytes() == ref.rotation.tobytes()
-    for k in ("outer_iterations", "evaluations", "queries", "cand_total", "valid_last"):
+    for k in _keys("outer_iterations", "evaluations", "queries", "cand_total", "valid_last"):
         assert m.stats[k] == ref_stats[k]
     g.setOption(lom.capi.OPT_DEVICE_PATIENCE_TICKS, 5_000_000)
     again = m.align(g, sm["scan"], lom.Pose3D())
@@ -597,7 +621,7 @@ def test_device_loop_gives_up_cleanly_and_falls_back(lom, monkeypatch):
     assert m.stats["host_fallback"] == 1
     assert got.translation.tobytes() == host.translation.tobytes()
     assert got.rotation.tobytes() == host.rotation.tobytes()
-    for k in ("outer_iterations", "lm_iterations", "evaluations", "queries", "cand_total", "valid_last"):
+    for k in _keys("outer_iterations", "lm_iterations", "evaluations", "queries", "cand_total", "valid_last"):
         assert m.stats[k] == host_stats[k], k
     g.setOption(lom.capi.OPT_DEVICE_PATIENCE_TICKS, 5_000_000)
     again = m.align(g, sm["scan"], lom.Pose3D())
@@ -635,7 +659,7 @@ def test_comm_path_single_rank(lom):
         got = m.align(g, sm["scan"], lom.Pose3D())
         assert got.translation.tobytes() == ref.translation.tobytes()
         assert got.rotation.tobytes() == ref.rotation.tobytes()
-        for k in ("outer_iterations", "evaluations", "queries", "cand_total", "valid_last"):
+        for k in _keys("outer_iterations", "evaluations", "queries", "cand_total", "valid_last"):
             assert m.stats[k] == ref_stats[k]
     finally:
         lom.capi.check(L.lom_comm_finalize(g.handle), g.handle)
@@ -794,7 +818,7 @@ def test_c3_full_size_properties(lom, oracle):
     pairs = g.findMatchingPairs(c["scan"], lom.Pose3D(), 0.3)
     opairs = og.findMatchingPairs(c["scan"], oracle.Pose3D(), 0.3, nthreads=4)
     assert np.array_equal(pairs["index"], opairs["index"])
-    assert int(pairs["n_cand"].sum()) == int(opairs["n_cand"].sum())
+    assert int(pairs["n_cand"].sum()) == (int(opairs["n_cand"].sum()) if _counted() else 0)
     m, om = lom.CloudMatcher(), oracle.CloudMatcher(nthreads=4)
     p = m.align(g, c["scan"], lom.Pose3D())
     o = om.align(og, c["scan"], oracle.Pose3D())
@@ -827,7 +851,7 @@ def test_c4_full_size_single_rank(lom, oracle, c4_case):
     o = om.align(og, c["scan"], oracle.Pose3D())
     dt, dr = scenes.pose_delta(p.translation, p.rotation, o.translation, o.rotation)
     assert dt < POSE_TOL_M and dr < POSE_TOL_RAD, (dt, dr)
-    for k in ("outer_iterations", "lm_iterations", "queries", "cand_total", "occ_total", "valid_last"):
+    for k in _keys("outer_iterations", "lm_iterations", "queries", "cand_total", "occ_total", "valid_last"):
         assert m.stats[k] == om.stats[k], k
     assert m.stats["evaluations"] == om.stats["points_evaluated"]
     assert abs(m.stats["last_step_norm"] - om.stats["last_step_norm"]) < 1e-9
@@ -978,7 +1002,7 @@ def test_scan_contexts_align_concurrently_against_one_keyframe(lom):
             fell_back += st["host_fallback"]
             if not st["host_fallback"]:                      # (a solve that found the GPU too full redoes itself on the
                 assert t_ == w[0] and q_ == w[1], i          #  host-driven path: same pose to 1e-6, other last bits)
-            for k in ("outer_iterations", "lm_iterations", "evaluations", "queries", "cand_total", "valid_last"):
+            for k in _keys("outer_iterations", "lm_iterations", "evaluations", "queries", "cand_total", "valid_last"):
                 assert st[k] == w[2][k], (i, k)
     assert fell_back <= 6, fell_back
     c = ctxs[0].handle and lom.capi.lib().lom_scan_find_pairs                     # the search entry on a context
@@ -1067,6 +1091,7 @@ def test_no_temporal_switch_gives_the_same_align(lom, oracle):
         for off in (0, 1):
             g = lom.VoxelGrid(0.5, 20)
             g.setOption(lom.capi.OPT_HOST_LM, host)
+            g.setOption(lom.capi.OPT_COUNT_CANDIDATES, 1)
             g.setOption(lom.capi.OPT_NO_TEMPORAL_BOUND, off)
             g.addCloud(sm["map_xyz"], sm["map_nrm"])
             m = lom.CloudMatcher()
@@ -1104,7 +1129,8 @@ def test_squared_threshold_is_taken_as_it_is(lom, oracle):
             got = g.getCorrespondence(q, thr)
             assert got["index"] == want["index"], (q, thr)
             assert got["sq_dist"].tobytes() == want["sq_dist"].tobytes()
-            assert got["n_cand"] == want["n_cand"] and got["n_occ"] == want["n_occ"]
+            if _counted():
+                assert got["n_cand"] == want["n_cand"] and got["n_occ"] == want["n_occ"]
             checked += 1
         assert g.getCorrespondence(q, d2)["index"] != c["index"]            # strict: the winner itself is rejected ...
         assert g.getCorrespondence(q, np.nextafter(d2, np.inf))["index"] == c["index"]   # ... and passes one ulp above

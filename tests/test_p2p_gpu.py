@@ -12,7 +12,7 @@ import pytest
 
 from tests.conftest import ROOT
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("counted_search")]
 
 
 def _rank_main(rank, world, ident, q):
