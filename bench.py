@@ -312,40 +312,47 @@ def streaming(args, lom, steps=None, warmup=None, cpu_frames=40):
     return line
 
 
-def concurrent_contexts(lom, torch, grid, d_scan, guess, steps, counts=(2, 3, 4)):
+def concurrent_contexts(lom, torch, grid, d_scan, guess, steps, counts=(2, 3, 4, 6, 8)):
     """Side figure (never `value`): `k` host threads, one scan context each (lom_scan_create), all aligning the same
     device-resident scan against the ONE keyframe at the same time -- what `const VoxelGrid&` allows the reference's
-    callers (voxel_grid.h:206, cloud_matcher.h:15).  A solve keeps ~53 of the 256 CUs busy on a VLP16-sized scan, so
-    concurrent callers are how one GPU is filled.  The C calls release the GIL."""
+    callers (voxel_grid.h:206, cloud_matcher.h:15).  A solve keeps ~53 of the 256 CUs busy on a VLP16-sized scan and every
+    launch of an align waits for the one before it, so concurrent callers are how one GPU is filled.  Two forms: contexts
+    that share the whole GPU (each search grid fills every SIMD, so the callers' kernels queue behind each other), and
+    contexts on k disjoint slices of the compute units (lom_scan_create_on_partition: a CU mask per stream), where the
+    callers' chains run side by side.  The C calls release the GIL."""
     import threading
 
     out = {}
     for k in counts:
-        ctxs = [lom.ScanContext(grid) for _ in range(k)]
-        for c in ctxs:
-            lom.align_repeat(c, d_scan.data_ptr(), d_scan.shape[0], guess, 20)
-        torch.cuda.synchronize()
-        start = threading.Barrier(k + 1)
-        res = [None] * k
+        for form in ("shared", "partitioned"):
+            if form == "shared" and k > 4:
+                continue
+            ctxs = [lom.ScanContext(grid, partition=((i, k) if form == "partitioned" else None)) for i in range(k)]
+            for c in ctxs:
+                lom.align_repeat(c, d_scan.data_ptr(), d_scan.shape[0], guess, 20)
+            torch.cuda.synchronize()
+            start = threading.Barrier(k + 1)
+            res = [None] * k
 
-        def work(i):
+            def work(i):
+                start.wait()
+                res[i] = lom.align_repeat(ctxs[i], d_scan.data_ptr(), d_scan.shape[0], guess, steps)[1]
+
+            th = [threading.Thread(target=work, args=(i,)) for i in range(k)]
+            for t in th:
+                t.start()
             start.wait()
-            res[i] = lom.align_repeat(ctxs[i], d_scan.data_ptr(), d_scan.shape[0], guess, steps)[1]
-
-        th = [threading.Thread(target=work, args=(i,)) for i in range(k)]
-        for t in th:
-            t.start()
-        start.wait()
-        t0 = time.perf_counter()
-        for t in th:
-            t.join()
-        torch.cuda.synchronize()
-        el = time.perf_counter() - t0
-        out[str(k)] = {"frames_per_s": k * steps / el, "value": sum(r["queries"] for r in res) / el / 1e6, "unit": "Mcorr/s",
-                       "ms_per_align_per_context": el / steps * 1e3,
-                       "host_fallbacks": sum(r["host_fallback"] for r in res)}
-        for c in ctxs:
-            c.close()
+            t0 = time.perf_counter()
+            for t in th:
+                t.join()
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            out[f"{k}_{form}"] = {"contexts": k, "form": form, "frames_per_s": k * steps / el,
+                                  "value": sum(r["queries"] for r in res) / el / 1e6, "unit": "Mcorr/s",
+                                  "ms_per_align_per_context": el / steps * 1e3,
+                                  "host_fallbacks": sum(r["host_fallback"] for r in res)}
+            for c in ctxs:
+                c.close()
     return out
 
 
@@ -809,8 +816,10 @@ def main():
             try:
                 cc = concurrent_contexts(lom, torch, grid, d_scan, guess, args.steps)
                 line["concurrent_contexts"] = dict(cc, note="k threads, one scan context each, the same scan against the one "
-                                                            "keyframe at the same time; a side figure, never `value`")
-                line["frames_per_s_2ctx"] = cc["2"]["frames_per_s"]
+                                                            "keyframe at the same time (shared: every context on the whole GPU; "
+                                                            "partitioned: context i on slice i of k of the compute units); a side "
+                                                            "figure, never `value`")
+                line["frames_per_s_4ctx"] = cc["4_partitioned"]["frames_per_s"]
             except Exception as e:  # noqa: BLE001
                 line["concurrent_contexts"] = {"error": repr(e)[:300]}
         if n == 1 and args.config == "C2" and not args.no_extras and not use_dist:

@@ -341,6 +341,13 @@ void *lom_map_get_stream(lom_map *m);
  * One solve keeps 53 of the 256 CUs busy on a VLP16-sized scan: concurrent contexts are how one GPU is filled. */
 typedef struct lom_scan lom_scan;
 int lom_scan_create(lom_map *map, lom_scan **out);
+/* The same, on a slice of the GPU: the context's stream runs on partition `part` of `nparts` equal, disjoint slices of
+ * the device's compute units (a CU mask on the stream: the same number of CUs on every XCD; 1 <= nparts <= 8), and its
+ * grids are sized for that slice.  One align alone leaves most of the GPU idle between the launches of its dependent
+ * chain, and unpartitioned contexts queue behind each other's full-GPU search grids; k callers on k slices run side by
+ * side (bench.py concurrent_contexts: 4 callers against 1).  Results do not depend on the slice: bit for bit those of
+ * lom_scan_create / of the map handle.  A stream handed over with lom_scan_set_stream overrides the partition. */
+int lom_scan_create_on_partition(lom_map *map, int part, int nparts, lom_scan **out);
 void lom_scan_destroy(lom_scan *s);
 const char *lom_scan_last_error(const lom_scan *s);
 int lom_scan_set_option(lom_scan *s, int option, int64_t value);   /* lom_map_set_option's switches, per context */

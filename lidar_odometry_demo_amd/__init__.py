@@ -234,9 +234,15 @@ class ScanContext:
     align against one keyframe at a time.  Pass it to CloudMatcher.align / alignDevice / align_repeat in place of the
     grid.  One caller per context; nobody changes the grid while contexts are in use."""
 
-    def __init__(self, keyframe):
+    def __init__(self, keyframe, partition=None):
+        """partition = (index, count): the context's stream runs on that slice of the GPU's compute units
+        (lom_scan_create_on_partition) -- for `count` callers side by side."""
         h = C.c_void_p()
-        capi.check(capi.lib().lom_scan_create(keyframe.handle, C.byref(h)), keyframe.handle)
+        if partition is None:
+            capi.check(capi.lib().lom_scan_create(keyframe.handle, C.byref(h)), keyframe.handle)
+        else:
+            capi.check(capi.lib().lom_scan_create_on_partition(keyframe.handle, int(partition[0]), int(partition[1]),
+                                                               C.byref(h)), keyframe.handle)
         self._h = h
         self.keyframe = keyframe          # keeps the grid alive
 

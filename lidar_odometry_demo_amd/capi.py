@@ -127,7 +127,7 @@ EXPORTED = [
     "lom_map_set_option", "lom_map_debug_counter", "lom_odometry_set_option", "lom_odometry_debug_counter",
     "lom_frontend_set_option", "lom_host_comm_set_timeout", "lom_host_comm_abort", "lom_host_comm_last_error",
     "lom_scan_create", "lom_scan_destroy", "lom_scan_last_error", "lom_scan_set_option", "lom_scan_set_stream",
-    "lom_scan_get_stream", "lom_scan_align", "lom_scan_align_device", "lom_scan_align_repeat", "lom_scan_find_pairs", "lom_scan_find_pairs_sq",
+    "lom_scan_get_stream", "lom_scan_create_on_partition", "lom_scan_align", "lom_scan_align_device", "lom_scan_align_repeat", "lom_scan_find_pairs", "lom_scan_find_pairs_sq",
 ]
 
 # lom_option / counters of include/lidar_odometry_amd.h
@@ -306,6 +306,8 @@ def lib():
     L.lom_host_comm_last_error.argtypes = [vp]
     L.lom_host_comm_last_error.restype = C.c_char_p
     L.lom_scan_create.argtypes = [vp, C.POINTER(vp)]
+    L.lom_scan_create_on_partition.argtypes = [vp, C.c_int, C.c_int, C.POINTER(vp)]
+    L.lom_scan_create_on_partition.restype = C.c_int
     L.lom_scan_destroy.argtypes = [vp]
     L.lom_scan_destroy.restype = None
     L.lom_scan_last_error.argtypes = [vp]

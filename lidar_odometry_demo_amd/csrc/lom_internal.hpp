@@ -146,6 +146,9 @@ struct lom_map {
     std::mutex settle_mutex;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
+    // compute units this handle's own stream runs on: 0 = all of the device; a scan context on a partition
+    // (lom_scan_create_on_partition) owns a stream with a CU mask, and its grids are sized for that many CUs
+    uint32_t partition_cus = 0;
     float voxel_size = 0.5f;
     uint32_t K = 10;          // row stride of the slabs: the largest max_points_ the stored voxels have seen
     uint32_t max_points = 10; // max_points_ (voxel_grid.h:253): what an insert fills a voxel up to; <= K

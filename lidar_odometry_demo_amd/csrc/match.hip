@@ -1595,11 +1595,13 @@ static inline float threshold_f32(double max_sq)
 }
 
 constexpr uint32_t kMaxMatchBlocks = 256u * (uint32_t)kMatchMinWaves;  // one resident round: kMatchMinWaves workgroups of 4 waves per CU
-static uint32_t match_grid(uint32_t n)
+// (a context on a partition of the GPU: one resident round of ITS compute units)
+static uint32_t match_grid(uint32_t n, uint32_t partition_cus = 0)
 {
     const uint32_t per_block = (uint32_t)(kMatchThreads / kMatchG);
     const uint32_t need = (n + per_block - 1) / per_block;
-    return std::max(1u, std::min(need, kMaxMatchBlocks));
+    const uint32_t cap = partition_cus ? partition_cus * (uint32_t)kMatchMinWaves : kMaxMatchBlocks;
+    return std::max(1u, std::min(need, cap));
 }
 
 constexpr uint32_t kMaxEvalBlocks = 64;  // records per launch (the host polls this many words)
@@ -1656,7 +1658,7 @@ static int launch_match(ScanCtx &c, const float t[3], const float q[4], float ma
     PoseArgs P;
     std::memset(&P, 0, sizeof P);
     if (!chained) pose_args(t, q, max_sq, P);
-    c.match_blocks = c.n ? match_grid(c.n) : 0;
+    c.match_blocks = c.n ? match_grid(c.n, m->stream == m->own_stream ? m->partition_cus : 0u) : 0;
     server_stop(m);  // the previous outer iteration's evaluation server leaves before the new search
     const double t_launch = now_s();
     if (c.n) {
@@ -1953,6 +1955,7 @@ static int lm_block_limit(lom_map *m, LmShape shape, uint32_t *out)
             LOM_HIP(m, hipOccupancyMaxActiveBlocksPerMultiprocessor(
                            &per_cu, reinterpret_cast<const void *>(k_lm<kEvalThreads, (int)kMaxLmBlocksBig>), kEvalThreads, 0));
         LOM_HIP(m, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, m->device));
+        if (m->partition_cus) cus = (int)m->partition_cus;  // this handle's stream only reaches its slice of the device
         cached = (uint32_t)std::max(1, per_cu * cus);
     }
     *out = cached;

@@ -1229,11 +1229,29 @@ int lom_device_local_cpus(int device, char *out, size_t cap)
 const char *lom_last_error(const lom_map *m) { return m ? m->last_error.c_str() : g_create_error.c_str(); }
 
 // what every handle owns besides a map: a stream and the pinned blocks the align talks to the host through
-static int handle_setup(lom_map *m)
+// (part >= 0: the stream runs on partition `part` of `nparts` equal slices of the device's compute units)
+static hipError_t create_stream(lom_map *m, int part, int nparts)
+{
+    if (part < 0) return hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking);
+    int cus = 0;
+    hipError_t e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, m->device);
+    if (e != hipSuccess) return e;
+    // Bit i of the mask is the device's i-th compute unit in the driver's enumeration, which deals consecutive bits
+    // round-robin over the XCDs: a contiguous range of bits is the same number of CUs on every XCD.
+    const uint32_t lo = (uint32_t)((uint64_t)cus * (uint32_t)part / (uint32_t)nparts);
+    const uint32_t hi = (uint32_t)((uint64_t)cus * ((uint32_t)part + 1u) / (uint32_t)nparts);
+    std::vector<uint32_t> mask(((size_t)cus + 31) / 32, 0u);
+    for (uint32_t c = lo; c < hi; c++) mask[c >> 5] |= 1u << (c & 31);
+    e = hipExtStreamCreateWithCUMask(&m->own_stream, (uint32_t)mask.size(), mask.data());
+    if (e == hipSuccess) m->partition_cus = hi - lo;
+    return e;
+}
+
+static int handle_setup(lom_map *m, int part = -1, int nparts = 1)
 {
     hipError_t e;
     if ((e = hipSetDevice(m->device)) != hipSuccess ||
-        (e = hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = create_stream(m, part, nparts)) != hipSuccess ||
         (e = hipHostMalloc((void **)&m->h_results, 1024 * sizeof(double), hipHostMallocDefault)) != hipSuccess ||
         (e = hipHostMalloc((void **)&m->h_flags, 64 * sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess ||
         (e = hipHostMalloc((void **)&m->h_mail, 64 * 32 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent)) !=
@@ -1255,10 +1273,14 @@ static int handle_setup(lom_map *m)
 // The reference's search and align take the grid by const reference (voxel_grid.h:164,206; cloud_matcher.h:15-16):
 // any number of callers may align against one keyframe at a time.  A context is a handle without a map of its own
 // -- stream, per-scan buffers, solve state, report block -- whose kernels read the keyframe's table and slabs.
-int lom_scan_create(lom_map *map, lom_scan **out)
+int lom_scan_create(lom_map *map, lom_scan **out) { return lom_scan_create_on_partition(map, -1, 1, out); }
+
+int lom_scan_create_on_partition(lom_map *map, int part, int nparts, lom_scan **out)
 {
     if (!map || !out) return LOM_ERR_ARG;
     *out = nullptr;
+    if (part >= 0 && (nparts < 1 || nparts > 8 || part >= nparts))
+        return set_error(map, LOM_ERR_ARG, "partition index / count: 0 <= part < nparts <= 8");
     if (map->parent) return set_error(map, LOM_ERR_ARG, "a scan context cannot be the keyframe of another");
     LOM_HIP(map, hipSetDevice(map->device));
     int rc;
@@ -1279,7 +1301,7 @@ int lom_scan_create(lom_map *map, lom_scan **out)
     c->opt_no_temporal = map->opt_no_temporal;
     c->opt_count = map->opt_count;
     c->patience_ticks = map->patience_ticks;
-    if (handle_setup(c) != LOM_OK) {
+    if (handle_setup(c, part, nparts) != LOM_OK) {
         map->last_error = g_create_error;
         lom_map_destroy(c);
         return LOM_ERR_HIP;

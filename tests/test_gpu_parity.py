@@ -954,11 +954,14 @@ def test_map_maintenance_survives_a_grid_give_up(lom, oracle, fixture_cloud, fai
 
 # ---- several callers, one keyframe (const VoxelGrid&, voxel_grid.h:206 / cloud_matcher.h:15) -----------------------
 
-def test_scan_contexts_align_concurrently_against_one_keyframe(lom):
+@pytest.mark.parametrize("again", range(3))
+def test_scan_contexts_align_concurrently_against_one_keyframe(lom, again):
     """Scan contexts (lom_scan_create) own stream, per-scan buffers and solve state; their kernels read the one
     keyframe.  Three threads, one context each, different scans and guesses, many aligns each, all at the same time
     (the C calls release the GIL): every result carries the bits of the same align issued alone through the map
-    handle, and so do the map handle's own aligns afterwards."""
+    handle, and so do the map handle's own aligns afterwards.  No solve loses the device loop: a solve's workgroups
+    wait up to 50 ms for each other, the kernels of the other callers it may have to wait behind last microseconds
+    (measured: 0 fall-backs in 3 x 2 runs of 120 aligns here, 0 of 4,400 in bench.py's concurrent_contexts)."""
     import threading
 
     sm = scenes.small_synth_case()
@@ -1000,11 +1003,10 @@ def test_scan_contexts_align_concurrently_against_one_keyframe(lom):
         assert len(got[i]) == 40
         for t_, q_, st in got[i]:
             fell_back += st["host_fallback"]
-            if not st["host_fallback"]:                      # (a solve that found the GPU too full redoes itself on the
-                assert t_ == w[0] and q_ == w[1], i          #  host-driven path: same pose to 1e-6, other last bits)
+            assert t_ == w[0] and q_ == w[1], i
             for k in _keys("outer_iterations", "lm_iterations", "evaluations", "queries", "cand_total", "valid_last"):
                 assert st[k] == w[2][k], (i, k)
-    assert fell_back <= 6, fell_back
+    assert fell_back == 0, fell_back
     c = ctxs[0].handle and lom.capi.lib().lom_scan_find_pairs                     # the search entry on a context
     pairs = (lom.capi.Correspondence * len(scan))()
     n_valid = c(ctxs[0].handle, scan.ctypes.data, len(scan), 12, lom.capi.f3((0, 0, 0)), lom.capi.f4((1, 0, 0, 0)), 0.3, pairs)
@@ -1188,3 +1190,60 @@ def test_contexts_created_concurrently_settle_a_pending_insert_once(lom, oracle,
             assert rc == int((want["index"] >= 0).sum())
             _assert_same_pairs(pairs, want)
         del d_xyz, d_nrm
+
+
+def test_partitioned_contexts_run_side_by_side_with_the_same_bits(lom):
+    """lom_scan_create_on_partition: k contexts on k disjoint slices of the compute units (a CU mask on each context's
+    stream).  Four threads, many aligns each, all at once: every result carries the bits of the same align issued alone
+    through the map handle -- the slice changes where the kernels run, not what they compute -- and no solve ever finds
+    its workgroups short of room (host_fallback == 0: each context's kernels have their slice to themselves)."""
+    import threading
+
+    sm = scenes.small_synth_case()
+    g = lom.VoxelGrid(0.5, 20)
+    g.addCloud(sm["map_xyz"], sm["map_nrm"])
+    scan = sm["scan"]
+    jobs = [(np.ascontiguousarray(scan[0::2]), lom.Pose3D((0.0, 0.0, 0.0), scenes.angle_axis_q(0.01, (0, 0, 1)))),
+            (np.ascontiguousarray(scan[1::2]), lom.Pose3D((0.2, -0.2, 0.0), scenes.angle_axis_q(0.01, (0, 0, 1)))),
+            (scan, lom.Pose3D((0.05, 0.02, 0.0), (1, 0, 0, 0))),
+            (np.ascontiguousarray(scan[::3]), lom.Pose3D((-0.1, 0.05, 0.02), scenes.angle_axis_q(-0.008, (0, 0, 1))))]
+    m = lom.CloudMatcher()
+    want = []
+    for cloud, guess in jobs:
+        p = m.align(g, cloud, guess)
+        want.append((p.translation.tobytes(), p.rotation.tobytes(), dict(m.stats)))
+    ctxs = [lom.ScanContext(g, partition=(i, len(jobs))) for i in range(len(jobs))]
+    got = [[] for _ in jobs]
+    errors = []
+    start = threading.Barrier(len(jobs))
+
+    def worker(i):
+        try:
+            mm = lom.CloudMatcher()
+            cloud, guess = jobs[i]
+            start.wait()
+            for _ in range(60):
+                p = mm.align(ctxs[i], cloud, guess)
+                got[i].append((p.translation.tobytes(), p.rotation.tobytes(), dict(mm.stats)))
+        except Exception as e:  # noqa: BLE001
+            errors.append((i, repr(e)))
+
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(len(jobs))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
+    for i, w in enumerate(want):
+        assert len(got[i]) == 60
+        for t_, q_, st in got[i]:
+            assert st["host_fallback"] == 0
+            assert t_ == w[0] and q_ == w[1], i
+            for k in _keys("outer_iterations", "lm_iterations", "evaluations", "queries", "cand_total", "valid_last"):
+                assert st[k] == w[2][k], (i, k)
+    # bad arguments are refused
+    h = C.c_void_p()
+    assert lom.capi.lib().lom_scan_create_on_partition(g.handle, 3, 3, C.byref(h)) == -1
+    assert lom.capi.lib().lom_scan_create_on_partition(g.handle, 0, 9, C.byref(h)) == -1
+    for cx in ctxs:
+        cx.close()
