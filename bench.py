@@ -49,6 +49,15 @@ def claim_stdout():
     os.dup2(2, 1)
 
 
+_T_START = time.perf_counter()
+
+
+def progress(what):
+    """LOM_BENCH_PROGRESS=1: where the run is, on stderr (the line itself stays the only thing on stdout)"""
+    if os.environ.get("LOM_BENCH_PROGRESS"):
+        print(f"[bench {time.perf_counter() - _T_START:7.1f} s] {what}", file=sys.stderr, flush=True)
+
+
 def emit(line):
     sys.stdout.flush()
     os.write(_REAL_STDOUT if _REAL_STDOUT is not None else 1, (json.dumps(line) + "\n").encode())
@@ -492,6 +501,11 @@ def main():
         # no launcher around us: be the launcher (before torch is imported or any HIP call is made in this process)
         sys.exit(self_launch(args.gpus, sys.argv[1:]))
     claim_stdout()
+    if os.environ.get("LOM_BENCH_WATCHDOG_S"):
+        # debugging aid: the Python stacks of all threads on stderr after that many seconds, then exit
+        import faulthandler
+
+        faulthandler.dump_traceback_later(float(os.environ["LOM_BENCH_WATCHDOG_S"]), exit=True)
 
     import torch
     import torch.distributed as dist
@@ -530,7 +544,9 @@ def main():
     if args.config == "C5":
         emit(streaming(args, lom))
         return
+    progress("building the workload")
     work = build_workload(n, rank, args.config)
+    progress("workload built")
     grid = lom.VoxelGrid(0.5, 20, device=local_rank)
     # the keyframe map: one bulk insert of device-resident points, bracketed by HIP events on the library's
     # stream (roofline entry of the insert chain; outside the timed region)
@@ -610,6 +626,7 @@ def main():
     # steady state; run the same workload (untimed) for about a quarter of a second first
     # (a fixed count, not a time limit: with several ranks every step is a sequence of exchanges
     # and all ranks must take the same number of them)
+    progress("map built; warm-up")
     lom.align_repeat(grid, d_scan.data_ptr(), d_scan.shape[0], guess, 600)
     for _ in range(args.warmup):
         step()
@@ -639,6 +656,7 @@ def main():
     lm_ms, lm_profiled = tot["lm_kernel_ms"], tot["lm_profiled_launches"]
     valid_last = tot["valid_last"]
     # the reference-algorithm counts of this align (all ranks take part: an align is a sequence of exchanges), untimed
+    progress("timed block done")
     replay = counted_replay(lom, grid, d_scan, guess)
     # ... and what producing them costs the product: one block of K steps with the counts on (never `value`)
     grid.setOption(lom.capi.OPT_COUNT_CANDIDATES, 1)
@@ -808,18 +826,23 @@ def main():
             "roofline": roof,
             "roofline_kernels": kernels,
         }
+        progress("line assembled")
         if n == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(work)
+            progress("cpu baseline done")
             line["speedup_vs_cpu_port"] = value / line["cpu_baseline"]["value"]
         line["pose"] = {"t": [float(v) for v in pose.translation], "q_wxyz": [float(v) for v in pose.rotation]}
-        if n == 1 and not use_dist and not args.no_extras:
+        # (C2 only: on a slice of the GPU the 128 x 512-thread solve of the 64- / 128-beam scans is not co-resident, every
+        # launch sits out its patience and the align is redone by the host-driven loop -- minutes per block)
+        if n == 1 and args.config == "C2" and not use_dist and not args.no_extras:
             try:
-                cc = concurrent_contexts(lom, torch, grid, d_scan, guess, args.steps)
+                cc = concurrent_contexts(lom, torch, grid, d_scan, guess, min(args.steps, 100), counts=(2, 3, 4, 8))
                 line["concurrent_contexts"] = dict(cc, note="k threads, one scan context each, the same scan against the one "
                                                             "keyframe at the same time (shared: every context on the whole GPU; "
                                                             "partitioned: context i on slice i of k of the compute units); a side "
                                                             "figure, never `value`")
                 line["frames_per_s_4ctx"] = cc["4_partitioned"]["frames_per_s"]
+                progress("concurrent contexts done")
             except Exception as e:  # noqa: BLE001
                 line["concurrent_contexts"] = {"error": repr(e)[:300]}
         if n == 1 and args.config == "C2" and not args.no_extras and not use_dist:
@@ -829,6 +852,7 @@ def main():
             try:
                 w3 = build_workload(1, 0, "C3")
                 extras["C3"] = align_block(lom, torch, w3, dev, steps=max(20, args.steps // 4))
+                progress("extra C3 done")
             except Exception as e:  # noqa: BLE001  (an extra must not cost the line)
                 w3 = None
                 extras["C3"] = {"error": repr(e)[:300]}
@@ -840,6 +864,7 @@ def main():
                            name=f"C4 (BASELINE configs[3]) on one GPU: 128x2048 scan ({len(scan4)} returns) vs 2M-pt map, "
                                 f"voxel 0.5 m, cap 20") if w3 is not None else build_workload(1, 0, "C4"))
                 extras["C4"] = align_block(lom, torch, w4, dev, steps=max(20, args.steps // 4), warmup_aligns=100)
+                progress("extra C4 done")
                 del w4
             except Exception as e:  # noqa: BLE001
                 extras["C4"] = {"error": repr(e)[:300]}

@@ -307,16 +307,27 @@ typedef enum {
                                           result cannot depend on a voxel none of whose points could win) and those fields read
                                           0.  LOM_COUNT_CANDIDATES=1 in the environment at create.  bench.py times the default
                                           and takes the algorithmic bytes from a counted replay of the same align. */
+    LOM_OPT_NO_BULK_INSERT = 7,        /* 1: inserts of more than 65,536 points take the four-kernel path of the smaller ones
+                                          (three device-scope atomics per point) instead of the partitioned bulk insert
+                                          (csrc/voxel_map.hip "bulk insert").  Same map either way, bytewise; the switch exists
+                                          for A/B timing (LOM_NO_BULK_INSERT=1 in the environment at create) */
     LOM_OPT_TEST_GIVE_UP_AT_OUTER = 100, /* k: the k_lm of outer iteration k of the NEXT align behaves as if its
                                           workgroups had timed out waiting (one shot; -1 = off) */
     LOM_OPT_TEST_GRID_GIVE_UP = 101,   /* b >= 0: in the NEXT map-maintenance call with an in-kernel scan, workgroups
                                           b, b+1, ... give up waiting for their predecessors (one shot; -1 = off;
-                                          + 65536 per such call to let pass first) */
+                                          + 65536 per such call to let pass first).  lom_frontend_set_option /
+                                          lom_odometry_set_option also take b + 0x40000000: workgroup b ALONE gives up, the
+                                          ones behind it get their prefix (a hole in the middle of the front end's output) */
     /* lom_odometry_set_option only: */
     LOM_OPT_TEST_FORCE_HOST_REDO = 102,        /* 1: every frame is handed back to the host stages */
     LOM_OPT_TEST_GRID_GIVE_UP_MATCHING_DS = 103, /* LOM_OPT_TEST_GRID_GIVE_UP on the matching down-sampler ... */
     LOM_OPT_TEST_GRID_GIVE_UP_UPDATE_DS = 104,   /* ... the next frame's update down-sampler ... */
-    LOM_OPT_TEST_GRID_GIVE_UP_KEYFRAME = 105     /* ... the keyframe (its next insert or cleanup) */
+    LOM_OPT_TEST_GRID_GIVE_UP_KEYFRAME = 105,    /* ... the keyframe (its next insert or cleanup) */
+    /* lom_map_set_option again: */
+    LOM_OPT_TEST_BULK_PARTITION_MAX = 106        /* p > 0: a partition of the bulk insert may hold p points (at most the
+                                                    1,024 its workgroup has LDS for; 0 = that limit): a bulk insert with a
+                                                    larger partition writes nothing and is redone by the four-kernel path
+                                                    (counted by LOM_COUNTER_GRID_REDOS) */
 } lom_option;
 int lom_map_set_option(lom_map *m, int option, int64_t value);
 /* diagnostics: LOM_COUNTER_GRID_REDOS = calls of this handle redone with the multi-launch scan after an

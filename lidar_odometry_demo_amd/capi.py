@@ -133,6 +133,7 @@ EXPORTED = [
 # lom_option / counters of include/lidar_odometry_amd.h
 OPT_HOST_LM, OPT_DEVICE_PATIENCE_TICKS, OPT_DEBUG_LM_STAMPS, OPT_DEBUG_TIMING, OPT_NO_TEMPORAL_BOUND, OPT_COUNT_CANDIDATES = 1, 2, 3, 4, 5, 6
 OPT_TEST_GIVE_UP_AT_OUTER, OPT_TEST_GRID_GIVE_UP, OPT_TEST_FORCE_HOST_REDO = 100, 101, 102
+OPT_NO_BULK_INSERT, OPT_TEST_BULK_PARTITION_MAX = 7, 106
 OPT_TEST_GRID_GIVE_UP_MATCHING_DS, OPT_TEST_GRID_GIVE_UP_UPDATE_DS, OPT_TEST_GRID_GIVE_UP_KEYFRAME = 103, 104, 105
 COUNTER_GRID_REDOS = 0
 

@@ -378,7 +378,10 @@ __global__ __launch_bounds__(kThreads) void k_fe_planar(const float4 *__restrict
         at++;
     }
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
-        const unsigned long long all = gave_up ? 0ull : before + tot;  // a grid that gave up hands an empty cloud on
+        // a grid that gave up hands an empty cloud on -- also when it was a workgroup in the MIDDLE that gave up and this
+        // one still got its prefix (the slow predecessor published in between): part of the output was never written
+        const bool hole = __hip_atomic_load(words + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == seq;
+        const unsigned long long all = (gave_up || hole) ? 0ull : before + tot;
         words[0] = (uint32_t)(all >> 32);  // planar points
         words[1] = (uint32_t)all;          // after the range filter
     }
@@ -546,7 +549,7 @@ const char *lom_frontend_last_error(const lom_frontend *f) { return f ? f->error
 int lom_frontend_set_option(lom_frontend *f, int option, int64_t value)
 {
     if (!f) return LOM_ERR_ARG;
-    if (option == LOM_OPT_TEST_GRID_GIVE_UP && value >= -1 && value <= 65535) {
+    if (option == LOM_OPT_TEST_GRID_GIVE_UP && value >= -1 && (value & ~(int64_t)kGridFailOnlyOne) <= 65535) {
         f->test_grid_give_up = (int)value;
         return LOM_OK;
     }

@@ -26,6 +26,7 @@ static inline uint32_t blocks_for(size_t n, int t = kThreads) { return (uint32_t
 constexpr uint32_t kOnePassMax = 256u * kThreads;
 constexpr uint32_t kInvalidSlot = 0xFFFFFFFFu;
 constexpr unsigned long long kGridWaitTicks = 2000000ull;  // 20 ms of s_memrealtime (100 MHz)
+constexpr uint32_t kGridFailOnlyOne = 0x40000000u;
 
 struct __attribute__((aligned(8))) Granule {
     uint32_t seq, val;
@@ -81,7 +82,8 @@ __device__ __forceinline__ unsigned long long block_scan64(unsigned long long v,
 // sum of the (lo, hi) totals of all workgroups before this one; agg: [gridDim.x][2] granules.
 // gave_up (uniform over the workgroup): a wait timed out, the returned prefix is not valid.
 // test_fail_from: workgroups of that index and beyond behave as if their waits had timed out
-// (LOM_OPT_TEST_GRID_GIVE_UP; 0xFFFFFFFF in production).
+// (LOM_OPT_TEST_GRID_GIVE_UP; 0xFFFFFFFF in production); with kGridFailOnlyOne set, that workgroup alone -- a give-up
+// in the middle of a grid whose later workgroups still get their prefix.
 __device__ __forceinline__ unsigned long long grid_prefix64(unsigned long long my_total, Granule *agg, uint32_t seq,
                                                             uint32_t *err_word, unsigned long long *s_w, bool &gave_up,
                                                             uint32_t test_fail_from = 0xFFFFFFFFu)
@@ -93,7 +95,10 @@ __device__ __forceinline__ unsigned long long grid_prefix64(unsigned long long m
     unsigned long long v = 0;
     bool timed_out = false;
     if (threadIdx.x < blockIdx.x) {
-        if (blockIdx.x >= test_fail_from) {
+        const bool forced = (test_fail_from != 0xFFFFFFFFu && (test_fail_from & kGridFailOnlyOne))
+                                ? blockIdx.x == (test_fail_from & ~kGridFailOnlyOne)
+                                : blockIdx.x >= test_fail_from;
+        if (forced) {
             __hip_atomic_store(err_word, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             timed_out = true;
         } else {

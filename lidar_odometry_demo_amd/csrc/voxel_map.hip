@@ -108,7 +108,10 @@ enum {
     S_ITEMS,
     S_SCAN,
     S_DS_HEAD,
-    S_MISC
+    S_MISC,
+    S_ENT_ROW,  // bulk insert: row of every survivor
+    S_HIST,     // bulk insert: [partition][block] counts
+    S_PART      // bulk insert: partition sizes and starts
 };
 
 
@@ -613,6 +616,307 @@ __global__ __launch_bounds__(kThreads) void k_ins_place2(Slot *table, uint32_t n
     }
 }
 
+// ---- bulk insert (batches above kOnePassMax points): partitions of the table, grouped in LDS -------------
+// The four kernels above pay three scattered device-scope atomics per point (slot CAS, bucket count, earliest
+// index) and write every stored point as a lone 12-byte transaction.  A bulk batch -- the map build -- goes
+// through a partition pass instead, so that all points of one voxel meet in ONE workgroup and everything per
+// voxel happens in LDS:
+//   1. k_bi_claim    slot per point (look, CAS only where the slot is still empty); LDS histogram of the
+//                    points over the partitions (partition = a contiguous segment of the table: the top bits
+//                    of the slot), one column of the [partition][block] count matrix per workgroup
+//   2. k_bi_colscan  one wave per partition: prefix of its counts over the blocks (blocks are in input order,
+//                    so a partition's list is ordered by block); partition sizes; verdict (a partition above
+//                    the LDS budget of step 4 sends the whole call to the four-kernel path: nothing written)
+//   3. k_bi_scatter  (slot, input index) pairs to their partition's list (LDS cursor per partition)
+//   4. k_bi_group    one workgroup per partition, all in LDS: points -> voxels (hash on the slot), bucket
+//                    sizes, room left in each voxel (voxel_grid.h:86), rank of every point inside its voxel
+//                    by input index (= insertion order), the first `room` survive; the survivors of a voxel
+//                    are written out side by side, in rank order; a NEW voxel's first point raises a flag at
+//                    its input index
+//   5. scan of the flags (two launches): creation order = order of first appearance (voxel_grid.h:83-87)
+//   6. k_bi_place    one thread per survivor: consecutive threads write consecutive rows of a slab --
+//                    coalesced slab writes, nothing but the stored rows is written
+// No kernel waits for another workgroup, so there is no give-up path; a range error (step 1) or an oversized
+// partition (step 2) is known before anything is written except claimed keys, which the table tolerates
+// (slab == kNoSlab, as after a range error of the four-kernel path).
+constexpr int kBiThreads = 1024;         // k_bi_claim, k_bi_scatter
+constexpr uint32_t kBiPartMax = 1024;    // points per partition k_bi_group holds in LDS
+constexpr uint32_t kBiEntries = 2 * kBiPartMax;
+constexpr uint32_t kBiMaxParts = 8192;   // LDS histogram of k_bi_claim: 32 KB
+constexpr uint32_t kBiMaxPoints = 4u << 20;
+constexpr uint32_t kBiDropped = 0xFFFFFFFFu;
+constexpr uint32_t kBiNewBit = 0x80000000u;
+
+__global__ __launch_bounds__(kBiThreads) void k_bi_claim(Slot *table, uint32_t mask, uint32_t shift, const char *xyz,
+                                                         size_t stride, uint32_t n, float vs, uint32_t *pt_slot,
+                                                         uint32_t *flag, uint32_t *hist, uint32_t n_parts,
+                                                         uint32_t part_shift, uint32_t n_blk, uint32_t ppt,
+                                                         const uint32_t *n_vox_dev, uint32_t seq, uint32_t *words)
+{
+    extern __shared__ uint32_t s_hist[];
+    for (uint32_t b = threadIdx.x; b < n_parts; b += kBiThreads) s_hist[b] = 0u;
+    if (blockIdx.x == 0 && threadIdx.x == 0) words[9] = *n_vox_dev;  // voxel count before this call (k_bi_place)
+    __syncthreads();
+    const uint32_t first = blockIdx.x * ppt * kBiThreads;
+    for (uint32_t k = 0; k < ppt; k++) {
+        const uint32_t i = first + k * kBiThreads + threadIdx.x;
+        if (i >= n) break;
+        const float *p = point_at(xyz, i, stride);
+        int ix = 0, iy = 0, iz = 0;
+        flag[i] = 0u;
+        if (!voxel_index(p[0], vs, ix) || !voxel_index(p[1], vs, iy) || !voxel_index(p[2], vs, iz)) {
+            pt_slot[i] = kInvalidSlot;
+            __hip_atomic_store(words + 5, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // LOM_ERR_RANGE for this call
+            continue;
+        }
+        const uint32_t h = claim_slot(table, mask, shift, pack_key(ix, iy, iz));
+        pt_slot[i] = h;
+        atomicAdd(&s_hist[h >> part_shift], 1u);
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < n_parts; b += kBiThreads) hist[(size_t)b * n_blk + blockIdx.x] = s_hist[b];
+}
+
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v)
+{
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(v, d, 64);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(kThreads) void k_bi_colscan(uint32_t *hist, uint32_t n_parts, uint32_t n_blk,
+                                                         uint32_t *part_total, uint32_t part_max, uint32_t seq,
+                                                         uint32_t *words)
+{
+    if (words[5] == seq) return;
+    const uint32_t part = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63;
+    if (part >= n_parts) return;
+    uint32_t *row = hist + (size_t)part * n_blk;
+    uint32_t carry = 0;
+    for (uint32_t c = 0; c < n_blk; c += 64) {
+        const uint32_t b = c + lane;
+        const uint32_t v = b < n_blk ? row[b] : 0u;
+        const uint32_t inc = wave_inclusive_scan(v);
+        if (b < n_blk) row[b] = carry + inc - v;
+        carry += __shfl(inc, 63, 64);
+    }
+    if (lane == 0) {
+        part_total[part] = carry;
+        if (carry > part_max) __hip_atomic_store(words + 8, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+__global__ __launch_bounds__(kBiThreads) void k_bi_scatter(uint32_t n, const uint32_t *__restrict__ pt_slot,
+                                                           const uint32_t *__restrict__ hist, uint32_t n_parts,
+                                                           uint32_t part_shift, uint32_t n_blk, uint32_t ppt,
+                                                           const uint32_t *__restrict__ part_total, uint32_t *part_start,
+                                                           uint32_t *part_slot, uint32_t *part_idx, uint32_t seq,
+                                                           const uint32_t *words)
+{
+    extern __shared__ uint32_t s_cur[];  // [n_parts] write cursor of this block in every partition's list
+    __shared__ uint32_t s_w[kBiThreads / 64];
+    if (words[5] == seq || words[8] == seq) return;
+    // start of every partition's list = exclusive scan of the partition sizes (every block redoes it: <= 8192 values)
+    const uint32_t per = (n_parts + kBiThreads - 1) / kBiThreads;
+    const uint32_t b0 = threadIdx.x * per;
+    uint32_t sum = 0;
+    for (uint32_t b = b0; b < b0 + per && b < n_parts; b++) sum += part_total[b];
+    const uint32_t inc = wave_inclusive_scan(sum);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 63) s_w[wave] = inc;
+    __syncthreads();
+    uint32_t run = inc - sum;
+    for (int w = 0; w < wave; w++) run += s_w[w];
+    for (uint32_t b = b0; b < b0 + per && b < n_parts; b++) {
+        s_cur[b] = run + hist[(size_t)b * n_blk + blockIdx.x];
+        if (blockIdx.x == 0) part_start[b] = run;
+        run += part_total[b];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == kBiThreads - 1) part_start[n_parts] = run;
+    __syncthreads();
+    const uint32_t first = blockIdx.x * ppt * kBiThreads;
+    for (uint32_t k = 0; k < ppt; k++) {
+        const uint32_t i = first + k * kBiThreads + threadIdx.x;
+        if (i >= n) break;
+        const uint32_t h = pt_slot[i];
+        const uint32_t pos = atomicAdd(&s_cur[h >> part_shift], 1u);
+        part_slot[pos] = h;
+        part_idx[pos] = i;
+    }
+}
+
+// One workgroup per partition.  What it leaves behind, at the partition's positions of three N-sized arrays:
+// the survivors (points that are stored) first, grouped by voxel and in rank order inside a voxel --
+// ent_idx = input index, ent_w = slot | kBiNewBit for a voxel this call creates, ent_row = row inside the slab --
+// and ent_row = kBiDropped for the rest.  table[h].count (and slab_count of voxels that exist) are final here;
+// slab ids of new voxels follow from the scan of the flags (k_bi_place).
+__global__ __launch_bounds__(kThreads) void k_bi_group(Slot *table, const uint32_t *__restrict__ part_start,
+                                                       const uint32_t *__restrict__ part_slot,
+                                                       const uint32_t *__restrict__ part_idx, uint32_t cap_points,
+                                                       uint32_t *slab_count, uint32_t *flag, uint32_t *ent_idx,
+                                                       uint32_t *ent_w, uint32_t *ent_row, uint32_t seq,
+                                                       const uint32_t *words)
+{
+    __shared__ uint32_t s_key[kBiEntries];   // slot of the voxel (0xFFFFFFFF: free)
+    __shared__ uint32_t s_cnt[kBiEntries];   // points of this call in the voxel
+    __shared__ uint32_t s_old[kBiEntries];   // stored points before this call | kBiNewBit
+    __shared__ uint16_t s_start[kBiEntries]; // first position of the voxel's bucket in s_grp
+    __shared__ uint16_t s_sst[kBiEntries];   // first position of the voxel's survivors in the output
+    __shared__ uint32_t s_idx[kBiPartMax];
+    __shared__ uint32_t s_grp[kBiPartMax];
+    __shared__ uint32_t s_w[kThreads / 64];
+    if (words[5] == seq || words[8] == seq) return;
+    const uint32_t base = part_start[blockIdx.x];
+    const uint32_t P = part_start[blockIdx.x + 1] - base;
+    if (P == 0) return;
+    uint32_t E = 256;  // entries: a power of two >= 2 P
+    while (E < 2 * P) E <<= 1;
+    const uint32_t ebits = (uint32_t)__builtin_ctz(E);
+    for (uint32_t e = threadIdx.x; e < E; e += kThreads) {
+        s_key[e] = 0xFFFFFFFFu;
+        s_cnt[e] = 0u;
+    }
+    __syncthreads();
+    constexpr int kItems = kBiPartMax / kThreads;
+    uint32_t my_e[kItems], my_a[kItems];
+#pragma unroll
+    for (int k = 0; k < kItems; k++) {
+        const uint32_t j = k * kThreads + threadIdx.x;
+        my_e[k] = 0;
+        my_a[k] = 0;
+        if (j < P) {
+            const uint32_t h = part_slot[base + j];
+            s_idx[j] = part_idx[base + j];
+            uint32_t e = (h * 0x9E3779B1u) >> (32 - ebits);
+            for (;;) {
+                const uint32_t prev = atomicCAS(&s_key[e], 0xFFFFFFFFu, h);
+                if (prev == 0xFFFFFFFFu || prev == h) break;
+                e = (e + 1) & (E - 1);
+            }
+            my_e[k] = e;
+            my_a[k] = atomicAdd(&s_cnt[e], 1u);
+        }
+    }
+    __syncthreads();
+    // per voxel: what the table holds, how much room is left (voxel_grid.h:86: while size() < max_points_), the new count.
+    // Thread t takes the entries [t * ept, (t + 1) * ept), so that the scan below runs over entries in order.
+    const uint32_t ept = E / kThreads;
+    uint32_t packed = 0;  // bucket sizes << 16 | survivors of this thread's entries
+    for (uint32_t e = threadIdx.x * ept; e < (threadIdx.x + 1) * ept; e++) {
+        const uint32_t h = s_key[e];
+        if (h == 0xFFFFFFFFu) continue;
+        const Slot s = table[h];
+        const bool is_new = s.slab == kNoSlab;  // voxel_grid.h:83 it == end()
+        const uint32_t old = is_new ? 0u : s.count;
+        const uint32_t room = cap_points > old ? cap_points - old : 0u;
+        const uint32_t c = s_cnt[e];
+        const uint32_t st = c < room ? c : room;
+        s_old[e] = old | (is_new ? kBiNewBit : 0u);
+        if (st) {
+            table[h].count = old + st;
+            if (!is_new) slab_count[s.slab] = old + st;
+        }
+        packed += (c << 16) | st;
+    }
+    const uint32_t inc = wave_inclusive_scan(packed);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 63) s_w[wave] = inc;
+    __syncthreads();
+    uint32_t run = inc - packed, total = 0;
+#pragma unroll
+    for (int w = 0; w < kThreads / 64; w++) {
+        if (w < wave) run += s_w[w];
+        total += s_w[w];
+    }
+    for (uint32_t e = threadIdx.x * ept; e < (threadIdx.x + 1) * ept; e++) {
+        if (s_key[e] == 0xFFFFFFFFu) continue;
+        const uint32_t old = s_old[e] & ~kBiNewBit;
+        const uint32_t room = cap_points > old ? cap_points - old : 0u;
+        const uint32_t c = s_cnt[e];
+        s_start[e] = (uint16_t)(run >> 16);
+        s_sst[e] = (uint16_t)(run & 0xFFFFu);
+        run += (c << 16) | (c < room ? c : room);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kItems; k++) {
+        const uint32_t j = k * kThreads + threadIdx.x;
+        if (j < P) s_grp[s_start[my_e[k]] + my_a[k]] = s_idx[j];
+    }
+    __syncthreads();
+    const uint32_t survivors = total & 0xFFFFu;
+#pragma unroll
+    for (int k = 0; k < kItems; k++) {
+        const uint32_t j = k * kThreads + threadIdx.x;
+        if (j >= P) continue;
+        const uint32_t e = my_e[k];
+        const uint32_t i = s_idx[j];
+        const uint32_t ow = s_old[e];
+        const uint32_t old = ow & ~kBiNewBit;
+        const uint32_t room = cap_points > old ? cap_points - old : 0u;
+        const uint32_t *g = s_grp + s_start[e];
+        const uint32_t m = s_cnt[e];
+        uint32_t rank = 0;  // voxel_grid.h:86,89-90: append in input order while size() < max_points_
+        for (uint32_t q = 0; q < m && rank < room; q++) rank += g[q] < i;
+        if (rank < room) {
+            const uint32_t o = base + s_sst[e] + rank;
+            ent_idx[o] = i;
+            ent_w[o] = s_key[e] | (ow & kBiNewBit);
+            ent_row[o] = old + rank;
+            if (rank == 0 && (ow & kBiNewBit)) flag[i] = 1u;  // first appearance of a voxel the map does not have yet
+        }
+    }
+    for (uint32_t j = survivors + threadIdx.x; j < P; j += kThreads) ent_row[base + j] = kBiDropped;
+}
+
+// the first level of the flags' scan: k_scan_tile leaves the exclusive scan inside tiles of kScanTile and the
+// tiles' totals; the second launch scans the totals; k_bi_place adds the two (no k_scan_add pass over N words)
+__global__ __launch_bounds__(kThreads) void k_bi_place(Slot *table, uint32_t n, const uint32_t *__restrict__ ent_idx,
+                                                       const uint32_t *__restrict__ ent_w,
+                                                       const uint32_t *__restrict__ ent_row,
+                                                       const uint32_t *__restrict__ scan_local,
+                                                       const uint32_t *__restrict__ tile_prefix,
+                                                       const uint32_t *__restrict__ new_total, const char *xyz,
+                                                       const char *nrm, size_t stride, uint32_t K, float *pts,
+                                                       float *nrm_out, unsigned long long *slab_key, uint32_t *slab_count,
+                                                       uint32_t *n_vox_dev, uint32_t seq, const uint32_t *words)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n || words[5] == seq || words[8] == seq) return;
+    const uint32_t n_vox_before = words[9];
+    if (j == 0) *n_vox_dev = n_vox_before + *new_total;
+    const uint32_t row = ent_row[j];
+    if (row == kBiDropped) return;
+    const uint32_t i = ent_idx[j];
+    const uint32_t w = ent_w[j];
+    const uint32_t h = w & ~kBiNewBit;
+    uint32_t slab;
+    if (w & kBiNewBit) {
+        // a new voxel's survivors sit side by side in rank order and its rows start at 0: the head is `row` to the left
+        const uint32_t head = ent_idx[j - row];
+        slab = n_vox_before + scan_local[head] + tile_prefix[head / kScanTile];  // creation order = order of first appearance
+        if (row == 0) {
+            const Slot s = table[h];
+            table[h].slab = slab;
+            slab_key[slab] = s.key;
+            slab_count[slab] = s.count;
+        }
+    } else {
+        slab = table[h].slab;
+    }
+    const size_t dst = ((size_t)slab * K + row) * 3;
+    const Point3 pv = load3(point_at(xyz, i, stride));
+    Point3 nv = {0.f, 0.f, 0.f};  // voxel_grid.h:103,107: no normals -> (0, 0, 0)
+    if (nrm) nv = load3(point_at(nrm, i, stride));
+    store3(pts + dst, pv);
+    store3(nrm_out + dst, nv);
+}
+
 // ---------------------------------------------------------------------------
 // cleanup / export kernels
 // ---------------------------------------------------------------------------
@@ -947,7 +1251,8 @@ static uint32_t take_test_fail_from(lom_map *m)
 // kernels do not wait for each other.
 static int map_status(lom_map *m)
 {
-    int rc = read_words(m, 5, 3);  // [0] range flag, [1] voxel counter, [2] grid error: sequence numbers of failed calls
+    // [0] range flag, [1] voxel counter, [2] grid error, [3] bulk insert sent back: sequence numbers of failed calls
+    int rc = read_words(m, 5, 4);
     if (rc != LOM_OK) return rc;
     const uint32_t checked = m->status_seq;
     m->status_seq = m->call_seq;
@@ -956,9 +1261,12 @@ static int map_status(lom_map *m)
         m->n_vox_ub = m->n_vox;
         m->n_vox_stale = false;
     }
-    const uint32_t grid_seq = m->h_flags[2], range_seq = m->h_flags[0];
+    const uint32_t range_seq = m->h_flags[0];
     const size_t pending = m->pending_n;
-    m->pending_n = 0;  // the last single-pass insert is through, one way or the other
+    m->pending_n = 0;  // the last single-pass / bulk insert is through, one way or the other
+    // a bulk insert with a partition beyond k_bi_group's LDS wrote nothing: the four-kernel path redoes it, like a
+    // single-pass insert whose scan gave up
+    const uint32_t grid_seq = (pending && m->h_flags[3] == m->pending_seq) ? m->h_flags[3] : m->h_flags[2];
     if (grid_seq > checked && grid_seq != m->grid_resolved_seq) {
         if (grid_seq == m->pending_seq && pending) {
             m->grid_redos++;
@@ -1015,14 +1323,106 @@ int resolve_pending(lom_map *m)
 static int settle_pending_locked(lom_map *m)
 {
     if (!m->pending_n) return LOM_OK;  // somebody else settled it while this thread waited for the lock
-    int rc = read_words(m, 7, 1);
+    int rc = read_words(m, 7, 2);  // scan gave up / bulk insert sent back
     if (rc != LOM_OK) return rc;
     const size_t n = m->pending_n;
     m->pending_n = 0;
-    if (m->h_flags[0] != m->pending_seq) return LOM_OK;
+    if (m->h_flags[0] != m->pending_seq && m->h_flags[1] != m->pending_seq) return LOM_OK;
     m->grid_redos++;
     m->grid_resolved_seq = m->pending_seq;
     return add_points_device(m, m->pending_xyz, m->pending_nrm, n, m->pending_stride, false, true, true, true);
+}
+
+// Table size after a bulk insert: 16..32 slots per voxel (LOM_TABLE_SLOTS_PER_VOXEL at create).  The search's probe
+// phase pays for every collision with a dependent round trip, and a longer table costs nothing but memory: k_match on
+// C2 / C3 / C4 with 4 slots per voxel (rounds 1-2) 7.5 / 25.1 / 43.2 us, 8: 7.5 / 24.0 / 41.1, 16: 7.2 / 23.9 / 40.7,
+// 32: 7.2 / 23.8 / 40.6, 64: 7.2 / 23.4 / 40.8 (same box, tools/ab_match.py).
+static int shrink_after_bulk(lom_map *m)
+{
+    if ((uint64_t)m->cap < 16ull * std::max<uint32_t>(m->min_cap, 1u)) return LOM_OK;
+    int rc = refresh_nvox(m);
+    if (rc != LOM_OK) return rc;
+    const uint32_t target = std::max(m->min_cap, next_pow2((uint64_t)m->table_slots_per_voxel * m->n_vox));
+    return m->cap > target ? rehash(m, target) : LOM_OK;
+}
+
+struct BulkShape {
+    uint32_t n_parts, part_shift, ppt, n_blk, n_tiles;
+};
+
+static BulkShape bulk_shape(uint32_t N, uint32_t cap)
+{
+    BulkShape b;
+    uint32_t np = 64;
+    while (np < kBiMaxParts && (uint64_t)np * 256 < N) np <<= 1;  // ~256 points per partition (<= 512 at 4 M points)
+    b.n_parts = std::min(np, cap);
+    b.part_shift = (uint32_t)__builtin_ctz(cap) - (uint32_t)__builtin_ctz(b.n_parts);
+    b.ppt = N <= (1u << 20) ? 4u : 8u;
+    b.n_blk = (N + b.ppt * kBiThreads - 1) / (b.ppt * kBiThreads);
+    b.n_tiles = (N + kScanTile - 1) / kScanTile;
+    return b;
+}
+
+static int bulk_scratch(lom_map *m, uint32_t N, const BulkShape &b)
+{
+    int rc;
+    for (int s : {S_PT_SLOT, S_FLAG, S_RANK, S_PT_POS, S_ITEMS, S_PT_OFF, S_PT_M, S_ENT_ROW})
+        if ((rc = ensure(m, m->scr[s], (size_t)N * 4)) != LOM_OK) return rc;
+    if ((rc = ensure(m, m->scr[S_SCAN], (size_t)(2 * b.n_tiles + 16) * 4)) != LOM_OK) return rc;
+    if ((rc = ensure(m, m->scr[S_HIST], (size_t)b.n_parts * b.n_blk * 4)) != LOM_OK) return rc;
+    return ensure(m, m->scr[S_PART], (size_t)(2 * b.n_parts + 1) * 4);
+}
+
+// batches above kOnePassMax points (see the kernels): everything is enqueued, nothing waits; the verdict -- range error,
+// or a partition beyond k_bi_group's LDS, which sends the call to the four-kernel path -- is read with the call's status
+static int add_points_bulk(lom_map *m, const char *d_xyz, const char *d_nrm, uint32_t N, size_t stride, uint64_t worst,
+                           bool validated_on_host, bool sync_status, bool allow_shrink)
+{
+    int rc;
+    const BulkShape b = bulk_shape(N, m->cap);
+    if ((rc = bulk_scratch(m, N, b)) != LOM_OK) return rc;
+    if (worst > m->slab_cap && (rc = ensure_slabs(m, worst + worst / 2)) != LOM_OK) return rc;
+    uint32_t *pt_slot = (uint32_t *)m->scr[S_PT_SLOT].p, *flag = (uint32_t *)m->scr[S_FLAG].p;
+    uint32_t *scan_local = (uint32_t *)m->scr[S_RANK].p, *part_slot = (uint32_t *)m->scr[S_PT_POS].p;
+    uint32_t *part_idx = (uint32_t *)m->scr[S_ITEMS].p, *ent_idx = (uint32_t *)m->scr[S_PT_OFF].p;
+    uint32_t *ent_w = (uint32_t *)m->scr[S_PT_M].p, *ent_row = (uint32_t *)m->scr[S_ENT_ROW].p;
+    uint32_t *tile_sums = (uint32_t *)m->scr[S_SCAN].p, *tile_prefix = tile_sums + b.n_tiles;
+    uint32_t *hist = (uint32_t *)m->scr[S_HIST].p;
+    uint32_t *part_total = (uint32_t *)m->scr[S_PART].p, *part_start = part_total + b.n_parts;
+    uint32_t *words = d_word(m, 0);
+    const uint32_t seq = ++m->call_seq;
+    m->mutations++;
+    const MapView v = view_of(m);
+    const uint32_t part_max = m->test_bulk_part_max ? std::min<uint32_t>(m->test_bulk_part_max, kBiPartMax) : kBiPartMax;
+    const size_t lds = (size_t)b.n_parts * 4;
+    hipLaunchKernelGGL(k_bi_claim, dim3(b.n_blk), dim3(kBiThreads), lds, m->stream, m->d_table, v.mask, v.shift, d_xyz,
+                       stride, N, m->voxel_size, pt_slot, flag, hist, b.n_parts, b.part_shift, b.n_blk, b.ppt, d_nvox(m),
+                       seq, words);
+    hipLaunchKernelGGL(k_bi_colscan, dim3((b.n_parts + 3) / 4), dim3(kThreads), 0, m->stream, hist, b.n_parts, b.n_blk,
+                       part_total, part_max, seq, words);
+    hipLaunchKernelGGL(k_bi_scatter, dim3(b.n_blk), dim3(kBiThreads), lds, m->stream, N, pt_slot, hist, b.n_parts,
+                       b.part_shift, b.n_blk, b.ppt, part_total, part_start, part_slot, part_idx, seq, words);
+    hipLaunchKernelGGL(k_bi_group, dim3(b.n_parts), dim3(kThreads), 0, m->stream, m->d_table, part_start, part_slot,
+                       part_idx, m->max_points, m->d_slab_count, flag, ent_idx, ent_w, ent_row, seq, words);
+    hipLaunchKernelGGL(k_scan_tile<uint32_t>, dim3(b.n_tiles), dim3(kThreads), 0, m->stream, flag, scan_local, tile_sums, N);
+    hipLaunchKernelGGL(k_scan_tile<uint32_t>, dim3(1), dim3(kThreads), 0, m->stream, tile_sums, tile_prefix, words + 10,
+                       b.n_tiles);
+    hipLaunchKernelGGL(k_bi_place, dim3(blocks_for(N)), dim3(kThreads), 0, m->stream, m->d_table, N, ent_idx, ent_w, ent_row,
+                       scan_local, tile_prefix, words + 10, d_xyz, d_nrm, stride, m->K, m->d_pts, m->d_nrm, m->d_slab_key,
+                       m->d_slab_count, d_nvox(m), seq, words);
+    LOM_HIP(m, hipGetLastError());
+    // should a partition have been too large, lom_map_status() / whoever consumes the map next redoes this insert with
+    // the four-kernel path: the caller keeps the input valid until then (as for a single-pass insert)
+    m->pending_xyz = d_xyz;
+    m->pending_nrm = d_nrm;
+    m->pending_stride = stride;
+    m->pending_seq = seq;
+    m->pending_n = N;
+    m->table_clean = false;
+    m->n_vox_ub = (uint32_t)std::min<uint64_t>(worst, 0xFFFFFFFFull);
+    m->n_vox_stale = true;
+    if (sync_status && (rc = map_status(m)) != LOM_OK) return rc;
+    return allow_shrink ? shrink_after_bulk(m) : LOM_OK;
 }
 
 // sync_status: wait for the insert's verdict (LOM_ERR_RANGE when a point's index is out of range; such a
@@ -1045,6 +1445,8 @@ static int add_points_device(lom_map *m, const char *d_xyz, const char *d_nrm, s
     }
     // 2. scratch
     const bool one_pass = N <= kOnePassMax && !multi_launch;
+    if (N > kOnePassMax && N <= kBiMaxPoints && !multi_launch && !m->opt_no_bulk)
+        return add_points_bulk(m, d_xyz, d_nrm, N, stride, worst, validated_on_host, sync_status, allow_shrink);
     if ((rc = ensure(m, m->scr[S_PT_SLOT], (size_t)N * 4)) != LOM_OK) return rc;
     if ((rc = ensure(m, m->scr[S_PT_POS], (size_t)N * 4)) != LOM_OK) return rc;
     if ((rc = ensure(m, m->scr[S_PT_OFF], (size_t)N * 4)) != LOM_OK) return rc;
@@ -1112,17 +1514,7 @@ static int add_points_device(lom_map *m, const char *d_xyz, const char *d_nrm, s
     if (sync_status && (!validated_on_host || multi_launch)) {
         if ((rc = map_status(m)) != LOM_OK) return rc;
     }
-    // Table size after a bulk insert: 16..32 slots per voxel (LOM_TABLE_SLOTS_PER_VOXEL at create).  The search's probe
-    // phase pays for every collision with a dependent round trip, and a longer table costs nothing but memory: k_match on
-    // C2 / C3 / C4 with 4 slots per voxel (rounds 1-2) 7.5 / 25.1 / 43.2 us, 8: 7.5 / 24.0 / 41.1, 16: 7.2 / 23.9 / 40.7,
-    // 32: 7.2 / 23.8 / 40.6, 64: 7.2 / 23.4 / 40.8 (same box, tools/ab_match.py).
-    if (allow_shrink && N > kOnePassMax && (uint64_t)m->cap >= 16ull * std::max<uint32_t>(m->min_cap, 1u)) {
-        if ((rc = refresh_nvox(m)) != LOM_OK) return rc;
-        const uint32_t target = std::max(m->min_cap, next_pow2((uint64_t)m->table_slots_per_voxel * m->n_vox));
-        if (m->cap > target) {
-            if ((rc = rehash(m, target)) != LOM_OK) return rc;
-        }
-    }
+    if (allow_shrink && N > kOnePassMax && (rc = shrink_after_bulk(m)) != LOM_OK) return rc;
     return LOM_OK;
 }
 
@@ -1373,6 +1765,7 @@ int lom_map_create(float voxel_size, size_t max_points, size_t capacity_hint, in
     m->opt_debug_timing = getenv("LOM_DEBUG_TIMING") != nullptr;
     m->opt_no_temporal = getenv("LOM_NO_TEMPORAL") != nullptr;
     if (const char *e = getenv("LOM_COUNT_CANDIDATES")) m->opt_count = atoi(e) != 0;
+    m->opt_no_bulk = getenv("LOM_NO_BULK_INSERT") != nullptr;
     if (handle_setup(m) != LOM_OK) {
         lom_map_destroy(m);
         return LOM_ERR_HIP;
@@ -1462,6 +1855,11 @@ int lom_map_set_option(lom_map *m, int option, int64_t value)
     case LOM_OPT_DEBUG_TIMING: m->opt_debug_timing = value != 0; return LOM_OK;
     case LOM_OPT_NO_TEMPORAL_BOUND: m->opt_no_temporal = value != 0; return LOM_OK;
     case LOM_OPT_COUNT_CANDIDATES: m->opt_count = value != 0; return LOM_OK;
+    case LOM_OPT_NO_BULK_INSERT: m->opt_no_bulk = value != 0; return LOM_OK;
+    case LOM_OPT_TEST_BULK_PARTITION_MAX:
+        if (value < 0 || value > (int64_t)kBiPartMax) return LOM_ERR_ARG;
+        m->test_bulk_part_max = (uint32_t)value;
+        return LOM_OK;
     case LOM_OPT_TEST_GIVE_UP_AT_OUTER:
         if (value < -1 || value >= 35) return LOM_ERR_ARG;
         m->test_give_up_outer = (int)value;
@@ -1597,6 +1995,9 @@ int lom_profile_insert(lom_map *m, const float *d_xyz, const float *d_nrm, size_
     const uint64_t worst = (uint64_t)m->n_vox + n;
     if ((uint64_t)m->cap < 2 * worst && (rc = rehash(m, next_pow2(4 * worst))) != LOM_OK) return rc;
     if (worst > m->slab_cap && (rc = ensure_slabs(m, worst + worst / 2)) != LOM_OK) return rc;
+    if (n > kOnePassMax && n <= kBiMaxPoints && !m->opt_no_bulk &&
+        (rc = bulk_scratch(m, (uint32_t)n, bulk_shape((uint32_t)n, m->cap))) != LOM_OK)
+        return rc;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     LOM_HIP(m, hipEventCreate(&e0));
     LOM_HIP(m, hipEventCreate(&e1));

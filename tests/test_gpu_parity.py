@@ -899,6 +899,97 @@ def test_deferred_insert_verdict(lom):
     assert tuple(xyz[-1]) == (np.float32(5.1), np.float32(0.1), np.float32(0.1))
 
 
+# ---- the partitioned bulk insert (batches above 65,536 points) ------------------------------------------------------
+
+def _bulk_cloud(rng, n, n_centers, spread, lo=-20, hi=20):
+    centers = rng.uniform(lo, hi, (n_centers, 3))
+    pts = (centers[rng.integers(0, n_centers, n)] + rng.normal(0, spread, (n, 3))).astype(np.float32)
+    return pts, scenes._unit(rng.standard_normal(pts.shape)).astype(np.float32)
+
+
+@pytest.mark.parametrize("mode", ["bulk", "four_kernel", "sent_back"])
+def test_bulk_insert_paths_give_the_same_map(lom, oracle, mode):
+    """Batches above 65,536 points go through the partition pass (k_bi_*), the four-kernel path (LOM_OPT_NO_BULK_INSERT),
+    or -- a partition beyond the workgroup's LDS, forced here by LOM_OPT_TEST_BULK_PARTITION_MAX -- start on the first and
+    are redone by the second.  Bytewise the oracle's map every way: a first batch (every voxel new, caps cutting buckets),
+    a second one over it (voxels that exist, with and without room), one without normals, interleaved 48-byte records."""
+    rng = np.random.default_rng(31)
+    for voxel, K, n, nc, spread in ((0.5, 20, 150_000, 3000, 0.8), (0.25, 3, 70_000, 500, 0.5), (1.0, 7, 300_001, 40, 3.0)):
+        g, og = _both(lom, oracle, voxel, K)
+        if mode == "four_kernel":
+            g.setOption(lom.capi.OPT_NO_BULK_INSERT, 1)
+        if mode == "sent_back":
+            g.setOption(lom.capi.OPT_TEST_BULK_PARTITION_MAX, 16)
+        redos = 0
+        pts, nrm = _bulk_cloud(rng, n, nc, spread)
+        g.addCloud(pts, nrm)
+        og.addCloud(pts, nrm)
+        redos += mode == "sent_back"
+        assert g.size() == og.size() and g.debugCounter() == redos
+        _assert_same_map(g, og)
+        more, mnrm = _bulk_cloud(rng, 80_000, nc, spread * 1.5)
+        g.addCloud(more, mnrm)
+        og.addCloud(more, mnrm)
+        redos += mode == "sent_back"
+        _assert_same_map(g, og)
+        assert g.debugCounter() == redos
+        bare = np.ascontiguousarray(pts[::2] + np.float32(0.05))
+        g.addCloudWithoutNormals(bare)
+        og.addCloudWithoutNormals(bare)
+        _assert_same_map(g, og)
+        rec = np.zeros((70_001, 12), np.float32)                       # x y z pad nx ny nz pad ... as one 48-byte record
+        rec[:, 0:3], rec[:, 4:7] = _bulk_cloud(rng, len(rec), nc, spread)
+        g.addCloudInterleaved(rec, 48, 16)
+        og.addCloud(np.ascontiguousarray(rec[:, 0:3]), np.ascontiguousarray(rec[:, 4:7]))
+        _assert_same_map(g, og)
+        q = pts[::50]
+        _assert_same_pairs(g.findMatchingPairs(q, lom.Pose3D(), 0.3), og.findMatchingPairs(q, oracle.Pose3D(), 0.3))
+
+
+def test_bulk_insert_crowded_voxels_are_sent_back(lom, oracle):
+    """100,000 points in a handful of voxels: every partition that holds one is far beyond the 1,024 points a workgroup
+    groups in LDS, the bulk insert writes nothing and the four-kernel path redoes it (first K in input order)."""
+    rng = np.random.default_rng(32)
+    g, og = _both(lom, oracle, 0.5, 20)
+    pts = (rng.integers(0, 2, (100_000, 3)) * 0.5 + rng.random((100_000, 3)) * 0.49).astype(np.float32)
+    nrm = scenes._unit(rng.standard_normal(pts.shape)).astype(np.float32)
+    g.addCloud(pts, nrm)
+    og.addCloud(pts, nrm)
+    assert g.size() == og.size() == 8 and g.debugCounter() == 1
+    _assert_same_map(g, og)
+    wide, wnrm = _bulk_cloud(rng, 90_000, 2000, 1.0)                   # and an ordinary bulk batch over it
+    g.addCloud(wide, wnrm)
+    og.addCloud(wide, wnrm)
+    assert g.debugCounter() == 1
+    _assert_same_map(g, og)
+
+
+def test_bulk_insert_range_error_inserts_nothing(lom, oracle):
+    """voxel_grid.h casts unchecked; here a coordinate beyond the index range rejects the whole call (LOM_ERR_RANGE) --
+    for a bulk batch too: the map is what it was, and the same batch without the bad point goes in afterwards."""
+    import torch
+
+    L = lom.capi.lib()
+    rng = np.random.default_rng(33)
+    g, og = _both(lom, oracle, 0.5, 20)
+    first, fn = _bulk_cloud(rng, 30_000, 300, 1.0)
+    g.addCloud(first, fn)
+    og.addCloud(first, fn)
+    pts, nrm = _bulk_cloud(rng, 100_000, 1000, 1.0)
+    bad = pts.copy()
+    bad[77_777, 1] = np.float32(3e9)
+    d_bad = torch.from_numpy(bad).to("cuda:0")
+    d_nrm = torch.from_numpy(nrm).to("cuda:0")
+    torch.cuda.synchronize()
+    assert L.lom_map_add_points_device(g.handle, d_bad.data_ptr(), d_nrm.data_ptr(), len(bad), 12) == lom.capi.ERR_RANGE
+    _assert_same_map(g, og)
+    d_ok = torch.from_numpy(pts).to("cuda:0")
+    torch.cuda.synchronize()
+    lom.capi.check(L.lom_map_add_points_device(g.handle, d_ok.data_ptr(), d_nrm.data_ptr(), len(pts), 12), g.handle)
+    og.addCloud(pts, nrm)
+    _assert_same_map(g, og)
+
+
 # ---- an in-kernel scan that gives up: the call changes nothing and is redone with the multi-launch scan -------
 
 @pytest.mark.parametrize("fail_from", [1, 3])
