@@ -246,6 +246,7 @@ struct lom_map {
     bool opt_no_temporal = false;   // LOM_OPT_NO_TEMPORAL_BOUND / LOM_NO_TEMPORAL=1: every search at the plain max_dist bound
     unsigned long long patience_ticks = 5000000ull;  // bounded in-kernel waits: 50 ms of s_memrealtime (100 MHz)
     bool opt_no_bulk = false;       // LOM_OPT_NO_BULK_INSERT / LOM_NO_BULK_INSERT=1: batches above 65,536 points take the four-kernel path
+    uint32_t bulk_ppt = 0;          // LOM_BULK_PPT at create: points per thread of k_bi_claim / k_bi_scatter (0: by batch size)
     uint32_t test_bulk_part_max = 0;  // LOM_OPT_TEST_BULK_PARTITION_MAX: points a partition of the bulk insert may hold (0: the LDS limit)
     int test_grid_give_up = -1;     // LOM_OPT_TEST_GRID_GIVE_UP: first workgroup that gives up in the next in-kernel scan
     int test_give_up_outer = -1;    // LOM_OPT_TEST_GIVE_UP_AT_OUTER: k_lm of that outer iteration of the next align gives up

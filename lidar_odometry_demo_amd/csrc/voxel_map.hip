@@ -621,9 +621,10 @@ __global__ __launch_bounds__(kThreads) void k_ins_place2(Slot *table, uint32_t n
 // index) and write every stored point as a lone 12-byte transaction.  A bulk batch -- the map build -- goes
 // through a partition pass instead, so that all points of one voxel meet in ONE workgroup and everything per
 // voxel happens in LDS:
-//   1. k_bi_claim    slot per point (look, CAS only where the slot is still empty); LDS histogram of the
-//                    points over the partitions (partition = a contiguous segment of the table: the top bits
-//                    of the slot), one column of the [partition][block] count matrix per workgroup
+//   1. k_bi_claim    slot per point (look, CAS only where the slot is still empty; the looks of a thread's
+//                    points are in flight together); LDS histogram of the points over the partitions
+//                    (partition = a contiguous segment of the table: the top bits of the slot), one column of
+//                    the [partition][block] count matrix per workgroup
 //   2. k_bi_colscan  one wave per partition: prefix of its counts over the blocks (blocks are in input order,
 //                    so a partition's list is ordered by block); partition sizes; verdict (a partition above
 //                    the LDS budget of step 4 sends the whole call to the four-kernel path: nothing written)
@@ -631,50 +632,115 @@ __global__ __launch_bounds__(kThreads) void k_ins_place2(Slot *table, uint32_t n
 //   4. k_bi_group    one workgroup per partition, all in LDS: points -> voxels (hash on the slot), bucket
 //                    sizes, room left in each voxel (voxel_grid.h:86), rank of every point inside its voxel
 //                    by input index (= insertion order), the first `room` survive; the survivors of a voxel
-//                    are written out side by side, in rank order; a NEW voxel's first point raises a flag at
-//                    its input index
-//   5. scan of the flags (two launches): creation order = order of first appearance (voxel_grid.h:83-87)
+//                    are written out side by side, in rank order; a NEW voxel's first point sets its bit in a
+//                    bitmap over the input indices
+//   5. k_bi_flagscan one workgroup: prefix of the bitmap's population counts -- creation order = order of
+//                    first appearance (voxel_grid.h:83-87)
 //   6. k_bi_place    one thread per survivor: consecutive threads write consecutive rows of a slab --
 //                    coalesced slab writes, nothing but the stored rows is written
 // No kernel waits for another workgroup, so there is no give-up path; a range error (step 1) or an oversized
 // partition (step 2) is known before anything is written except claimed keys, which the table tolerates
 // (slab == kNoSlab, as after a range error of the four-kernel path).
-constexpr int kBiThreads = 1024;         // k_bi_claim, k_bi_scatter
-constexpr uint32_t kBiPartMax = 1024;    // points per partition k_bi_group holds in LDS
-constexpr uint32_t kBiEntries = 2 * kBiPartMax;
-constexpr uint32_t kBiMaxParts = 8192;   // LDS histogram of k_bi_claim: 32 KB
+constexpr int kBiThreads = 1024;         // k_bi_claim, k_bi_scatter, k_bi_flagscan
+constexpr uint32_t kBiPartMax = 1024;    // points per partition k_bi_group can hold in LDS (its larger shape)
+constexpr uint32_t kBiMaxParts = 16384;  // LDS histogram of k_bi_claim: 64 KB
 constexpr uint32_t kBiMaxPoints = 4u << 20;
 constexpr uint32_t kBiDropped = 0xFFFFFFFFu;
 constexpr uint32_t kBiNewBit = 0x80000000u;
 
+// what k_bi_claim learns about a point's voxel on the way: the points it holds (kBiNewBit: the map does not have the
+// voxel yet -- no slab; voxel_grid.h:83 it == end()).  Nothing in this kernel changes counts or slabs, so a look taken
+// at any time during it holds for the whole call.
+template <int kPpt>
 __global__ __launch_bounds__(kBiThreads) void k_bi_claim(Slot *table, uint32_t mask, uint32_t shift, const char *xyz,
-                                                         size_t stride, uint32_t n, float vs, uint32_t *pt_slot,
-                                                         uint32_t *flag, uint32_t *hist, uint32_t n_parts,
-                                                         uint32_t part_shift, uint32_t n_blk, uint32_t ppt,
-                                                         const uint32_t *n_vox_dev, uint32_t seq, uint32_t *words)
+                                                         size_t stride, uint32_t n, float vs, uint2 *pt_info,
+                                                         uint32_t *flag_bits, uint32_t *hist, uint32_t n_parts,
+                                                         uint32_t part_shift, const uint32_t *n_vox_dev, uint32_t seq,
+                                                         uint32_t *words)
 {
     extern __shared__ uint32_t s_hist[];
     for (uint32_t b = threadIdx.x; b < n_parts; b += kBiThreads) s_hist[b] = 0u;
     if (blockIdx.x == 0 && threadIdx.x == 0) words[9] = *n_vox_dev;  // voxel count before this call (k_bi_place)
-    __syncthreads();
-    const uint32_t first = blockIdx.x * ppt * kBiThreads;
-    for (uint32_t k = 0; k < ppt; k++) {
-        const uint32_t i = first + k * kBiThreads + threadIdx.x;
-        if (i >= n) break;
-        const float *p = point_at(xyz, i, stride);
-        int ix = 0, iy = 0, iz = 0;
-        flag[i] = 0u;
-        if (!voxel_index(p[0], vs, ix) || !voxel_index(p[1], vs, iy) || !voxel_index(p[2], vs, iz)) {
-            pt_slot[i] = kInvalidSlot;
-            __hip_atomic_store(words + 5, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // LOM_ERR_RANGE for this call
-            continue;
-        }
-        const uint32_t h = claim_slot(table, mask, shift, pack_key(ix, iy, iz));
-        pt_slot[i] = h;
-        atomicAdd(&s_hist[h >> part_shift], 1u);
+    const uint32_t first = blockIdx.x * kPpt * kBiThreads;
+    if (threadIdx.x < kPpt * kBiThreads / 32) {  // this block's words of the bitmap of first appearances
+        const uint32_t w = first / 32 + threadIdx.x;
+        if (w < (n + 31) / 32) flag_bits[w] = 0u;
     }
     __syncthreads();
-    for (uint32_t b = threadIdx.x; b < n_parts; b += kBiThreads) hist[(size_t)b * n_blk + blockIdx.x] = s_hist[b];
+    // the chain per point is point -> slot look -> (CAS) -> (next slot): all looks of this thread's points are issued
+    // before the first is consumed (the table is far larger than the caches while it is being built).  A look is the
+    // whole 16-byte slot: key, count and slab together.
+    unsigned long long key[kPpt];
+    typedef uint32_t SlotWords __attribute__((ext_vector_type(4)));
+    SlotWords seen[kPpt];
+    uint32_t h[kPpt];
+    bool ok[kPpt];
+#pragma unroll
+    for (int k = 0; k < kPpt; k++) {
+        const uint32_t i = first + k * kBiThreads + threadIdx.x;
+        ok[k] = false;
+        key[k] = 0;
+        h[k] = 0;
+        if (i < n) {
+            const Point3 p = load3(point_at(xyz, i, stride));
+            int ix = 0, iy = 0, iz = 0;
+            if (voxel_index(p.x, vs, ix) && voxel_index(p.y, vs, iy) && voxel_index(p.z, vs, iz)) {
+                ok[k] = true;
+                key[k] = pack_key(ix, iy, iz);
+                h[k] = hash_key(key[k], shift) & mask;
+            } else {
+                pt_info[i] = make_uint2(kInvalidSlot, 0u);
+                __hip_atomic_store(words + 5, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // LOM_ERR_RANGE for this call
+            }
+        }
+    }
+    const SlotWords *slots = reinterpret_cast<const SlotWords *>(table);
+#pragma unroll
+    for (int k = 0; k < kPpt; k++) seen[k] = ok[k] ? slots[h[k]] : SlotWords{0u, 0u, 0u, 0u};
+    // first round of the claims, all of this thread's compare-and-swaps in flight together: a slot that looked empty
+    unsigned long long prev[kPpt];
+#pragma unroll
+    for (int k = 0; k < kPpt; k++) {
+        const unsigned long long sk = ((unsigned long long)seen[k].y << 32) | seen[k].x;
+        prev[k] = (ok[k] && sk == kEmptyKey) ? atomicCAS(&table[h[k]].key, kEmptyKey, key[k]) : sk;
+    }
+#pragma unroll
+    for (int k = 0; k < kPpt; k++) {
+        if (!ok[k]) continue;
+        uint32_t s = h[k];
+        SlotWords sn = seen[k];
+        const unsigned long long sk0 = ((unsigned long long)sn.y << 32) | sn.x;
+        uint32_t oldw;
+        if (sk0 == kEmptyKey && (prev[k] == kEmptyKey || prev[k] == key[k])) {
+            oldw = kBiNewBit;  // this call's own claim, now or a moment ago: no voxel yet
+        } else {
+            if (sk0 == kEmptyKey) {  // somebody else's key arrived in between: on to the next slot
+                s = (s + 1) & mask;
+                sn = slots[s];
+            }
+            for (;;) {  // claim_slot from here on
+                const unsigned long long sk = ((unsigned long long)sn.y << 32) | sn.x;
+                if (sk == key[k]) {
+                    oldw = sn.w == kNoSlab ? kBiNewBit : sn.z;
+                    break;
+                }
+                if (sk == kEmptyKey) {
+                    const unsigned long long pv = atomicCAS(&table[s].key, kEmptyKey, key[k]);
+                    if (pv == kEmptyKey || pv == key[k]) {
+                        oldw = kBiNewBit;
+                        break;
+                    }
+                }
+                s = (s + 1) & mask;
+                sn = slots[s];
+            }
+        }
+        pt_info[first + k * kBiThreads + threadIdx.x] = make_uint2(s, oldw);
+        atomicAdd(&s_hist[s >> part_shift], 1u);
+    }
+    __syncthreads();
+    uint32_t *row = hist + (size_t)blockIdx.x * n_parts;  // [block][partition]
+    for (uint32_t b = threadIdx.x; b < n_parts; b += kBiThreads) row[b] = s_hist[b];
 }
 
 __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v)
@@ -688,40 +754,66 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v)
     return v;
 }
 
-__global__ __launch_bounds__(kThreads) void k_bi_colscan(uint32_t *hist, uint32_t n_parts, uint32_t n_blk,
-                                                         uint32_t *part_total, uint32_t part_max, uint32_t seq,
-                                                         uint32_t *words)
+// 64 partitions per workgroup (one 256-byte piece of every block's row), the blocks in sixteen slices, one per wave:
+// column sums of the slices, then the running prefixes written over the counts
+__global__ __launch_bounds__(kBiThreads) void k_bi_colscan(uint32_t *hist, uint32_t n_parts, uint32_t n_blk,
+                                                           uint32_t *part_total, uint32_t part_max, uint32_t seq,
+                                                           uint32_t *words)
 {
+    constexpr uint32_t kSlices = kBiThreads / 64;
+    __shared__ uint32_t s_slice[kSlices][64];
     if (words[5] == seq) return;
-    const uint32_t part = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
-    const uint32_t lane = threadIdx.x & 63;
-    if (part >= n_parts) return;
-    uint32_t *row = hist + (size_t)part * n_blk;
-    uint32_t carry = 0;
-    for (uint32_t c = 0; c < n_blk; c += 64) {
-        const uint32_t b = c + lane;
-        const uint32_t v = b < n_blk ? row[b] : 0u;
-        const uint32_t inc = wave_inclusive_scan(v);
-        if (b < n_blk) row[b] = carry + inc - v;
-        carry += __shfl(inc, 63, 64);
+    const uint32_t lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const uint32_t part = blockIdx.x * 64 + lane;
+    const bool live = part < n_parts;
+    const uint32_t per = (n_blk + kSlices - 1) / kSlices;
+    const uint32_t b0 = min(slice * per, n_blk), b1 = min(b0 + per, n_blk);
+    uint32_t *col = hist + part;
+    uint32_t sum = 0;
+    if (live) {
+#pragma unroll 8
+        for (uint32_t b = b0; b < b1; b++) sum += col[(size_t)b * n_parts];
     }
-    if (lane == 0) {
-        part_total[part] = carry;
-        if (carry > part_max) __hip_atomic_store(words + 8, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_slice[slice][lane] = sum;
+    __syncthreads();
+    uint32_t run = 0, total = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < kSlices; k++) {
+        if (k < slice) run += s_slice[k][lane];
+        total += s_slice[k][lane];
+    }
+    if (live) {
+#pragma unroll 8
+        for (uint32_t b = b0; b < b1; b++) {
+            const uint32_t v = col[(size_t)b * n_parts];
+            col[(size_t)b * n_parts] = run;
+            run += v;
+        }
+    }
+    if (slice == 0 && live) {
+        part_total[part] = total;
+        if (total > part_max) __hip_atomic_store(words + 8, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
-__global__ __launch_bounds__(kBiThreads) void k_bi_scatter(uint32_t n, const uint32_t *__restrict__ pt_slot,
+template <int kPpt>
+__global__ __launch_bounds__(kBiThreads) void k_bi_scatter(uint32_t n, const uint2 *__restrict__ pt_info,
                                                            const uint32_t *__restrict__ hist, uint32_t n_parts,
-                                                           uint32_t part_shift, uint32_t n_blk, uint32_t ppt,
-                                                           const uint32_t *__restrict__ part_total, uint32_t *part_start,
-                                                           uint32_t *part_slot, uint32_t *part_idx, uint32_t seq,
+                                                           uint32_t part_shift, const uint32_t *__restrict__ part_total,
+                                                           uint32_t *part_start, uint4 *part_rec, uint32_t seq,
                                                            const uint32_t *words)
 {
     extern __shared__ uint32_t s_cur[];  // [n_parts] write cursor of this block in every partition's list
     __shared__ uint32_t s_w[kBiThreads / 64];
     if (words[5] == seq || words[8] == seq) return;
-    // start of every partition's list = exclusive scan of the partition sizes (every block redoes it: <= 8192 values)
+    const uint32_t first = blockIdx.x * kPpt * kBiThreads;
+    uint2 info[kPpt];
+#pragma unroll
+    for (int k = 0; k < kPpt; k++) {
+        const uint32_t i = first + k * kBiThreads + threadIdx.x;
+        info[k] = i < n ? pt_info[i] : make_uint2(0u, 0u);
+    }
+    // start of every partition's list = exclusive scan of the partition sizes (every block redoes it: <= 16384 values)
     const uint32_t per = (n_parts + kBiThreads - 1) / kBiThreads;
     const uint32_t b0 = threadIdx.x * per;
     uint32_t sum = 0;
@@ -732,48 +824,56 @@ __global__ __launch_bounds__(kBiThreads) void k_bi_scatter(uint32_t n, const uin
     __syncthreads();
     uint32_t run = inc - sum;
     for (int w = 0; w < wave; w++) run += s_w[w];
+    const uint32_t *row = hist + (size_t)blockIdx.x * n_parts;  // this block's offsets inside the partitions' lists
     for (uint32_t b = b0; b < b0 + per && b < n_parts; b++) {
-        s_cur[b] = run + hist[(size_t)b * n_blk + blockIdx.x];
+        s_cur[b] = run + row[b];
         if (blockIdx.x == 0) part_start[b] = run;
         run += part_total[b];
     }
     if (blockIdx.x == 0 && threadIdx.x == kBiThreads - 1) part_start[n_parts] = run;
     __syncthreads();
-    const uint32_t first = blockIdx.x * ppt * kBiThreads;
-    for (uint32_t k = 0; k < ppt; k++) {
+#pragma unroll
+    for (int k = 0; k < kPpt; k++) {
         const uint32_t i = first + k * kBiThreads + threadIdx.x;
         if (i >= n) break;
-        const uint32_t h = pt_slot[i];
-        const uint32_t pos = atomicAdd(&s_cur[h >> part_shift], 1u);
-        part_slot[pos] = h;
-        part_idx[pos] = i;
+        const uint32_t pos = atomicAdd(&s_cur[info[k].x >> part_shift], 1u);
+        part_rec[pos] = make_uint4(info[k].x, i, info[k].y, 0u);  // slot, input index, what the voxel held
     }
 }
 
 // One workgroup per partition.  What it leaves behind, at the partition's positions of three N-sized arrays:
 // the survivors (points that are stored) first, grouped by voxel and in rank order inside a voxel --
-// ent_idx = input index, ent_w = slot | kBiNewBit for a voxel this call creates, ent_row = row inside the slab --
-// and ent_row = kBiDropped for the rest.  table[h].count (and slab_count of voxels that exist) are final here;
-// slab ids of new voxels follow from the scan of the flags (k_bi_place).
+// ent_idx = input index, ent_row = row inside the slab, ent_w = the slot of a voxel that exists (| kBiFirstBit for the
+// first survivor, which settles the slab's count), or for a voxel this call creates kBiNewBit | its slot (first
+// survivor) / kBiNewBit | the input index of its first point (the others) -- and ent_row = kBiDropped for the rest.
+// table[h].count is final here; slab ids of new voxels follow from the bitmap of first appearances (k_bi_flagscan,
+// k_bi_place).  Nothing is read but the partition's own records: what the voxels held came along from k_bi_claim.
+constexpr uint32_t kBiFirstBit = 0x40000000u;
+template <int kPartMax>  // points the partition may hold: 512 (20 KB of LDS, eight workgroups per CU) or 1024
 __global__ __launch_bounds__(kThreads) void k_bi_group(Slot *table, const uint32_t *__restrict__ part_start,
-                                                       const uint32_t *__restrict__ part_slot,
-                                                       const uint32_t *__restrict__ part_idx, uint32_t cap_points,
-                                                       uint32_t *slab_count, uint32_t *flag, uint32_t *ent_idx,
-                                                       uint32_t *ent_w, uint32_t *ent_row, uint32_t seq,
-                                                       const uint32_t *words)
+                                                       const uint4 *__restrict__ part_rec, uint32_t cap_points,
+                                                       uint32_t *flag_bits, uint32_t *ent_idx, uint32_t *ent_w,
+                                                       uint32_t *ent_row, uint32_t seq, const uint32_t *words)
 {
-    __shared__ uint32_t s_key[kBiEntries];   // slot of the voxel (0xFFFFFFFF: free)
-    __shared__ uint32_t s_cnt[kBiEntries];   // points of this call in the voxel
-    __shared__ uint32_t s_old[kBiEntries];   // stored points before this call | kBiNewBit
-    __shared__ uint16_t s_start[kBiEntries]; // first position of the voxel's bucket in s_grp
-    __shared__ uint16_t s_sst[kBiEntries];   // first position of the voxel's survivors in the output
-    __shared__ uint32_t s_idx[kBiPartMax];
-    __shared__ uint32_t s_grp[kBiPartMax];
+    constexpr uint32_t kEntries = 2 * kPartMax;
+    __shared__ uint32_t s_key[kEntries];   // slot of the voxel (0xFFFFFFFF: free)
+    __shared__ uint32_t s_cnt[kEntries];   // points of this call in the voxel
+    __shared__ uint32_t s_old[kEntries];   // stored points before this call | kBiNewBit
+    __shared__ uint16_t s_start[kEntries]; // first position of the voxel's bucket in s_grp
+    __shared__ uint16_t s_sst[kEntries];   // first position of the voxel's survivors in the output
+    __shared__ uint32_t s_grp[kPartMax];
     __shared__ uint32_t s_w[kThreads / 64];
     if (words[5] == seq || words[8] == seq) return;
     const uint32_t base = part_start[blockIdx.x];
     const uint32_t P = part_start[blockIdx.x + 1] - base;
     if (P == 0) return;
+    constexpr int kItems = kPartMax / kThreads;
+    uint4 pr[kItems];
+#pragma unroll
+    for (int k = 0; k < kItems; k++) {  // the partition's records, on their way while the tables are cleared
+        const uint32_t j = k * kThreads + threadIdx.x;
+        pr[k] = j < P ? part_rec[base + j] : make_uint4(0u, 0u, 0u, 0u);
+    }
     uint32_t E = 256;  // entries: a power of two >= 2 P
     while (E < 2 * P) E <<= 1;
     const uint32_t ebits = (uint32_t)__builtin_ctz(E);
@@ -782,7 +882,6 @@ __global__ __launch_bounds__(kThreads) void k_bi_group(Slot *table, const uint32
         s_cnt[e] = 0u;
     }
     __syncthreads();
-    constexpr int kItems = kBiPartMax / kThreads;
     uint32_t my_e[kItems], my_a[kItems];
 #pragma unroll
     for (int k = 0; k < kItems; k++) {
@@ -790,8 +889,7 @@ __global__ __launch_bounds__(kThreads) void k_bi_group(Slot *table, const uint32
         my_e[k] = 0;
         my_a[k] = 0;
         if (j < P) {
-            const uint32_t h = part_slot[base + j];
-            s_idx[j] = part_idx[base + j];
+            const uint32_t h = pr[k].x;
             uint32_t e = (h * 0x9E3779B1u) >> (32 - ebits);
             for (;;) {
                 const uint32_t prev = atomicCAS(&s_key[e], 0xFFFFFFFFu, h);
@@ -800,27 +898,22 @@ __global__ __launch_bounds__(kThreads) void k_bi_group(Slot *table, const uint32
             }
             my_e[k] = e;
             my_a[k] = atomicAdd(&s_cnt[e], 1u);
+            if (my_a[k] == 0) s_old[e] = pr[k].z;  // the same for all points of the voxel
         }
     }
     __syncthreads();
-    // per voxel: what the table holds, how much room is left (voxel_grid.h:86: while size() < max_points_), the new count.
+    // per voxel: how much room is left (voxel_grid.h:86: while size() < max_points_), the new count.
     // Thread t takes the entries [t * ept, (t + 1) * ept), so that the scan below runs over entries in order.
     const uint32_t ept = E / kThreads;
     uint32_t packed = 0;  // bucket sizes << 16 | survivors of this thread's entries
     for (uint32_t e = threadIdx.x * ept; e < (threadIdx.x + 1) * ept; e++) {
         const uint32_t h = s_key[e];
         if (h == 0xFFFFFFFFu) continue;
-        const Slot s = table[h];
-        const bool is_new = s.slab == kNoSlab;  // voxel_grid.h:83 it == end()
-        const uint32_t old = is_new ? 0u : s.count;
+        const uint32_t old = s_old[e] & ~kBiNewBit;
         const uint32_t room = cap_points > old ? cap_points - old : 0u;
         const uint32_t c = s_cnt[e];
         const uint32_t st = c < room ? c : room;
-        s_old[e] = old | (is_new ? kBiNewBit : 0u);
-        if (st) {
-            table[h].count = old + st;
-            if (!is_new) slab_count[s.slab] = old + st;
-        }
+        if (st) table[h].count = old + st;
         packed += (c << 16) | st;
     }
     const uint32_t inc = wave_inclusive_scan(packed);
@@ -846,7 +939,7 @@ __global__ __launch_bounds__(kThreads) void k_bi_group(Slot *table, const uint32
 #pragma unroll
     for (int k = 0; k < kItems; k++) {
         const uint32_t j = k * kThreads + threadIdx.x;
-        if (j < P) s_grp[s_start[my_e[k]] + my_a[k]] = s_idx[j];
+        if (j < P) s_grp[s_start[my_e[k]] + my_a[k]] = pr[k].y;
     }
     __syncthreads();
     const uint32_t survivors = total & 0xFFFFu;
@@ -855,31 +948,96 @@ __global__ __launch_bounds__(kThreads) void k_bi_group(Slot *table, const uint32
         const uint32_t j = k * kThreads + threadIdx.x;
         if (j >= P) continue;
         const uint32_t e = my_e[k];
-        const uint32_t i = s_idx[j];
-        const uint32_t ow = s_old[e];
+        const uint32_t i = pr[k].y;
+        const uint32_t ow = pr[k].z;
         const uint32_t old = ow & ~kBiNewBit;
         const uint32_t room = cap_points > old ? cap_points - old : 0u;
         const uint32_t *g = s_grp + s_start[e];
         const uint32_t m = s_cnt[e];
-        uint32_t rank = 0;  // voxel_grid.h:86,89-90: append in input order while size() < max_points_
-        for (uint32_t q = 0; q < m && rank < room; q++) rank += g[q] < i;
+        uint32_t rank = 0, head = i;  // voxel_grid.h:86,89-90: append in input order while size() < max_points_
+        for (uint32_t q = 0; q < m && rank < room; q++) {
+            const uint32_t o = g[q];
+            rank += o < i;
+            head = o < head ? o : head;
+        }
         if (rank < room) {
             const uint32_t o = base + s_sst[e] + rank;
             ent_idx[o] = i;
-            ent_w[o] = s_key[e] | (ow & kBiNewBit);
             ent_row[o] = old + rank;
-            if (rank == 0 && (ow & kBiNewBit)) flag[i] = 1u;  // first appearance of a voxel the map does not have yet
+            if (ow & kBiNewBit) {
+                // (a survivor has seen its whole bucket -- the loop ends early only once `room` smaller indices were
+                // counted, and then the point is no survivor -- so `head` is the bucket's minimum)
+                ent_w[o] = kBiNewBit | (rank == 0 ? pr[k].x : head);
+                if (rank == 0) atomicOr(&flag_bits[i >> 5], 1u << (i & 31));  // first appearance of a voxel the map does not have yet
+            } else {
+                ent_w[o] = pr[k].x | (rank == 0 ? kBiFirstBit : 0u);
+            }
         }
     }
     for (uint32_t j = survivors + threadIdx.x; j < P; j += kThreads) ent_row[base + j] = kBiDropped;
 }
 
-// the first level of the flags' scan: k_scan_tile leaves the exclusive scan inside tiles of kScanTile and the
-// tiles' totals; the second launch scans the totals; k_bi_place adds the two (no k_scan_add pass over N words)
+// Prefix of the population counts of the bitmap's words, one launch: a workgroup per tile of 1024 words (32,768 points)
+// leaves the prefix inside its tile and the tile's total; the workgroup that finishes LAST (a counter tells it; nobody
+// waits for anybody) turns the <= 128 totals into the tiles' own prefix.
+// rank of a new voxel = tile_prefix[i / 32768] + word_prefix[i / 32] + the bits below bit i % 32 of its word
+constexpr uint32_t kBiTileWords = 1024;
+__global__ __launch_bounds__(kThreads) void k_bi_flagscan(const uint32_t *__restrict__ flag_bits, uint32_t n_words,
+                                                          uint32_t *word_prefix, uint32_t *tile_total,
+                                                          uint32_t *tile_prefix, uint32_t *done, uint32_t *total_out,
+                                                          uint32_t seq, const uint32_t *words)
+{
+    __shared__ uint32_t s_w[kThreads / 64];
+    __shared__ uint32_t s_last;
+    if (words[5] == seq || words[8] == seq) return;
+    const uint32_t w0 = blockIdx.x * kBiTileWords + threadIdx.x * 4;
+    uint32_t c[4], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        c[k] = w0 + k < n_words ? (uint32_t)__popc(flag_bits[w0 + k]) : 0u;
+        sum += c[k];
+    }
+    const uint32_t inc = wave_inclusive_scan(sum);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 63) s_w[wave] = inc;
+    __syncthreads();
+    uint32_t run = inc - sum, total = 0;
+#pragma unroll
+    for (int w = 0; w < kThreads / 64; w++) {
+        if (w < wave) run += s_w[w];
+        total += s_w[w];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if (w0 + k < n_words) word_prefix[w0 + k] = run;
+        run += c[k];
+    }
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(tile_total + blockIdx.x, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t before = __hip_atomic_fetch_add(done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = before == gridDim.x - 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!s_last || threadIdx.x >= 64) return;
+    uint32_t carry = 0;
+    for (uint32_t t0 = 0; t0 < gridDim.x; t0 += 64) {  // one wave, 64 tiles at a time
+        const uint32_t t = t0 + threadIdx.x;
+        const uint32_t v = t < gridDim.x ? __hip_atomic_load(tile_total + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        const uint32_t in2 = wave_inclusive_scan(v);
+        if (t < gridDim.x) tile_prefix[t] = carry + in2 - v;
+        carry += __shfl(in2, 63, 64);
+    }
+    if (threadIdx.x == 0) {
+        *total_out = carry;
+        __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // at rest for the next call
+    }
+}
+
 __global__ __launch_bounds__(kThreads) void k_bi_place(Slot *table, uint32_t n, const uint32_t *__restrict__ ent_idx,
                                                        const uint32_t *__restrict__ ent_w,
                                                        const uint32_t *__restrict__ ent_row,
-                                                       const uint32_t *__restrict__ scan_local,
+                                                       const uint32_t *__restrict__ flag_bits,
+                                                       const uint32_t *__restrict__ word_prefix,
                                                        const uint32_t *__restrict__ tile_prefix,
                                                        const uint32_t *__restrict__ new_total, const char *xyz,
                                                        const char *nrm, size_t stride, uint32_t K, float *pts,
@@ -894,25 +1052,28 @@ __global__ __launch_bounds__(kThreads) void k_bi_place(Slot *table, uint32_t n, 
     if (row == kBiDropped) return;
     const uint32_t i = ent_idx[j];
     const uint32_t w = ent_w[j];
-    const uint32_t h = w & ~kBiNewBit;
+    const Point3 pv = load3(point_at(xyz, i, stride));
+    Point3 nv = {0.f, 0.f, 0.f};  // voxel_grid.h:103,107: no normals -> (0, 0, 0)
+    if (nrm) nv = load3(point_at(nrm, i, stride));
     uint32_t slab;
     if (w & kBiNewBit) {
-        // a new voxel's survivors sit side by side in rank order and its rows start at 0: the head is `row` to the left
-        const uint32_t head = ent_idx[j - row];
-        slab = n_vox_before + scan_local[head] + tile_prefix[head / kScanTile];  // creation order = order of first appearance
+        const uint32_t head = row == 0 ? i : (w & ~kBiNewBit);  // a new voxel's rows start at 0: row 0 is its first point
+        // creation order = order of first appearance: the new voxels' first points before this one
+        slab = n_vox_before + tile_prefix[head / (32 * kBiTileWords)] + word_prefix[head >> 5] +
+               (uint32_t)__popc(flag_bits[head >> 5] & ((1u << (head & 31)) - 1u));
         if (row == 0) {
+            const uint32_t h = w & ~kBiNewBit;
             const Slot s = table[h];
             table[h].slab = slab;
             slab_key[slab] = s.key;
             slab_count[slab] = s.count;
         }
     } else {
-        slab = table[h].slab;
+        const Slot s = table[w & ~kBiFirstBit];
+        slab = s.slab;
+        if (w & kBiFirstBit) slab_count[slab] = s.count;  // the voxel's first survivor settles the slab's count
     }
     const size_t dst = ((size_t)slab * K + row) * 3;
-    const Point3 pv = load3(point_at(xyz, i, stride));
-    Point3 nv = {0.f, 0.f, 0.f};  // voxel_grid.h:103,107: no normals -> (0, 0, 0)
-    if (nrm) nv = load3(point_at(nrm, i, stride));
     store3(pts + dst, pv);
     store3(nrm_out + dst, nv);
 }
@@ -1347,30 +1508,42 @@ static int shrink_after_bulk(lom_map *m)
 }
 
 struct BulkShape {
-    uint32_t n_parts, part_shift, ppt, n_blk, n_tiles;
+    uint32_t n_parts, part_shift, part_max, ppt, n_blk, n_words;
 };
 
-static BulkShape bulk_shape(uint32_t N, uint32_t cap)
+static BulkShape bulk_shape(uint32_t N, uint32_t cap, uint32_t ppt_override = 0)
 {
     BulkShape b;
+    // ~128 points per partition (the 512-point shape of k_bi_group: 20 KB of LDS, eight workgroups per CU) while the
+    // partitions number at most kBiMaxParts; beyond 2 M points the partitions grow and the 1024-point shape takes over
     uint32_t np = 64;
-    while (np < kBiMaxParts && (uint64_t)np * 256 < N) np <<= 1;  // ~256 points per partition (<= 512 at 4 M points)
+    while (np < kBiMaxParts && (uint64_t)np * 128 < N) np <<= 1;
     b.n_parts = std::min(np, cap);
     b.part_shift = (uint32_t)__builtin_ctz(cap) - (uint32_t)__builtin_ctz(b.n_parts);
+    b.part_max = (uint64_t)b.n_parts * 128 >= N ? 512u : kBiPartMax;
     b.ppt = N <= (1u << 20) ? 4u : 8u;
+    if (ppt_override == 2 || ppt_override == 4 || ppt_override == 8) b.ppt = ppt_override;
     b.n_blk = (N + b.ppt * kBiThreads - 1) / (b.ppt * kBiThreads);
-    b.n_tiles = (N + kScanTile - 1) / kScanTile;
+    b.n_words = (N + 31) / 32;
     return b;
 }
 
 static int bulk_scratch(lom_map *m, uint32_t N, const BulkShape &b)
 {
     int rc;
-    for (int s : {S_PT_SLOT, S_FLAG, S_RANK, S_PT_POS, S_ITEMS, S_PT_OFF, S_PT_M, S_ENT_ROW})
+    for (int s : {S_PT_OFF, S_PT_M, S_ENT_ROW})
         if ((rc = ensure(m, m->scr[s], (size_t)N * 4)) != LOM_OK) return rc;
-    if ((rc = ensure(m, m->scr[S_SCAN], (size_t)(2 * b.n_tiles + 16) * 4)) != LOM_OK) return rc;
+    if ((rc = ensure(m, m->scr[S_PT_SLOT], (size_t)N * 8)) != LOM_OK) return rc;
+    if ((rc = ensure(m, m->scr[S_PT_POS], (size_t)N * 16)) != LOM_OK) return rc;
+    if ((rc = ensure(m, m->scr[S_FLAG], (size_t)b.n_words * 4)) != LOM_OK) return rc;
+    if ((rc = ensure(m, m->scr[S_RANK], (size_t)b.n_words * 4)) != LOM_OK) return rc;
     if ((rc = ensure(m, m->scr[S_HIST], (size_t)b.n_parts * b.n_blk * 4)) != LOM_OK) return rc;
-    return ensure(m, m->scr[S_PART], (size_t)(2 * b.n_parts + 1) * 4);
+    // partition sizes and starts, then the bitmap's tiles: totals, prefixes, and the counter of finished tiles (at rest: 0)
+    const size_t tiles = (b.n_words + kBiTileWords - 1) / kBiTileWords;
+    const bool fresh = m->scr[S_PART].bytes < (size_t)(2 * kBiMaxParts + 1 + 2 * 256 + 1) * 4;
+    if ((rc = ensure(m, m->scr[S_PART], (size_t)(2 * kBiMaxParts + 1 + 2 * 256 + 1) * 4)) != LOM_OK) return rc;
+    if (fresh) LOM_HIP(m, hipMemsetAsync(m->scr[S_PART].p, 0, m->scr[S_PART].bytes, m->stream));
+    return tiles <= 256 ? LOM_OK : set_error(m, LOM_ERR_ARG, "bulk insert: too many points");
 }
 
 // batches above kOnePassMax points (see the kernels): everything is enqueued, nothing waits; the verdict -- range error,
@@ -1379,37 +1552,68 @@ static int add_points_bulk(lom_map *m, const char *d_xyz, const char *d_nrm, uin
                            bool validated_on_host, bool sync_status, bool allow_shrink)
 {
     int rc;
-    const BulkShape b = bulk_shape(N, m->cap);
+    const BulkShape b = bulk_shape(N, m->cap, m->bulk_ppt);
     if ((rc = bulk_scratch(m, N, b)) != LOM_OK) return rc;
     if (worst > m->slab_cap && (rc = ensure_slabs(m, worst + worst / 2)) != LOM_OK) return rc;
-    uint32_t *pt_slot = (uint32_t *)m->scr[S_PT_SLOT].p, *flag = (uint32_t *)m->scr[S_FLAG].p;
-    uint32_t *scan_local = (uint32_t *)m->scr[S_RANK].p, *part_slot = (uint32_t *)m->scr[S_PT_POS].p;
-    uint32_t *part_idx = (uint32_t *)m->scr[S_ITEMS].p, *ent_idx = (uint32_t *)m->scr[S_PT_OFF].p;
-    uint32_t *ent_w = (uint32_t *)m->scr[S_PT_M].p, *ent_row = (uint32_t *)m->scr[S_ENT_ROW].p;
-    uint32_t *tile_sums = (uint32_t *)m->scr[S_SCAN].p, *tile_prefix = tile_sums + b.n_tiles;
+    uint2 *pt_info = (uint2 *)m->scr[S_PT_SLOT].p;
+    uint32_t *flag_bits = (uint32_t *)m->scr[S_FLAG].p, *word_prefix = (uint32_t *)m->scr[S_RANK].p;
+    uint4 *part_rec = (uint4 *)m->scr[S_PT_POS].p;
+    uint32_t *ent_idx = (uint32_t *)m->scr[S_PT_OFF].p, *ent_w = (uint32_t *)m->scr[S_PT_M].p;
+    uint32_t *ent_row = (uint32_t *)m->scr[S_ENT_ROW].p;
     uint32_t *hist = (uint32_t *)m->scr[S_HIST].p;
-    uint32_t *part_total = (uint32_t *)m->scr[S_PART].p, *part_start = part_total + b.n_parts;
+    uint32_t *part_total = (uint32_t *)m->scr[S_PART].p, *part_start = part_total + kBiMaxParts;
+    uint32_t *tile_total = part_start + kBiMaxParts + 1, *tile_prefix = tile_total + 256, *tiles_done = tile_prefix + 256;
+    const uint32_t n_tiles = (b.n_words + kBiTileWords - 1) / kBiTileWords;
     uint32_t *words = d_word(m, 0);
     const uint32_t seq = ++m->call_seq;
     m->mutations++;
     const MapView v = view_of(m);
-    const uint32_t part_max = m->test_bulk_part_max ? std::min<uint32_t>(m->test_bulk_part_max, kBiPartMax) : kBiPartMax;
+    const uint32_t part_max = m->test_bulk_part_max ? std::min<uint32_t>(m->test_bulk_part_max, b.part_max) : b.part_max;
     const size_t lds = (size_t)b.n_parts * 4;
-    hipLaunchKernelGGL(k_bi_claim, dim3(b.n_blk), dim3(kBiThreads), lds, m->stream, m->d_table, v.mask, v.shift, d_xyz,
-                       stride, N, m->voxel_size, pt_slot, flag, hist, b.n_parts, b.part_shift, b.n_blk, b.ppt, d_nvox(m),
-                       seq, words);
-    hipLaunchKernelGGL(k_bi_colscan, dim3((b.n_parts + 3) / 4), dim3(kThreads), 0, m->stream, hist, b.n_parts, b.n_blk,
+    if (lds + 256 > 65536) {  // the histograms of 16,384 partitions fill the 64 KB a launch gets without asking
+        static std::once_flag once;
+        std::call_once(once, [] {
+            const int want = (int)kBiMaxParts * 4;
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bi_claim<2>), hipFuncAttributeMaxDynamicSharedMemorySize, want);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bi_scatter<2>), hipFuncAttributeMaxDynamicSharedMemorySize, want);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bi_claim<4>), hipFuncAttributeMaxDynamicSharedMemorySize, want);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bi_claim<8>), hipFuncAttributeMaxDynamicSharedMemorySize, want);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bi_scatter<4>), hipFuncAttributeMaxDynamicSharedMemorySize, want);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bi_scatter<8>), hipFuncAttributeMaxDynamicSharedMemorySize, want);
+        });
+    }
+    const dim3 gb(b.n_blk), tb(kBiThreads);
+    if (b.ppt == 2)
+        hipLaunchKernelGGL(k_bi_claim<2>, gb, tb, lds, m->stream, m->d_table, v.mask, v.shift, d_xyz, stride, N, m->voxel_size,
+                           pt_info, flag_bits, hist, b.n_parts, b.part_shift, d_nvox(m), seq, words);
+    else if (b.ppt == 4)
+        hipLaunchKernelGGL(k_bi_claim<4>, gb, tb, lds, m->stream, m->d_table, v.mask, v.shift, d_xyz, stride, N, m->voxel_size,
+                           pt_info, flag_bits, hist, b.n_parts, b.part_shift, d_nvox(m), seq, words);
+    else
+        hipLaunchKernelGGL(k_bi_claim<8>, gb, tb, lds, m->stream, m->d_table, v.mask, v.shift, d_xyz, stride, N, m->voxel_size,
+                           pt_info, flag_bits, hist, b.n_parts, b.part_shift, d_nvox(m), seq, words);
+    hipLaunchKernelGGL(k_bi_colscan, dim3((b.n_parts + 63) / 64), dim3(kBiThreads), 0, m->stream, hist, b.n_parts, b.n_blk,
                        part_total, part_max, seq, words);
-    hipLaunchKernelGGL(k_bi_scatter, dim3(b.n_blk), dim3(kBiThreads), lds, m->stream, N, pt_slot, hist, b.n_parts,
-                       b.part_shift, b.n_blk, b.ppt, part_total, part_start, part_slot, part_idx, seq, words);
-    hipLaunchKernelGGL(k_bi_group, dim3(b.n_parts), dim3(kThreads), 0, m->stream, m->d_table, part_start, part_slot,
-                       part_idx, m->max_points, m->d_slab_count, flag, ent_idx, ent_w, ent_row, seq, words);
-    hipLaunchKernelGGL(k_scan_tile<uint32_t>, dim3(b.n_tiles), dim3(kThreads), 0, m->stream, flag, scan_local, tile_sums, N);
-    hipLaunchKernelGGL(k_scan_tile<uint32_t>, dim3(1), dim3(kThreads), 0, m->stream, tile_sums, tile_prefix, words + 10,
-                       b.n_tiles);
+    if (b.ppt == 2)
+        hipLaunchKernelGGL(k_bi_scatter<2>, gb, tb, lds, m->stream, N, pt_info, hist, b.n_parts, b.part_shift, part_total,
+                           part_start, part_rec, seq, words);
+    else if (b.ppt == 4)
+        hipLaunchKernelGGL(k_bi_scatter<4>, gb, tb, lds, m->stream, N, pt_info, hist, b.n_parts, b.part_shift, part_total,
+                           part_start, part_rec, seq, words);
+    else
+        hipLaunchKernelGGL(k_bi_scatter<8>, gb, tb, lds, m->stream, N, pt_info, hist, b.n_parts, b.part_shift, part_total,
+                           part_start, part_rec, seq, words);
+    if (b.part_max == 512)
+        hipLaunchKernelGGL(k_bi_group<512>, dim3(b.n_parts), dim3(kThreads), 0, m->stream, m->d_table, part_start, part_rec,
+                           m->max_points, flag_bits, ent_idx, ent_w, ent_row, seq, words);
+    else
+        hipLaunchKernelGGL(k_bi_group<kBiPartMax>, dim3(b.n_parts), dim3(kThreads), 0, m->stream, m->d_table, part_start,
+                           part_rec, m->max_points, flag_bits, ent_idx, ent_w, ent_row, seq, words);
+    hipLaunchKernelGGL(k_bi_flagscan, dim3(n_tiles), dim3(kThreads), 0, m->stream, flag_bits, b.n_words, word_prefix,
+                       tile_total, tile_prefix, tiles_done, words + 10, seq, words);
     hipLaunchKernelGGL(k_bi_place, dim3(blocks_for(N)), dim3(kThreads), 0, m->stream, m->d_table, N, ent_idx, ent_w, ent_row,
-                       scan_local, tile_prefix, words + 10, d_xyz, d_nrm, stride, m->K, m->d_pts, m->d_nrm, m->d_slab_key,
-                       m->d_slab_count, d_nvox(m), seq, words);
+                       flag_bits, word_prefix, tile_prefix, words + 10, d_xyz, d_nrm, stride, m->K, m->d_pts, m->d_nrm,
+                       m->d_slab_key, m->d_slab_count, d_nvox(m), seq, words);
     LOM_HIP(m, hipGetLastError());
     // should a partition have been too large, lom_map_status() / whoever consumes the map next redoes this insert with
     // the four-kernel path: the caller keeps the input valid until then (as for a single-pass insert)
@@ -1766,6 +1970,7 @@ int lom_map_create(float voxel_size, size_t max_points, size_t capacity_hint, in
     m->opt_no_temporal = getenv("LOM_NO_TEMPORAL") != nullptr;
     if (const char *e = getenv("LOM_COUNT_CANDIDATES")) m->opt_count = atoi(e) != 0;
     m->opt_no_bulk = getenv("LOM_NO_BULK_INSERT") != nullptr;
+    if (const char *e = getenv("LOM_BULK_PPT")) m->bulk_ppt = (uint32_t)atoi(e);  // development: points per thread of k_bi_claim
     if (handle_setup(m) != LOM_OK) {
         lom_map_destroy(m);
         return LOM_ERR_HIP;
@@ -1996,7 +2201,7 @@ int lom_profile_insert(lom_map *m, const float *d_xyz, const float *d_nrm, size_
     if ((uint64_t)m->cap < 2 * worst && (rc = rehash(m, next_pow2(4 * worst))) != LOM_OK) return rc;
     if (worst > m->slab_cap && (rc = ensure_slabs(m, worst + worst / 2)) != LOM_OK) return rc;
     if (n > kOnePassMax && n <= kBiMaxPoints && !m->opt_no_bulk &&
-        (rc = bulk_scratch(m, (uint32_t)n, bulk_shape((uint32_t)n, m->cap))) != LOM_OK)
+        (rc = bulk_scratch(m, (uint32_t)n, bulk_shape((uint32_t)n, m->cap, m->bulk_ppt))) != LOM_OK)
         return rc;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     LOM_HIP(m, hipEventCreate(&e0));
