@@ -588,6 +588,11 @@ void lom_odometry_default_params(lom_odometry_params *p);          /* lidar_odom
 int lom_odometry_create(const lom_odometry_params *p, int device, lom_odometry **out); /* lidar_odometry.cpp:14-20 */
 void lom_odometry_destroy(lom_odometry *o);
 int lom_odometry_process_cloud(lom_odometry *o, const lom_point_xyzirt *pts, size_t n); /* :22-77 */
+/* a caller's frame loop in compiled code (the reference's caller is the C++ node, lidar_odometry_node.cpp:45-76): exactly
+ * `count` calls of lom_odometry_process_cloud, frames[i] with n[i] points, nothing else; stops at the first frame that
+ * fails and returns its status; *done = frames processed */
+int lom_odometry_process_sequence(lom_odometry *o, const lom_point_xyzirt *const *frames, const size_t *n, size_t count,
+                                  size_t *done);
 int lom_odometry_get_pose(const lom_odometry *o, lom_pose *out);   /* getCurrentPose, :87-89 */
 /* getTempCloud(), lidar_odometry.h:73-75 (the node publishes it as /deskewed_cloud,
  * lidar_odometry_node.cpp:66-75): the time-normalised, deskewed input cloud of the last processCloud

@@ -555,6 +555,18 @@ class LidarOdometry:
             text = capi.lib().lom_odometry_last_error(self._h)
             raise LomError(int(rc), text.decode() if text else "")
 
+    def processSequence(self, clouds):
+        """processCloud of every frame of `clouds`, in order, issued from compiled code (lom_odometry_process_sequence): the
+        reference's caller is the C++ node -- no interpreter between two frames."""
+        arrs = [_cloud(c) for c in clouds]
+        ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+        ns = (C.c_size_t * len(arrs))(*[len(a) for a in arrs])
+        done = C.c_size_t(0)
+        rc = capi.lib().lom_odometry_process_sequence(self._h, ptrs, ns, len(arrs), C.byref(done))
+        if rc != 0:
+            text = capi.lib().lom_odometry_last_error(self._h)
+            raise LomError(int(rc), (text.decode() if text else "") + f" (frame {done.value} of the sequence)")
+
     def getCurrentPose(self):                              # lidar_odometry.cpp:87-89
         p = capi.Pose()
         capi.check(capi.lib().lom_odometry_get_pose(self._h, C.byref(p)))

@@ -119,7 +119,7 @@ EXPORTED = [
     "lom_comm_finalize", "lom_comm_host_id", "lom_host_comm_create", "lom_host_comm_allreduce",
     "lom_host_comm_destroy", "lom_host_comm_allgather", "lom_comm_attach_host", "lom_comm_attach_p2p", "lom_align_with_hooks", "lom_point_time_normalize", "lom_transform_non_rigid",
     "lom_range_filter", "lom_cloud_classify", "lom_odometry_default_params", "lom_odometry_create",
-    "lom_odometry_destroy", "lom_odometry_process_cloud", "lom_odometry_get_pose", "lom_odometry_get_stats", "lom_odometry_get_temp_cloud", "lom_odometry_debug_set_state",
+    "lom_odometry_destroy", "lom_odometry_process_cloud", "lom_odometry_process_sequence", "lom_odometry_get_pose", "lom_odometry_get_stats", "lom_odometry_get_temp_cloud", "lom_odometry_debug_set_state",
     "lom_odometry_keyframe", "lom_odometry_last_error", "lom_pcd_read", "lom_pcd_last_error", "lom_estimate_normals", "lom_frontend_create", "lom_frontend_destroy", "lom_frontend_last_error",
     "lom_frontend_process", "lom_frontend_results", "lom_frontend_wait", "lom_frontend_fetch", "lom_frontend_stream", "lom_frontend_stage", "lom_frontend_done_event", "lom_map_wait_event", "lom_frontend_sequence", "lom_map_status_words", "lom_debug_sinf",
     "lom_voxel_downsample_device_nowait", "lom_map_read_device_words", "lom_map_read_device_words_begin", "lom_map_read_device_words_end",
@@ -257,6 +257,7 @@ def lib():
     L.lom_odometry_destroy.argtypes = [vp]
     L.lom_odometry_destroy.restype = None
     L.lom_odometry_process_cloud.argtypes = [vp, vp, C.c_size_t]
+    L.lom_odometry_process_sequence.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t), C.c_size_t, C.POINTER(C.c_size_t)]
     L.lom_odometry_get_pose.argtypes = [vp, pp]
     L.lom_odometry_get_stats.argtypes = [vp, C.POINTER(OdometryFrameStats)]
     L.lom_odometry_get_temp_cloud.argtypes = [vp, vp, C.c_size_t]

@@ -240,6 +240,7 @@ struct lom_map {
     uint32_t table_slots_per_voxel = 16;  // after a bulk insert (LOM_TABLE_SLOTS_PER_VOXEL at create)
     bool opt_host_lm = false;       // LOM_OPT_HOST_LM / LOM_HOST_LM=1
     bool opt_debug_lm = false;      // LOM_OPT_DEBUG_LM_STAMPS / LOM_DEBUG_LM=1
+    bool opt_debug_lm_twice = false;  // LOM_DEBUG_LM_TWICE=1 at create: k_lm<256, 64, 2> runs every policy step twice, stamps time the second
     bool opt_debug_timing = false;  // LOM_OPT_DEBUG_TIMING / LOM_DEBUG_TIMING=1
     bool opt_count = false;         // LOM_OPT_COUNT_CANDIDATES / LOM_COUNT_CANDIDATES=1: the searches also produce the reference-
                                     // algorithm counts (occupied voxels, stored points of all 27 neighbours): 27 slot loads per query

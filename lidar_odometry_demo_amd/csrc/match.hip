@@ -1332,7 +1332,10 @@ __device__ __forceinline__ void accumulate_all(const MatchRec *__restrict__ rec,
     }
 }
 
-template <int kT, int kBlocks = (int)kMaxLmBlocks, int kRegPts = 1>
+// kPolicyTwice (LOM_DEBUG_LM_TWICE=1 at create, a measurement aid): the first wave runs every policy step twice -- the
+// first time on state that is put back afterwards -- and the phase stamps time the second run: the same instructions
+// on the same data, with the step's code already in the instruction cache.
+template <int kT, int kBlocks = (int)kMaxLmBlocks, int kRegPts = 1, bool kPolicyTwice = false>
 __global__ __launch_bounds__(kT) void k_lm(const MatchRec *__restrict__ rec, uint32_t n, AlignState *state,
                                                      LmInit init, int first_outer,
                                                      const uint32_t *__restrict__ block_counters,
@@ -1446,7 +1449,25 @@ __global__ __launch_bounds__(kT) void k_lm(const MatchRec *__restrict__ rec, uin
             if (lane == 31) dbg_trace[ev * 40 + 8 + 31] = px.nranks > 1 ? s_tot[31] : (double)n;
             if (lane == 0) dbg_trace[200] = (double)(ev + 1);
         }
+        LmWave W_keep = W;
+        LmShared S_keep = r_lm;
+        double x_keep = 0.0;
+#pragma nounroll
+        for (int rep = 0; rep < (kPolicyTwice ? 2 : 1); rep++)
         if (wave == 0 && !s_failed) {
+            if constexpr (kPolicyTwice) {
+                if (rep == 0) {
+                    if (lane < 7) x_keep = s_x[lane];
+                } else {
+                    W = W_keep;
+                    r_lm = S_keep;
+                    if (lane < 7) s_x[lane] = x_keep;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    LM_STAMP(3);
+                }
+            }
             // the first wave holds the totals (s_tot) and runs the policy (lm_core.hpp's, lane-parallel and
             // register-resident: lm_wave.hpp)
             int a;
@@ -2039,6 +2060,8 @@ static int align_chained(lom_map *m, const char *d_src, size_t n, size_t stride,
         };
         if (shape == kLmSmall)
             launch(k_lm<(int)kLmSmallThreads>);
+        else if (shape == kLmSmall2 && m->opt_debug_lm_twice)
+            launch(k_lm<(int)kLmSmallThreads, (int)kMaxLmBlocks, 2, true>);
         else if (shape == kLmSmall2)
             launch(k_lm<(int)kLmSmallThreads, (int)kMaxLmBlocks, 2>);
 

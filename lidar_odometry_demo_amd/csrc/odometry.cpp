@@ -1054,4 +1054,17 @@ int lom_odometry_process_cloud(lom_odometry *o, const lom_point_xyzirt *pts, siz
     }
 }
 
+int lom_odometry_process_sequence(lom_odometry *o, const lom_point_xyzirt *const *frames, const size_t *n, size_t count,
+                                  size_t *done)
+{
+    if (done) *done = 0;
+    if (!o || (count && (!frames || !n))) return LOM_ERR_ARG;
+    for (size_t i = 0; i < count; i++) {
+        const int rc = lom_odometry_process_cloud(o, frames[i], n[i]);
+        if (rc != LOM_OK) return rc;
+        if (done) *done = i + 1;
+    }
+    return LOM_OK;
+}
+
 }  // extern "C"

@@ -1966,6 +1966,7 @@ int lom_map_create(float voxel_size, size_t max_points, size_t capacity_hint, in
     m->opt_host_lm = getenv("LOM_HOST_LM") != nullptr;
     if (const char *e = getenv("LOM_TABLE_SLOTS_PER_VOXEL")) m->table_slots_per_voxel = (uint32_t)std::min(256, std::max(2, atoi(e)));
     m->opt_debug_lm = getenv("LOM_DEBUG_LM") != nullptr;
+    m->opt_debug_lm_twice = getenv("LOM_DEBUG_LM_TWICE") != nullptr;
     m->opt_debug_timing = getenv("LOM_DEBUG_TIMING") != nullptr;
     m->opt_no_temporal = getenv("LOM_NO_TEMPORAL") != nullptr;
     if (const char *e = getenv("LOM_COUNT_CANDIDATES")) m->opt_count = atoi(e) != 0;

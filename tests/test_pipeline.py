@@ -223,6 +223,29 @@ def test_device_stages_equal_host_stages(lom, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dma", [False, True])
+def test_process_sequence_equals_the_frame_loop(lom, monkeypatch, dma):
+    """lom_odometry_process_sequence is a frame loop in compiled code and nothing else: same pose bits, same counts, same
+    keyframe as processCloud frame by frame -- with the frame uploaded by the front end's first kernel (the default) and
+    by a copy in front of it (LOM_FE_DMA_UPLOAD=1)."""
+    if dma:
+        monkeypatch.setenv("LOM_FE_DMA_UPLOAD", "1")
+    boxes = synth.make_boxes()
+    frames = [synth.make_sequence_frame(k, boxes=boxes) for k in range(12)]
+    a, b = lom.LidarOdometry(), lom.LidarOdometry()
+    for f in frames:
+        a.processCloud(f)
+    b.processSequence(frames)
+    pa, pb = a.getCurrentPose(), b.getCurrentPose()
+    assert pa.translation.tobytes() == pb.translation.tobytes() and pa.rotation.tobytes() == pb.rotation.tobytes()
+    sa, sb = a.stats, b.stats
+    for key in ("planar_points", "filtered_points", "update_points", "matching_points", "outer_iterations", "queries_total",
+                "keyframe_voxels"):
+        assert sa[key] == sb[key], key
+    assert a.getFullKeyFrameCloud().tobytes() == b.getFullKeyFrameCloud().tobytes()
+
+
+@pytest.mark.gpu
 def test_frame_handed_back_by_the_device_front_end(lom, monkeypatch):
     """A frame the device front end cannot decide bit-exactly (an azimuth on a bin boundary: ~1e-11 per point) is
     redone by the host stages after the device stages have already run.  Forced on every frame here: same
