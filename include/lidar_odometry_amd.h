@@ -244,11 +244,6 @@ int lom_match_align_repeat(lom_map *m, const float *d_src_xyz, size_t n, size_t 
 /* Diagnostic build of the correspondence kernel with shader-clock stamps after each phase of every
  * workgroup's first query (8 u64 per workgroup: entry, point transformed, slots probed, prefix in
  * LDS, candidates scanned, minimum known, record stored, exit).  Not a timing of the product kernel. */
-/* diagnostics of the last search launch of this handle, if it was the one-lane-per-query kernel of outer iterations >= 2
- * (csrc/match.hip k_match_next): the queries that had no usable bound from their previous winner and were searched by
- * their whole wave together.  (After an align that stopped early the last launches returned at once and left the
- * counters of the last search that ran.) */
-int64_t lom_debug_next_search_slow(lom_map *m);
 int lom_debug_match_stamps(lom_map *m, const float *d_src_xyz, size_t n, size_t stride_bytes, const float t[3],
                            const float q_wxyz[4], float max_dist, unsigned long long *stamps_out,
                            size_t cap_blocks, uint32_t *n_blocks_out);
@@ -316,10 +311,6 @@ typedef enum {
                                           (three device-scope atomics per point) instead of the partitioned bulk insert
                                           (csrc/voxel_map.hip "bulk insert").  Same map either way, bytewise; the switch exists
                                           for A/B timing (LOM_NO_BULK_INSERT=1 in the environment at create) */
-    LOM_OPT_NO_NEXT_SEARCH = 8,        /* 1: the searches of outer iterations >= 2 of an align run the first search's kernel
-                                          (16 lanes per query, k_match) instead of the one-lane-per-query kernel that lives
-                                          off the previous winner's bound (k_match_next).  Same winners either way; A/B timing
-                                          (LOM_NO_NEXT_SEARCH=1 in the environment at create) */
     LOM_OPT_TEST_GIVE_UP_AT_OUTER = 100, /* k: the k_lm of outer iteration k of the NEXT align behaves as if its
                                           workgroups had timed out waiting (one shot; -1 = off) */
     LOM_OPT_TEST_GRID_GIVE_UP = 101,   /* b >= 0: in the NEXT map-maintenance call with an in-kernel scan, workgroups

@@ -124,7 +124,7 @@ EXPORTED = [
     "lom_frontend_process", "lom_frontend_results", "lom_frontend_wait", "lom_frontend_fetch", "lom_frontend_stream", "lom_frontend_stage", "lom_frontend_done_event", "lom_map_wait_event", "lom_frontend_sequence", "lom_map_status_words", "lom_debug_sinf",
     "lom_voxel_downsample_device_nowait", "lom_map_read_device_words", "lom_map_read_device_words_begin", "lom_map_read_device_words_end",
     "lom_pointcloud2_unpack", "lom_pointcloud2_layout", "lom_pointcloud2_pack_xyz", "lom_pointcloud2_last_error",
-    "lom_map_set_option", "lom_map_debug_counter", "lom_debug_next_search_slow", "lom_odometry_set_option", "lom_odometry_debug_counter",
+    "lom_map_set_option", "lom_map_debug_counter", "lom_odometry_set_option", "lom_odometry_debug_counter",
     "lom_frontend_set_option", "lom_host_comm_set_timeout", "lom_host_comm_abort", "lom_host_comm_last_error",
     "lom_scan_create", "lom_scan_destroy", "lom_scan_last_error", "lom_scan_set_option", "lom_scan_set_stream",
     "lom_scan_get_stream", "lom_scan_create_on_partition", "lom_scan_align", "lom_scan_align_device", "lom_scan_align_repeat", "lom_scan_find_pairs", "lom_scan_find_pairs_sq",
@@ -133,7 +133,7 @@ EXPORTED = [
 # lom_option / counters of include/lidar_odometry_amd.h
 OPT_HOST_LM, OPT_DEVICE_PATIENCE_TICKS, OPT_DEBUG_LM_STAMPS, OPT_DEBUG_TIMING, OPT_NO_TEMPORAL_BOUND, OPT_COUNT_CANDIDATES = 1, 2, 3, 4, 5, 6
 OPT_TEST_GIVE_UP_AT_OUTER, OPT_TEST_GRID_GIVE_UP, OPT_TEST_FORCE_HOST_REDO = 100, 101, 102
-OPT_NO_BULK_INSERT, OPT_NO_NEXT_SEARCH, OPT_TEST_BULK_PARTITION_MAX = 7, 8, 106
+OPT_NO_BULK_INSERT, OPT_TEST_BULK_PARTITION_MAX = 7, 106
 OPT_TEST_GRID_GIVE_UP_MATCHING_DS, OPT_TEST_GRID_GIVE_UP_UPDATE_DS, OPT_TEST_GRID_GIVE_UP_KEYFRAME = 103, 104, 105
 COUNTER_GRID_REDOS = 0
 
@@ -298,8 +298,6 @@ def lib():
     L.lom_pointcloud2_last_error.restype = C.c_char_p
     L.lom_map_set_option.argtypes = [vp, C.c_int, C.c_int64]
     L.lom_map_debug_counter.argtypes = [vp, C.c_int]
-    L.lom_debug_next_search_slow.argtypes = [vp]
-    L.lom_debug_next_search_slow.restype = C.c_int64
     L.lom_map_debug_counter.restype = C.c_int64
     L.lom_odometry_set_option.argtypes = [vp, C.c_int, C.c_int64]
     L.lom_odometry_debug_counter.argtypes = [vp, C.c_int]

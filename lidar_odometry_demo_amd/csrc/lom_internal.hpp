@@ -194,9 +194,6 @@ struct lom_map {
     uint32_t grid_redos = 0;  // calls redone with the multi-launch scan after a give-up (lom_map_debug_counter)
     // per-scan buffers of align/find_pairs
     lom::DeviceBuf scan_src, scan_idx, scan_on, scan_stats, partials, results;
-    lom::DeviceBuf scan_list;      // [16 words: counter] [n query ids]: what k_match_next leaves for k_match<..., kList>
-    bool scan_list_clean = false;  // the counter is known to be zero (k_lm puts it back after every pair)
-    uint32_t next_search_min = 65536;  // scans from this many points on search outer iterations >= 2 with k_match_next (LOM_NEXT_SEARCH_MIN)
 
     // pinned host result buffer
     double *h_results = nullptr;  // 1024 doubles (rank-ordered gather of up to 32 ranks)
@@ -221,7 +218,6 @@ struct lom_map {
     int words_pending = 0;  // words of a lom_map_read_device_words_begin not yet collected
     unsigned long long report_seq = 0, lm_seq = 0, lm_launches = 0;
     uint32_t lm_max_blocks[4] = {0, 0, 0, 0};  // co-resident k_lm workgroups this device admits, per variant (occupancy query, cached)
-    uint32_t last_match_blocks = 0;  // workgroups of the last search launch (lom_debug_next_search_slow)
     double last_counters[4] = {0, 0, 0, 0};  // valid, cand, occ, queries of the last k_match
 
     bool profiling = false;       // this align carries event pairs
@@ -248,7 +244,6 @@ struct lom_map {
     bool opt_debug_timing = false;  // LOM_OPT_DEBUG_TIMING / LOM_DEBUG_TIMING=1
     bool opt_count = false;         // LOM_OPT_COUNT_CANDIDATES / LOM_COUNT_CANDIDATES=1: the searches also produce the reference-
                                     // algorithm counts (occupied voxels, stored points of all 27 neighbours): 27 slot loads per query
-    bool opt_no_next_search = false;  // LOM_OPT_NO_NEXT_SEARCH / LOM_NO_NEXT_SEARCH=1: outer iterations >= 2 search with k_match too (16 lanes per query)
     bool opt_no_temporal = false;   // LOM_OPT_NO_TEMPORAL_BOUND / LOM_NO_TEMPORAL=1: every search at the plain max_dist bound
     unsigned long long patience_ticks = 5000000ull;  // bounded in-kernel waits: 50 ms of s_memrealtime (100 MHz)
     bool opt_no_bulk = false;       // LOM_OPT_NO_BULK_INSERT / LOM_NO_BULK_INSERT=1: batches above 65,536 points take the four-kernel path

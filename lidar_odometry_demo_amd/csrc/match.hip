@@ -186,63 +186,6 @@ __device__ __forceinline__ void load_chunk48(const float *a, f32x3 (&r)[4])
     r[3] = f32x3{v2.y, v2.z, v2.w};
 }
 
-// k_match_next: two / five chunks of four rows (six / fifteen dwordx4) in flight per lane, and four slots
-__device__ __forceinline__ void unpack_chunk48(const float (&v)[12], f32x3 *r)
-{
-    r[0] = f32x3{v[0], v[1], v[2]};
-    r[1] = f32x3{v[3], v[4], v[5]};
-    r[2] = f32x3{v[6], v[7], v[8]};
-    r[3] = f32x3{v[9], v[10], v[11]};
-}
-__device__ __forceinline__ void load_chunk48x2(const float *a, const float *b, f32x3 (&ra)[4], f32x3 (&rb)[4])
-{
-    typedef float f32x4 __attribute__((ext_vector_type(4)));
-    f32x4 v[6];
-    asm volatile("global_load_dwordx4 %0, %6, off\n\tglobal_load_dwordx4 %1, %6, off offset:16\n\t"
-                 "global_load_dwordx4 %2, %6, off offset:32\n\tglobal_load_dwordx4 %3, %7, off\n\t"
-                 "global_load_dwordx4 %4, %7, off offset:16\n\tglobal_load_dwordx4 %5, %7, off offset:32\n\t"
-                 "s_waitcnt vmcnt(0)"
-                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5])
-                 : "v"(a), "v"(b)
-                 : "memory");
-    const float fa[12] = {v[0].x, v[0].y, v[0].z, v[0].w, v[1].x, v[1].y, v[1].z, v[1].w, v[2].x, v[2].y, v[2].z, v[2].w};
-    const float fb[12] = {v[3].x, v[3].y, v[3].z, v[3].w, v[4].x, v[4].y, v[4].z, v[4].w, v[5].x, v[5].y, v[5].z, v[5].w};
-    unpack_chunk48(fa, ra);
-    unpack_chunk48(fb, rb);
-}
-__device__ __forceinline__ void load_chunk48x5(const float *a0, const float *a1, const float *a2, const float *a3,
-                                               const float *a4, f32x3 (&r)[20])
-{
-    typedef float f32x4 __attribute__((ext_vector_type(4)));
-    f32x4 v[15];
-    asm volatile("global_load_dwordx4 %0, %15, off\n\tglobal_load_dwordx4 %1, %15, off offset:16\n\t"
-                 "global_load_dwordx4 %2, %15, off offset:32\n\tglobal_load_dwordx4 %3, %16, off\n\t"
-                 "global_load_dwordx4 %4, %16, off offset:16\n\tglobal_load_dwordx4 %5, %16, off offset:32\n\t"
-                 "global_load_dwordx4 %6, %17, off\n\tglobal_load_dwordx4 %7, %17, off offset:16\n\t"
-                 "global_load_dwordx4 %8, %17, off offset:32\n\tglobal_load_dwordx4 %9, %18, off\n\t"
-                 "global_load_dwordx4 %10, %18, off offset:16\n\tglobal_load_dwordx4 %11, %18, off offset:32\n\t"
-                 "global_load_dwordx4 %12, %19, off\n\tglobal_load_dwordx4 %13, %19, off offset:16\n\t"
-                 "global_load_dwordx4 %14, %19, off offset:32\n\ts_waitcnt vmcnt(0)"
-                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7]),
-                   "=&v"(v[8]), "=&v"(v[9]), "=&v"(v[10]), "=&v"(v[11]), "=&v"(v[12]), "=&v"(v[13]), "=&v"(v[14])
-                 : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4)
-                 : "memory");
-#pragma unroll
-    for (int c = 0; c < 5; c++) {
-        const float f[12] = {v[3 * c].x,     v[3 * c].y,     v[3 * c].z,     v[3 * c].w,     v[3 * c + 1].x, v[3 * c + 1].y,
-                             v[3 * c + 1].z, v[3 * c + 1].w, v[3 * c + 2].x, v[3 * c + 2].y, v[3 * c + 2].z, v[3 * c + 2].w};
-        unpack_chunk48(f, r + 4 * c);
-    }
-}
-__device__ __forceinline__ void load_slots4(const Slot *a, const Slot *b, const Slot *c, const Slot *d, u32x4 (&r)[4])
-{
-    asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %5, off\n\tglobal_load_dwordx4 %2, %6, off\n\t"
-                 "global_load_dwordx4 %3, %7, off\n\ts_waitcnt vmcnt(0)"
-                 : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3])
-                 : "v"(a), "v"(b), "v"(c), "v"(d)
-                 : "memory");
-}
-
 // Two 12-byte loads issued back to back and waited for together (the winner's point and normal).  The loads of a
 // trip are asm blocks because, left to the compiler, the first use of load 1 was scheduled ahead of the address
 // computation of load 2: the "two loads in flight" of round 2 were two dependent round trips (C2 / C3 / C4: 7.9 / 29.9
@@ -295,18 +238,14 @@ struct Stamper<true> {
 // cand(q), the tests' n_cand / n_occ) need every one of the 27 slots.  Without them (the product's align, unless
 // LOM_OPT_COUNT_CANDIDATES asks) a neighbour voxel that the bound prunes is not even looked up: its slot is neither
 // hashed nor loaded -- the result cannot depend on whether a voxel exists whose points could not win.
-// kList: the queries are the first *qcount entries of qlist (what k_match_next left for this kernel), not 0 .. n - 1.
-template <int G, int kU, int kMinWaves, bool kStamp = false, bool kChained = false, bool kPrev = kChained, bool kCount = true,
-          bool kList = false>
+template <int G, int kU, int kMinWaves, bool kStamp = false, bool kChained = false, bool kPrev = kChained, bool kCount = true>
 __global__ __launch_bounds__(kMatchThreads, kMinWaves) void k_match(MapView map, const char *__restrict__ src, size_t stride,
                                                          uint32_t n, PoseArgs Parg, int32_t *__restrict__ out_idx,
                                                          MatchRec *__restrict__ out_rec,
                                                          QStat *__restrict__ out_stat,
                                                          uint32_t *__restrict__ block_counters,
                                                          unsigned long long *__restrict__ stamps = nullptr,
-                                                         const AlignState *state = nullptr,
-                                                         const uint32_t *__restrict__ qlist = nullptr,
-                                                         const uint32_t *__restrict__ qcount = nullptr)
+                                                         const AlignState *state = nullptr)
 {
     static_assert(G == 16 && kU == 4, "one query per 16-lane DPP row, a chunk of four rows per lane and trip");
     constexpr uint32_t kRowsLog2 = 2;  // rows per chunk
@@ -314,17 +253,13 @@ __global__ __launch_bounds__(kMatchThreads, kMinWaves) void k_match(MapView map,
     // scalar-cache miss of its own, and the LDS tables below need a barrier -- one memory round trip instead of two
     // ahead of the first probe (the loop fetches the next query's point the same way, behind the current one's work)
     constexpr int kGroups0 = kMatchThreads / G;
-    if constexpr (kList) n = min(n, *qcount);  // from here on n counts list entries, j runs over them, q = qlist[j]
-    const uint32_t j_first = blockIdx.x * kGroups0 + threadIdx.x / G;
-    uint32_t q_next = j_first;
-    if constexpr (kList) q_next = j_first < n ? qlist[j_first] : 0u;
-    const uint32_t q_first = kList ? (j_first < n ? q_next : 0xFFFFFFFFu) : j_first;
+    const uint32_t q_first = blockIdx.x * kGroups0 + threadIdx.x / G;
     f32x3 sp_next = {0.f, 0.f, 0.f};
     // (without the counts the temporal bound decides which slots are loaded at all: the previous record travels with the
     // source point, one query ahead; with them it is only needed once the slots are back)
     constexpr bool kPrevEarly = kPrev && !kCount;
     float4 pv_next = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (kList ? (j_first < n) : (q_first < n)) {
+    if (q_first < n) {
         sp_next = *reinterpret_cast<const f32x3 *>(src + (size_t)q_first * stride);
         if constexpr (kPrevEarly) pv_next = reinterpret_cast<const float4 *>(out_rec + q_first)[1];
     }
@@ -410,18 +345,15 @@ __global__ __launch_bounds__(kMatchThreads, kMinWaves) void k_match(MapView map,
     if (gl < 3) s_gap[grp][gl * 3 + 1] = 0.f;  // the centre column of the gap table never changes (own group, own wave)
 
     const float slack_vs = map.prune_slack;  // 1e-4f * voxel_size
-    for (uint32_t j = blockIdx.x * kGroups + grp; j < n; j += groups_total) {
-        const uint32_t q = kList ? q_next : j;
+    for (uint32_t q = blockIdx.x * kGroups + grp; q < n; q += groups_total) {
         f32x3 sp = sp_next;
         // the previous search's {winner point, valid} of this query: not needed before the slots are back, so it is
         // asked for here (one round trip beside theirs) rather than a query ahead (four more live registers)
         float4 pv = pv_next;
         if constexpr (kPrev && !kPrevEarly) pv = reinterpret_cast<const float4 *>(out_rec + q)[1];
-        if (j + groups_total < n) {
-            const uint32_t qn = kList ? qlist[j + groups_total] : j + groups_total;
-            q_next = qn;
-            sp_next = *reinterpret_cast<const f32x3 *>(src + (size_t)qn * stride);
-            if constexpr (kPrevEarly) pv_next = reinterpret_cast<const float4 *>(out_rec + qn)[1];
+        if (q + groups_total < n) {
+            sp_next = *reinterpret_cast<const f32x3 *>(src + (size_t)(q + groups_total) * stride);
+            if constexpr (kPrevEarly) pv_next = reinterpret_cast<const float4 *>(out_rec + (q + groups_total))[1];
         }
         const double p0 = (double)sp.x, p1 = (double)sp.y, p2 = (double)sp.z;
         // voxel_grid.h:220-223: R*p + t in f64 (Eigen order a0 + (a1 + a2)), cast to f32 -- this lane's component
@@ -693,334 +625,6 @@ __global__ __launch_bounds__(kMatchThreads, kMinWaves) void k_match(MapView map,
     if (threadIdx.x < 4) {
         uint32_t v = 0;
         for (int g = 0; g < kGroups; g++) v += s_cnt[g][threadIdx.x];
-        block_counters[blockIdx.x * 4 + threadIdx.x] = v;
-    }
-}
-
-// ---------------------------------------------------------------------------
-// k_match_next: the searches of outer iterations >= 2 of an align (and lom_debug_find_pairs_after's second search),
-// ONE LANE PER QUERY.
-//
-// After the first search every query has a record; between two outer iterations the pose moves by millimetres, so the
-// old winner is still among the query's candidates and its distance at the new pose -- a few centimetres -- bounds
-// the new minimum from above (the "temporal bound" of k_match, same argument, same slack).  A bound that tight leaves
-// one to four of the 27 neighbour voxels: a 16-lane row per query then spends its ~100 instructions per query on
-// hashing, prefix tables and row reductions for voxels it never scans (C3: 12 M VALU instructions per launch, the
-// kernel's whole 23 us at four cycles each).  Here a lane does one query by itself: transform, index, gaps, the old
-// winner's bound, a 27-bit mask of the voxels whose nearest face lies within it, then voxel by voxel in the
-// reference's scan order (voxel_grid.h:175-183) slot -> rows, strict minimum (:186-187: first encountered wins).  No
-// cross-lane traffic, no LDS, ~10 wave instructions per query.
-// Queries without a usable bound -- no previous winner, one that left the 27 voxels or max_dist, a centre at the rim
-// of the index range -- are searched afterwards by their whole wave together, one at a time, at the plain max_dist
-// bound: lanes 0..26 probe one neighbour each, the occupied voxels' rows form one flattened sequence in scan order
-// (wave scan of the counts), lane l takes rows l, l + 64, ..., and the lexicographic minimum of (distance, ordinal)
-// over the wave is the reference's winner.  Exact either way; a launch of queries that all lack a bound is correct,
-// only slow (the first search of a scan goes through k_match).
-// The record's first quarter holds the source point since the first search: the cloud itself is not read.
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
-{
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        const uint32_t o = (uint32_t)__shfl_xor((int)v, d, 64);
-        v = o < v ? o : v;
-    }
-    return v;
-}
-
-__device__ __forceinline__ bool probe_slot(const MapView &map, unsigned long long key, uint32_t &cnt, uint32_t &slab)
-{
-    uint32_t hh = hash_key(key, map.shift) & map.mask;
-    for (uint32_t probe = 0; probe <= map.mask; probe++) {
-        const u32x4 r = load_slot(map.table + hh);
-        const unsigned long long k = ((unsigned long long)r.y << 32) | r.x;
-        if (k == key) {
-            cnt = r.z;
-            slab = r.w;
-            return true;
-        }
-        if (k == kEmptyKey) break;
-        hh = (hh + 1) & map.mask;
-    }
-    cnt = 0;
-    slab = 0;
-    return false;
-}
-
-template <bool kChained>
-__global__ __launch_bounds__(kMatchThreads) void k_match_next(MapView map, uint32_t n, PoseArgs Parg,
-                                                              int32_t *__restrict__ out_idx, MatchRec *__restrict__ out_rec,
-                                                              QStat *__restrict__ out_stat,
-                                                              uint32_t *__restrict__ block_counters,
-                                                              const AlignState *state, uint32_t *__restrict__ qlist,
-                                                              uint32_t *__restrict__ qcount)
-{
-    __shared__ uint32_t s_inc[kMatchThreads / 64][32];   // slow queries: inclusive prefix of the neighbours' counts
-    __shared__ uint32_t s_row0[kMatchThreads / 64][32];  // ... and first row of a neighbour minus its exclusive prefix
-    __shared__ uint32_t s_valid[kMatchThreads / 64], s_slow[kMatchThreads / 64];
-    const uint32_t q = blockIdx.x * kMatchThreads + threadIdx.x;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const bool live = q < n;
-    float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
-    if (live) {
-        const float4 *rec = reinterpret_cast<const float4 *>(out_rec + q);
-        r0 = rec[0];
-        r1 = rec[1];
-    }
-    struct {
-        double R[9], t[3];
-        float max_sq;
-    } P;
-    if constexpr (kChained) {
-        typedef const __attribute__((address_space(4))) AlignState *ConstState;
-        ConstState cs = (ConstState)(state);
-#pragma unroll
-        for (int i = 0; i < 9; i++) P.R[i] = cs->P.R[i];
-#pragma unroll
-        for (int i = 0; i < 3; i++) P.t[i] = cs->P.t[i];
-        P.max_sq = cs->P.max_sq;
-        if (cs->finished | cs->error) return;
-    } else {
-#pragma unroll
-        for (int i = 0; i < 9; i++) P.R[i] = Parg.R[i];
-#pragma unroll
-        for (int i = 0; i < 3; i++) P.t[i] = Parg.t[i];
-        P.max_sq = Parg.max_sq;
-    }
-    // voxel_grid.h:220-223: R*p + t in f64 (Eigen order a0 + (a1 + a2)), cast to f32
-    const double p0 = (double)r0.x, p1 = (double)r0.y, p2 = (double)r0.z;
-    const float qx = (float)((P.R[0] * p0 + (P.R[1] * p1 + P.R[2] * p2)) + P.t[0]);
-    const float qy = (float)((P.R[3] * p0 + (P.R[4] * p1 + P.R[5] * p2)) + P.t[1]);
-    const float qz = (float)((P.R[6] * p0 + (P.R[7] * p1 + P.R[8] * p2)) + P.t[2]);
-    int ix = 0, iy = 0, iz = 0;
-    const bool inr = voxel_index_fast(qx, map.voxel_size, map.inv_voxel_size, ix) &
-                     voxel_index_fast(qy, map.voxel_size, map.inv_voxel_size, iy) &
-                     voxel_index_fast(qz, map.voxel_size, map.inv_voxel_size, iz);
-    float gx[3], gy[3], gz[3];  // squared gaps to the neighbour voxels i - 1, i, i + 1 of each axis
-    gx[1] = gy[1] = gz[1] = 0.f;
-    axis_gaps(qx, ix, map.voxel_size, map.prune_slack, gx[0], gx[2]);
-    axis_gaps(qy, iy, map.voxel_size, map.prune_slack, gy[0], gy[2]);
-    axis_gaps(qz, iz, map.voxel_size, map.prune_slack, gz[0], gz[2]);
-    // stored indices lie in (-2^20, 2^20): a centre at least two voxels inside has all 27 neighbours in range
-    const uint32_t kInner = (uint32_t)(2 * kIdxBias - 3);
-    const bool safe = (uint32_t)(ix + (kIdxBias - 2)) < kInner && (uint32_t)(iy + (kIdxBias - 2)) < kInner &&
-                      (uint32_t)(iz + (kIdxBias - 2)) < kInner;
-    // the temporal bound (see k_match): the old winner, if its own voxel index lies within one of the new centre's
-    int ox = 0, oy = 0, oz = 0;
-    const bool oko = voxel_index_fast(r1.x, map.voxel_size, map.inv_voxel_size, ox) &
-                     voxel_index_fast(r1.y, map.voxel_size, map.inv_voxel_size, oy) &
-                     voxel_index_fast(r1.z, map.voxel_size, map.inv_voxel_size, oz);
-    const bool near = oko && (uint32_t)(ox - ix + 1) <= 2u && (uint32_t)(oy - iy + 1) <= 2u && (uint32_t)(oz - iz + 1) <= 2u;
-    const float ex = qx - r1.x, ey = qy - r1.y, ez = qz - r1.z;
-    const float d_prev2 = ex * ex + (ey * ey + ez * ez);
-    bool fast = live && inr && safe && near && r1.w != 0.f && d_prev2 < P.max_sq;  // (NaN: no bound)
-    const unsigned long long key0 = pack_key(ix, iy, iz);
-    float best = P.max_sq;  // "d2 < best" then implies voxel_grid.h:186's d2 < max_sq, and NaN never wins
-    uint32_t best_row = 0xFFFFFFFFu;
-    {
-        const float bound = d_prev2 * 1.0001f;
-        uint32_t todo = 0;  // bit b: neighbour b = (dx + 1) * 9 + (dy + 1) * 3 + (dz + 1) may hold a point within the bound
-        if (fast) {
-#pragma unroll
-            for (int b = 0; b < 27; b++) {
-                const float lower = gx[b / 9] + (gy[(b / 3) % 3] + gz[b % 3]);
-                todo |= (lower > bound) ? 0u : (1u << b);
-            }
-            // a bound that leaves more than four voxels is no bound to live off alone: that query joins the ones the
-            // wave searches together (a lane on its own would walk the voxels one round trip after the other)
-            if (__popc(todo) > 4) {
-                fast = false;
-                todo = 0u;
-            }
-        }
-        auto key_of = [&](uint32_t b) {
-            const int dx = (int)(b / 9u) - 1, dy = (int)((b / 3u) % 3u) - 1, dz = (int)(b % 3u) - 1;
-            return key0 + (unsigned long long)(((long long)dx << 42) + ((long long)dy << 21) + (long long)dz);
-        };
-        // a lane that has nothing to load in a step loads its own record instead: always mapped, and its rows never count
-        const float *idle = reinterpret_cast<const float *>(out_rec + (live ? q : 0u));
-        // One voxel's rows, all in flight together: chunks of four consecutive 12-byte rows as three dwordx4 each (the
-        // address of a chunk a lane does not need is its first chunk's: no load is ever out of bounds beyond the three
-        // rows past a voxel's count the slabs are padded for), compared in ascending order -- first encountered wins.
-        auto scan_voxel = [&](uint32_t cnt, uint32_t slab) {
-            const uint32_t row0 = slab * map.K;
-            const float *rows = cnt ? map.pts + (size_t)row0 * 3 : idle;
-            for (uint32_t r0 = 0; __ballot(r0 < cnt) != 0ull; r0 += 20u) {  // (wave-uniform trip count)
-                const bool wide = __ballot(r0 + 8u < cnt) != 0ull;  // some lane has more than two chunks left
-                const float *a0 = rows + (size_t)(r0 < cnt ? r0 : 0u) * 3;
-                const float *a1 = (r0 + 4u < cnt) ? a0 + 12 : a0;
-                auto compare = [&](const f32x3 &a, uint32_t u) {
-                    const float ax = qx - a.x, ay = qy - a.y, az = qz - a.z;
-                    const float d2 = ax * ax + (ay * ay + az * az);  // voxel_grid.h:184 f32 squaredNorm
-                    if (r0 + u < cnt && d2 < best) {                 // :186-187 strict
-                        best = d2;
-                        best_row = row0 + r0 + u;
-                    }
-                };
-                if (!wide) {
-                    f32x3 c0[4], c1[4];
-                    load_chunk48x2(a0, a1, c0, c1);
-#pragma unroll
-                    for (int u = 0; u < 4; u++) compare(c0[u], (uint32_t)u);
-#pragma unroll
-                    for (int u = 0; u < 4; u++) compare(c1[u], (uint32_t)(4 + u));
-                } else {
-                    const float *a2 = (r0 + 8u < cnt) ? a0 + 24 : a0;
-                    const float *a3 = (r0 + 12u < cnt) ? a0 + 36 : a0;
-                    const float *a4 = (r0 + 16u < cnt) ? a0 + 48 : a0;
-                    f32x3 pt[20];
-                    load_chunk48x5(a0, a1, a2, a3, a4, pt);
-#pragma unroll
-                    for (int u = 0; u < 20; u++) compare(pt[u], (uint32_t)u);
-                }
-            }
-        };
-        // the first four voxels of the mask: their slots in flight together, then one voxel's rows at a time
-        while (__ballot(todo != 0u) != 0ull) {
-            uint32_t bsel[4], hh[4], cnt[4], slab[4];
-            unsigned long long key[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                bsel[j] = todo ? (uint32_t)__builtin_ctz(todo) : 32u;
-                todo &= todo - 1u;  // (0 stays 0)
-                key[j] = bsel[j] < 32u ? key_of(bsel[j]) : 0ull;
-                hh[j] = bsel[j] < 32u ? (hash_key(key[j], map.shift) & map.mask) : 0u;
-                cnt[j] = slab[j] = 0u;
-            }
-            u32x4 raw[4];
-            load_slots4(map.table + hh[0], map.table + hh[1], map.table + hh[2], map.table + hh[3], raw);
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                if (bsel[j] >= 32u) continue;
-                u32x4 r = raw[j];
-                uint32_t h2 = hh[j];
-                for (uint32_t probe = 0; probe <= map.mask; probe++) {
-                    const unsigned long long k = ((unsigned long long)r.y << 32) | r.x;
-                    if (k == key[j]) {
-                        cnt[j] = r.z;
-                        slab[j] = r.w;
-                        break;
-                    }
-                    if (k == kEmptyKey) break;
-                    h2 = (h2 + 1) & map.mask;
-                    r = load_slot(map.table + h2);
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-                if (__ballot(cnt[j] != 0u) != 0ull) scan_voxel(cnt[j], slab[j]);  // ascending b = the reference's scan order
-        }
-    }
-    uint32_t n_valid = 0;
-    auto write_record = [&](uint32_t qq, bool valid, uint32_t row, float d2) {
-        f32x3 wp = {0.f, 0.f, 0.f}, wn = {0.f, 0.f, 0.f};
-        if (valid) load_points2(map.pts + (size_t)row * 3, map.nrm + (size_t)row * 3, wp, wn);  // voxel_grid.h:197-198
-        float4 *rec = reinterpret_cast<float4 *>(out_rec + qq);
-        reinterpret_cast<float *>(rec)[3] = wn.x;  // the source point stays
-        rec[1] = make_float4(wp.x, wp.y, wp.z, valid ? 1.f : 0.f);
-        rec[2] = make_float4(wn.y, wn.z, 0.f, 0.f);
-        if constexpr (!kChained) {
-            out_idx[qq] = valid ? (int32_t)row : -1;
-            if (out_stat) {
-                QStat st;
-                st.sq_dist = valid ? d2 : 0.f;
-                st.n_cand = st.n_occ = st.pad = 0u;
-                out_stat[qq] = st;
-            }
-        }
-    };
-    if (fast) {  // the old winner itself is a candidate within the bound: a fast query always has a winner
-        write_record(q, best_row != 0xFFFFFFFFu, best_row, best);
-        n_valid = best_row != 0xFFFFFFFFu ? 1u : 0u;
-    }
-    // ---- the queries without a bound: the wave together, one query at a time ----
-    unsigned long long slow = __ballot(live && !fast);
-    const uint32_t n_slow = (uint32_t)__popcll(slow);
-    uint32_t slow_valid = 0;
-    if (qlist && slow) {
-        // the caller launches k_match<..., kList> behind this kernel: the queries without a bound go onto its list (one
-        // returning atomic per wave; the order of the list does not matter to any result) and are not searched here
-        const int leader = (int)__builtin_ctzll(slow);
-        uint32_t base = 0;
-        if (lane == leader) base = atomicAdd(qcount, n_slow);
-        base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
-        if (live && !fast) qlist[base + (uint32_t)__popcll(slow & ((1ull << lane) - 1ull))] = q;
-        slow = 0ull;
-    }
-    while (slow) {
-        const int s = (int)__builtin_ctzll(slow);
-        slow &= slow - 1ull;
-        auto lane_f = [&](float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), s)); };
-        const float sx = lane_f(qx), sy = lane_f(qy), sz = lane_f(qz);
-        const int jx = __builtin_amdgcn_readlane(ix, s), jy = __builtin_amdgcn_readlane(iy, s), jz = __builtin_amdgcn_readlane(iz, s);
-        const bool s_inr = __builtin_amdgcn_readlane((int)inr, s) != 0;
-        const float g_s[6] = {lane_f(gx[0]), lane_f(gx[2]), lane_f(gy[0]), lane_f(gy[2]), lane_f(gz[0]), lane_f(gz[2])};
-        uint32_t cnt = 0, slab = 0;
-        if (lane < 27 && s_inr) {
-            const int dx = lane / 9 - 1, dy = (lane / 3) % 3 - 1, dz = lane % 3 - 1;
-            const int nx = jx + dx, ny = jy + dy, nz = jz + dz;
-            const bool in_range = nx > -kIdxBias && nx < kIdxBias && ny > -kIdxBias && ny < kIdxBias && nz > -kIdxBias && nz < kIdxBias;
-            // the plain bound: a voxel whose nearest face is provably farther than max_dist is not looked up
-            const float gsx = dx < 0 ? g_s[0] : (dx > 0 ? g_s[1] : 0.f);
-            const float gsy = dy < 0 ? g_s[2] : (dy > 0 ? g_s[3] : 0.f);
-            const float gsz = dz < 0 ? g_s[4] : (dz > 0 ? g_s[5] : 0.f);
-            const float lower = gsx + (gsy + gsz);
-            if (in_range && !(lower > P.max_sq * 1.0001f)) probe_slot(map, pack_key(nx, ny, nz), cnt, slab);
-        }
-        uint32_t inc = cnt;
-#pragma unroll
-        for (int d = 1; d < 32; d <<= 1) {  // lanes >= 27 hold zero: a scan over the first 32 lanes is the scan over the 27
-            const uint32_t o = (uint32_t)__shfl_up((int)inc, d, 64);
-            if (lane >= d) inc += o;
-        }
-        const uint32_t T = (uint32_t)__builtin_amdgcn_readlane((int)inc, 31);
-        if (lane < 32) {
-            s_inc[wave][lane] = inc;
-            s_row0[wave][lane] = slab * map.K - (inc - cnt);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        float bl = P.max_sq;
-        uint32_t bf = 0xFFFFFFFFu, br = 0;
-        for (uint32_t f = (uint32_t)lane; f < T; f += 64u) {  // flattened candidate f in scan order: its neighbour, its row
-            uint32_t pos = 0;
-#pragma unroll
-            for (uint32_t step = 16; step >= 1; step >>= 1)
-                if (s_inc[wave][pos + step - 1] <= f) pos += step;
-            const uint32_t row = s_row0[wave][pos] + f;
-            const f32x3 a = *reinterpret_cast<const f32x3 *>(map.pts + (size_t)row * 3);
-            const float ax = sx - a.x, ay = sy - a.y, az = sz - a.z;
-            const float d2 = ax * ax + (ay * ay + az * az);
-            if (d2 < bl) {
-                bl = d2;
-                bf = f;
-                br = row;
-            }
-        }
-        // lexicographic minimum of (distance, ordinal): d2 >= 0, so its bit pattern orders like the value
-        const uint32_t wd = wave_min_u32(__float_as_uint(bl));
-        const uint32_t wf = wave_min_u32((__float_as_uint(bl) == wd) ? bf : 0xFFFFFFFFu);
-        const bool valid = wf != 0xFFFFFFFFu;
-        const uint32_t qs = blockIdx.x * kMatchThreads + (uint32_t)(wave * 64 + s);
-        if (valid ? (bf == wf) : (lane == 0)) write_record(qs, valid, br, bl);
-        slow_valid += valid ? 1u : 0u;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();  // the tables are rewritten for the next slow query
-    }
-    // per-block counters as k_match leaves them: [0] valid matches, [1..3] not produced here
-    const uint32_t wave_valid = (uint32_t)__popcll(__ballot(n_valid != 0u)) + slow_valid;
-    if (lane == 0) {
-        s_valid[wave] = wave_valid;
-        s_slow[wave] = n_slow;
-    }
-    __syncthreads();
-    if (threadIdx.x < 4) {
-        uint32_t v = 0;
-        if (threadIdx.x == 0)
-            for (int w = 0; w < kMatchThreads / 64; w++) v += s_valid[w];
-        if (threadIdx.x == 3)  // [3]: queries searched by their wave together (k_lm does not read it: lom_debug_next_search_slow)
-            for (int w = 0; w < kMatchThreads / 64; w++) v += s_slow[w];
         block_counters[blockIdx.x * 4 + threadIdx.x] = v;
     }
 }
@@ -1740,11 +1344,8 @@ __global__ __launch_bounds__(kT) void k_lm(const MatchRec *__restrict__ rec, uin
                                                      unsigned long long report_seq,
                                                      unsigned long long timeout_ticks,
                                                      unsigned long long *dbg_stamps, P2pArgs px,
-                                                     double *dbg_trace, int test_give_up, uint32_t *list_count)
+                                                     double *dbg_trace, int test_give_up)
 {
-    // the search in front of this launch may have handed part of its queries to a second kernel through a list: its
-    // counter goes back to rest here (both search kernels are through; also when this launch returns at once below)
-    if (list_count && blockIdx.x == 0 && threadIdx.x == 0) *list_count = 0u;
     __shared__ double s_acc[(kT / 64) * 32];  // the waves' totals of one evaluation
     __shared__ double s_tot[kRecWords];
     __shared__ double s_part[kT];
@@ -2060,7 +1661,7 @@ static int scan_buffers(lom_map *m, uint32_t n, bool want_stats)
     if ((rc = ensure(m, m->scan_on, nn * sizeof(MatchRec))) != LOM_OK) return rc;
     if (want_stats && (rc = ensure(m, m->scan_stats, nn * sizeof(QStat))) != LOM_OK) return rc;
     if ((rc = ensure(m, m->partials, (size_t)kMaxEvalBlocks * kRecWords * 8)) != LOM_OK) return rc;
-    if ((rc = ensure(m, m->results, 1024 + (size_t)2 * kMaxMatchBlocks * 16)) != LOM_OK) return rc;
+    if ((rc = ensure(m, m->results, 1024 + (size_t)kMaxMatchBlocks * 16)) != LOM_OK) return rc;
     return LOM_OK;
 }
 
@@ -2072,7 +1673,7 @@ static void server_stop(lom_map *m);
 // chained: the pose comes from the AlignState in HBM (t, q unused)
 // count_mode: -1 = as the handle says (LOM_OPT_COUNT_CANDIDATES), 0 / 1 = without / with the reference-algorithm counts
 static int launch_match(ScanCtx &c, const float t[3], const float q[4], float max_sq, bool stats,
-                        bool chained = false, int count_mode = -1, bool force_next = false)
+                        bool chained = false, int count_mode = -1)
 {
     lom_map *m = c.m;
     PoseArgs P;
@@ -2110,7 +1711,7 @@ static int launch_match(ScanCtx &c, const float t[3], const float q[4], float ma
         auto launch = [&](auto kernel, QStat *st, const AlignState *as) {
             hipLaunchKernelGGL(kernel, dim3(c.match_blocks), dim3(kMatchThreads), 0, m->stream, view_of(m), c.d_src, c.stride,
                                c.n, P, (int32_t *)m->scan_idx.p, (MatchRec *)m->scan_on.p, st, d_block_counters(m),
-                               (unsigned long long *)nullptr, as, (const uint32_t *)nullptr, (const uint32_t *)nullptr);
+                               (unsigned long long *)nullptr, as);
         };
         QStat *st = (stats && !chained) ? (QStat *)m->scan_stats.p : (QStat *)nullptr;
         // (a chained launch always follows a search of the same scan: launch_pair's first pair is not chained)
@@ -2118,41 +1719,7 @@ static int launch_match(ScanCtx &c, const float t[3], const float q[4], float ma
         const bool count = count_mode < 0 ? m->opt_count : count_mode != 0;
         const AlignState *as = chained ? (const AlignState *)m->align_state.p : (const AlignState *)nullptr;
         constexpr int W = kMatchMinWaves;
-        // searches that follow a search of the same scan, without the reference-algorithm counts: one lane per query
-        const uint32_t next_blocks = (c.n + (uint32_t)kMatchThreads - 1) / (uint32_t)kMatchThreads;
-        // (only where the previous search was one solve earlier -- the chained launches of an align -- or where a test asks:
-        // the first search of an align that follows another align of the same scan still finds old records, but a whole
-        // alignment away)
-        if (prev && !count && !m->opt_no_next_search && next_blocks <= kMaxMatchBlocks &&
-            ((chained && c.n >= m->next_search_min) || force_next)) {
-            if (chained) {
-                // k_match_next searches the queries that can live off their old winner; the others (a few per cent) go
-                // onto a list, and the first search's kernel (16 lanes per query, with the temporal bound where there is
-                // one) takes them from there.  The list's counter is put back to zero by the k_lm that follows.
-                const void *list_before = m->scan_list.p;
-                const int rc_list = ensure(m, m->scan_list, 64 + (size_t)c.n * 4);
-                if (rc_list != LOM_OK) return rc_list;
-                if (m->scan_list.p != list_before) m->scan_list_clean = false;
-                uint32_t *qcount = (uint32_t *)m->scan_list.p, *qlist = qcount + 16;
-                if (!m->scan_list_clean) {
-                    LOM_HIP(m, hipMemsetAsync(qcount, 0, 64, m->stream));
-                    m->scan_list_clean = true;
-                }
-                const uint32_t list_blocks = std::max(64u, std::min((c.n + 127u) / 128u, kMaxMatchBlocks));
-                hipLaunchKernelGGL(k_match_next<true>, dim3(next_blocks), dim3(kMatchThreads), 0, m->stream, view_of(m), c.n, P,
-                                   (int32_t *)m->scan_idx.p, (MatchRec *)m->scan_on.p, st, d_block_counters(m), as, qlist, qcount);
-                hipLaunchKernelGGL((k_match<kMatchG, kMatchRows, W, false, true, true, false, true>), dim3(list_blocks),
-                                   dim3(kMatchThreads), 0, m->stream, view_of(m), c.d_src, c.stride, c.n, P,
-                                   (int32_t *)m->scan_idx.p, (MatchRec *)m->scan_on.p, st, d_block_counters(m) + (size_t)next_blocks * 4,
-                                   (unsigned long long *)nullptr, as, (const uint32_t *)qlist, (const uint32_t *)qcount);
-                c.match_blocks = next_blocks + list_blocks;
-            } else {  // lom_debug_find_pairs_after: every query in the one kernel (the wave searches the ones without a bound)
-                c.match_blocks = next_blocks;
-                hipLaunchKernelGGL(k_match_next<false>, dim3(next_blocks), dim3(kMatchThreads), 0, m->stream, view_of(m), c.n, P,
-                                   (int32_t *)m->scan_idx.p, (MatchRec *)m->scan_on.p, st, d_block_counters(m), as,
-                                   (uint32_t *)nullptr, (uint32_t *)nullptr);
-            }
-        } else if (chained) {
+        if (chained) {
             if (prev && count) launch(k_match<kMatchG, kMatchRows, W, false, true, true, true>, st, as);
             else if (prev) launch(k_match<kMatchG, kMatchRows, W, false, true, true, false>, st, as);
             else if (count) launch(k_match<kMatchG, kMatchRows, W, false, true, false, true>, st, as);
@@ -2164,7 +1731,6 @@ static int launch_match(ScanCtx &c, const float t[3], const float q[4], float ma
             else launch(k_match<kMatchG, kMatchRows, W, false, false, false, false>, st, as);
         }
         LOM_HIP(m, hipGetLastError());
-        m->last_match_blocks = c.match_blocks;
         c.counted = count;
         c.have_prev = true;
         if (m->profiling) LOM_HIP(m, hipEventRecord(e1, m->stream));
@@ -2490,8 +2056,7 @@ static int align_chained(lom_map *m, const char *d_src, size_t n, size_t stride,
                                (const uint32_t *)d_block_counters(m), c.match_blocks, (XWord *)m->xrec.p, m->lm_seq,
                                reinterpret_cast<AlignReport *>(m->d_report), seq0 + (unsigned long long)i + 1,
                                m->patience_ticks, dbg, px,
-                               (d_trace && i == trace_outer) ? d_trace : (double *)nullptr, i == give_up_outer ? 1 : 0,
-                               (uint32_t *)m->scan_list.p);
+                               (d_trace && i == trace_outer) ? d_trace : (double *)nullptr, i == give_up_outer ? 1 : 0);
         };
         if (shape == kLmSmall)
             launch(k_lm<(int)kLmSmallThreads>);
@@ -2541,7 +2106,6 @@ static int align_chained(lom_map *m, const char *d_src, size_t n, size_t stride,
             (void)hipStreamSynchronize(m->stream);
             m->report_seq = want;
             m->align_state_dirty = true;
-            m->scan_list_clean = false;
             set_error(m, LOM_ERR_HIP, "device solve: a workgroup timed out waiting for the others");
             return kDeviceLoopGaveUp;
         }
@@ -2725,7 +2289,7 @@ static int64_t find_pairs_core(lom_map *m, const float *src, size_t n, size_t st
     if ((rc = scan_buffers(m, (uint32_t)n, true)) != LOM_OK) return rc;
     ScanCtx c{m, d_src, stride, (uint32_t)n, 0};
     if (t0 && q0 && (rc = launch_match(c, t0, q0, max_sq, true)) != LOM_OK) return rc;
-    if ((rc = launch_match(c, t, q, max_sq, true, false, -1, t0 && q0)) != LOM_OK) return rc;
+    if ((rc = launch_match(c, t, q, max_sq, true)) != LOM_OK) return rc;
     std::vector<int32_t> idx(n);
     std::vector<MatchRec> on(n);
     std::vector<QStat> st(n);
@@ -3017,20 +2581,6 @@ int lom_debug_lm_trace(lom_map *m, const float *src, size_t n, size_t stride, co
 }
 
 // diagnostic: per-workgroup phase stamps of one correspondence launch (shader clock ticks)
-int64_t lom_debug_next_search_slow(lom_map *m)
-{
-    if (!m) return LOM_ERR_ARG;
-    LOM_HIP(m, hipSetDevice(m->device));
-    const uint32_t nb = m->last_match_blocks;
-    if (!nb || !m->results.p) return 0;
-    std::vector<uint32_t> h((size_t)nb * 4);
-    LOM_HIP(m, hipMemcpyAsync(h.data(), d_block_counters(m), h.size() * 4, hipMemcpyDeviceToHost, m->stream));
-    LOM_HIP(m, hipStreamSynchronize(m->stream));
-    int64_t slow = 0;
-    for (uint32_t b = 0; b < nb; b++) slow += h[(size_t)b * 4 + 3];
-    return slow;
-}
-
 int lom_debug_match_stamps(lom_map *m, const float *d_src, size_t n, size_t stride, const float t[3],
                            const float q[4], float max_dist, unsigned long long *stamps_out, size_t cap_blocks,
                            uint32_t *n_blocks_out)

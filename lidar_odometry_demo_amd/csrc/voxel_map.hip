@@ -1969,8 +1969,6 @@ int lom_map_create(float voxel_size, size_t max_points, size_t capacity_hint, in
     m->opt_debug_lm_twice = getenv("LOM_DEBUG_LM_TWICE") != nullptr;
     m->opt_debug_timing = getenv("LOM_DEBUG_TIMING") != nullptr;
     m->opt_no_temporal = getenv("LOM_NO_TEMPORAL") != nullptr;
-    m->opt_no_next_search = getenv("LOM_NO_NEXT_SEARCH") != nullptr;
-    if (const char *e = getenv("LOM_NEXT_SEARCH_MIN")) m->next_search_min = (uint32_t)std::max(0, atoi(e));
     if (const char *e = getenv("LOM_COUNT_CANDIDATES")) m->opt_count = atoi(e) != 0;
     m->opt_no_bulk = getenv("LOM_NO_BULK_INSERT") != nullptr;
     if (const char *e = getenv("LOM_BULK_PPT")) m->bulk_ppt = (uint32_t)atoi(e);  // development: points per thread of k_bi_claim
@@ -2064,7 +2062,6 @@ int lom_map_set_option(lom_map *m, int option, int64_t value)
     case LOM_OPT_NO_TEMPORAL_BOUND: m->opt_no_temporal = value != 0; return LOM_OK;
     case LOM_OPT_COUNT_CANDIDATES: m->opt_count = value != 0; return LOM_OK;
     case LOM_OPT_NO_BULK_INSERT: m->opt_no_bulk = value != 0; return LOM_OK;
-    case LOM_OPT_NO_NEXT_SEARCH: m->opt_no_next_search = value != 0; return LOM_OK;
     case LOM_OPT_TEST_BULK_PARTITION_MAX:
         if (value < 0 || value > (int64_t)kBiPartMax) return LOM_ERR_ARG;
         m->test_bulk_part_max = (uint32_t)value;

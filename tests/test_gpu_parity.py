@@ -1197,45 +1197,11 @@ def test_no_temporal_switch_gives_the_same_align(lom, oracle):
     assert res[(0, 0)][2] == res[(1, 0)][2]
 
 
-def test_one_lane_per_query_search_equals_the_row_search(lom, oracle, fixture_cloud):
-    """Outer iterations >= 2 of an align search with one lane per query (k_match_next: the old winner's bound, the few
-    voxels it leaves, the rest of the wave together for queries without a bound); LOM_OPT_NO_NEXT_SEARCH keeps them on
-    the first search's kernel.  Same pose bits, same iteration counts, same valid matches -- on the small synthetic
-    case (guesses from close to far: with the far ones many queries lose their old winner's voxel), on the reference's
-    scan with short voxels, and with queries at the rim of the index range."""
-    sm = scenes.small_synth_case()
-    _, xyzn = fixture_cloud
-    cases = [(0.5, 20, sm["map_xyz"], sm["map_nrm"], sm["scan"]),
-             (0.2, 3, xyzn[:, :3], xyzn[:, 3:], np.ascontiguousarray(xyzn[::5, :3]))]
-    guesses = [((0.0, 0.0, 0.0), (1, 0, 0, 0)), ((0.2, -0.2, 0.0), scenes.angle_axis_q(0.01, (0, 0, 1))),
-               ((0.6, 0.5, -0.1), scenes.angle_axis_q(0.05, (0, 0, 1))), ((3.0, -2.0, 0.5), scenes.angle_axis_q(0.3, (0, 1, 0)))]
-    for voxel, K, mx, mn, scan in cases:
-        res = {}
-        for off in (0, 1):
-            g, og = _both(lom, oracle, voxel, K)
-            g.setOption(lom.capi.OPT_NO_NEXT_SEARCH, off)
-            g.addCloud(mx, mn)
-            m = lom.CloudMatcher()
-            out = []
-            for t, q in guesses:
-                p = m.align(g, scan, lom.Pose3D(t, q))
-                out.append((p.translation.tobytes(), p.rotation.tobytes(),
-                            tuple(m.stats[k] for k in ("outer_iterations", "lm_iterations", "evaluations", "queries", "valid_last"))))
-            res[off] = out
-        assert res[0] == res[1]
-        og.addCloud(mx, mn)
-        om = oracle.CloudMatcher()
-        r = om.align(og, scan, oracle.Pose3D(*guesses[1]))
-        g2 = lom.VoxelGrid(voxel, K)
-        g2.addCloud(mx, mn)
-        m2 = lom.CloudMatcher()
-        p = m2.align(g2, scan, lom.Pose3D(*guesses[1]))
-        dt, dr = scenes.pose_delta(p.translation, p.rotation, r.translation, r.rotation)
-        assert dt < POSE_TOL_M and dr < POSE_TOL_RAD
-        for k in ("outer_iterations", "lm_iterations", "queries", "valid_last"):
-            assert m2.stats[k] == om.stats[k], k
-        assert m2.stats["evaluations"] == om.stats["points_evaluated"]
-    # the second of two searches, entry for entry against the oracle: far moves, the index range's rim, empty space
+def test_second_search_far_moves_rim_and_empty_space(lom, oracle):
+    """The second of two searches of one scan (what outer iterations >= 2 of an align run, with the previous winner's
+    bound where there is one), entry for entry against the oracle: millimetre and far moves between the two, queries at
+    the rim of the index range (neighbours beyond it cannot exist), queries in empty space, voxels smaller than the
+    search radius."""
     rng = np.random.default_rng(17)
     g, og = _both(lom, oracle, 0.5, 20)
     far = np.float32(0.5 * ((1 << 20) - 4))
