@@ -369,7 +369,7 @@ def concurrent_contexts(lom, torch, grid, d_scan, guess, steps, counts=(2, 3, 4,
 def traffic_record(config):
     """HBM-side bytes per k_match launch as last collected with rocprofv3 --pmc (tools/collect_traffic.py; FETCH_SIZE
     doubled + WRITE_SIZE, MI355X_MICROARCH.md): a constant from profiles/, NOT a measurement of this run."""
-    for tag in ("r03", "r02", "r01"):
+    for tag in ("r04", "r03", "r02", "r01"):
         tpath = os.path.join(ROOT, "profiles", f"traffic_{tag}.json" if config == "C2" else f"traffic_{tag}_{config.lower()}.json")
         if os.path.exists(tpath):
             with open(tpath) as f:
@@ -771,14 +771,17 @@ def main():
              "note": "a latency chain, not a stream: per evaluation one pass over <= 1 point per lane, a workgroup "
                      "reduction, one exchange between the workgroups through HBM and a serial 6x6 policy step on one "
                      "wave; phase stamps and SQ counters in profiles/"},
-            {"kernel": "insert chain of the bulk map build (k_ins_claim2, k_ins_heads, scan, k_ins_assign, "
-                       "k_ins_scatter2, k_ins_place2)",
+            {"kernel": "insert chain of the bulk map build (k_bi_claim, k_bi_colscan, k_bi_scatter, k_bi_group, "
+                       "k_bi_flagscan, k_bi_place)",
              "algorithmic_bytes_per_launch": ins_bytes, "avg_us": insert_us,
              "gbs": ins_bytes / (insert_us * 1e-6) / 1e9, "frac_of_hbm_peak": ins_bytes / (insert_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
              "bytes_note": "per input point 24 B read (point, normal) + one 16-B slot; per stored point 24 B written",
              "points": n_map, "stored": stored,
              "note": "one call, all kernels under one HIP event pair; per-kernel split in profiles/ (kernel stats); "
-                     "bound by scattered device-scope atomics (3 per point), not by bytes"},
+                     "the partitioned bulk insert (one slot look per point, a compare-and-swap per new voxel, everything per "
+                     "voxel in LDS, slab rows written side by side): bound by the scattered passes of the partition (16-byte "
+                     "records) and of the place kernel's gather of the input rows, not by bytes; the four-kernel path of "
+                     "batches up to 65,536 points takes 2.5-3x as long (tools/ab_insert.py, profiles/r04_i_ab_insert.txt)"},
         ]
         bsorted = sorted(block_ms)
         line = {

@@ -393,7 +393,10 @@ int lom_comm_finalize(lom_map *m);
 typedef struct lom_host_comm lom_host_comm;
 int lom_comm_host_id(char id_out[LOM_COMM_ID_BYTES]);
 int lom_host_comm_create(int rank, int nranks, const char id[LOM_COMM_ID_BYTES], lom_host_comm **out);
-int lom_host_comm_allreduce(lom_host_comm *c, double *buf, int count); /* in place, count <= LOM_NSUMS */
+/* in place, count <= LOM_NSUMS.  LOM_ERR_COMM: a rank did not arrive within the deadline (lom_host_comm_set_timeout) or had
+ * abandoned an exchange; the object stays broken on every rank from then on.  On the exchange a rank gives up on, a peer
+ * that had just completed it may still return LOM_OK -- it fails at its next exchange, at once (csrc/comm.cpp exchange()). */
+int lom_host_comm_allreduce(lom_host_comm *c, double *buf, int count);
 /* Deadline of one exchange (default 60 s).  A rank that reaches it ABANDONS the exchange object: it marks its
  * slots, so that every rank still waiting for it -- or arriving later -- fails with LOM_ERR_COMM as well instead
  * of pairing with slots their owner has walked away from; all later calls on the object fail at once.

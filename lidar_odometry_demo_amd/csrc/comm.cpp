@@ -129,6 +129,14 @@ void abandon(lom_host_comm *hc, const std::string &why)
 // `take(r, slot)` consumes rank r's payload in rank order.  Double buffered: a rank can start exchange k+2
 // only after every rank finished k+1, i.e. after every rank is done reading exchange k, whose buffer it
 // then reuses.
+// What the return value does NOT promise: that every rank returns the same.  Slots are consumed in rank order and a
+// rank gives up by its own clock, so a rank that has taken rank A's slot and then sees the late rank publish returns
+// LOM_OK while A -- waiting for the same late rank -- reaches its deadline in that instant and returns LOM_ERR_COMM
+// (the two-generals residue of any deadline; a second "done" round would only move the window).  What IS promised: the
+// object is broken from then on for everybody -- A marked both its slots, so the ranks that came through fail at
+// their NEXT exchange, at once.  For the agreement after a device-to-device align (match.hip align_device) this means:
+// in that one instant a rank may return the align's pose with LOM_OK while a peer returns LOM_ERR_COMM for the same
+// align; the rank that came through learns it at its next call, which fails at once instead of computing alone.
 template <typename Take>
 int exchange(lom_host_comm *hc, HostSlot *slots, unsigned long long seq, double timeout_s, Take take)
 {
