@@ -291,7 +291,11 @@ typedef enum {
     LOM_OPT_HOST_LM = 1,               /* 1: outer loop and LM policy on the host (one round trip per LM iteration) */
     LOM_OPT_DEVICE_PATIENCE_TICKS = 2, /* bound of every in-kernel wait, ticks of 10 ns; default 5,000,000 = 50 ms.
                                           Waits for a peer RANK take ten times that; the host-side agreement after
-                                          a device-to-device align outlasts both (see lom_comm_attach_p2p). */
+                                          a device-to-device align outlasts both (see lom_comm_attach_p2p).  A patience
+                                          below 40 ticks -- shorter than the head start k_lm's gather sleeps before its
+                                          first poll -- counts as timed out whatever the poll would find: that is what
+                                          makes "1 tick" a deterministic way for the tests to force the give-up path, and
+                                          it means values below 0.4 us are not a usable patience for anything else. */
     LOM_OPT_DEBUG_LM_STAMPS = 3,       /* 1: print k_lm's phase stamps after every align (stderr) */
     LOM_OPT_DEBUG_TIMING = 4,          /* 1: print host launch / wait times per evaluation (stderr) */
     LOM_OPT_NO_TEMPORAL_BOUND = 5,     /* 1: every correspondence search prunes at max_dist only.  Default 0: the searches

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Turn the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs, as
 MI355X_MICROARCH.md prescribes) of `bench.py --steps 5 --warmup 1 --no-cpu-baseline` into
-profiles/traffic_<tag>.json:   collect_traffic.py <fetch_dir> <write_dir> <out.json> [commit] [C2|C3]
+profiles/traffic_<tag>.json:   collect_traffic.py <fetch_dir> <write_dir> <out.json> [commit] [C2|C3|C4]
 
 FETCH_SIZE / WRITE_SIZE count kilobytes.  On gfx950 FETCH_SIZE under-counts 16-B/lane streams by
 1/2 (guide, HBM section; checked in this repo on k_eval's clean stream, profiles history r01_c), so
@@ -27,10 +27,11 @@ def per_kernel(root, counter):
 
 fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
 config = sys.argv[5] if len(sys.argv) > 5 else "C2"
-n_queries = {"C2": 26642, "C3": 123944}[config]
+n_queries = {"C2": 26642, "C3": 123944, "C4": 247951}[config]
 out = {"command": "rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE (separate passes) --output-format csv -- "
                   "python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras" + ("" if config == "C2" else " --config " + config),
-       "workload": {"C2": "C2 (26,642 queries vs 499,975-pt map)", "C3": "C3 (123,944 queries vs 2M-pt map, 1,776,862 stored)"}[config],
+       "workload": {"C2": "C2 (26,642 queries vs 499,975-pt map)", "C3": "C3 (123,944 queries vs 2M-pt map, 1,776,862 stored)",
+                    "C4": "C4 on one GPU (247,951 queries vs 2M-pt map, 1,776,862 stored)"}[config],
        "config": config,
        "commit": (sys.argv[4] if len(sys.argv) > 4 else "?"), "raw_counters_kb_per_dispatch": {}}
 for name, acc in (("FETCH_SIZE", fetch), ("WRITE_SIZE", write)):
