@@ -49,10 +49,13 @@ constexpr int kEvalThreads = 512;
 // quarter back as its temporal pruning bound)
 struct __attribute__((aligned(16))) MatchRec {
     float px, py, pz, nx;     // source_point_local (voxel_grid.h:226), plane_normal.x
-    float ox, oy, oz, valid;  // plane_origin; valid = 1.0f / 0.0f
+    float ox, oy, oz, valid;  // plane_origin; valid: 0.0f = no match, else the bits kRecValid | the winner's row in the slabs
+                              // (never zero, never a denormal: consumers test `!= 0.f`; the next search of the same scan
+                              // reads the row back: a query whose winner has not changed leaves its record alone)
     float ny, nz, pad0, pad1;
 };
 static_assert(sizeof(MatchRec) == 48, "three dwordx4");
+constexpr uint32_t kRecValid = 0x40000000u;  // rows below 2^30 are told apart (a larger map still matches, it only rewrites)
 
 // per-query debug record written by k_match for lom_match_find_pairs
 struct __attribute__((aligned(8))) QStat {
@@ -581,20 +584,26 @@ __global__ __launch_bounds__(kMatchThreads, kMinWaves) void k_match(MapView map,
         // trip: keeping the point in registers through the candidate loop cost three selects per candidate)
         if (valid ? (best_c == w_c) : (gl == 0)) {
             int32_t idx = -1;
-            f32x3 wp = {0.f, 0.f, 0.f}, wn = {0.f, 0.f, 0.f};
-            if (valid) {
-                const size_t pi = (size_t)best_pi0 + (best_c & 3u);
-                idx = (int32_t)pi;
-                load_points2(map.pts + pi * 3, map.nrm + pi * 3, wp, wn);  // voxel_grid.h:197-198
+            const size_t pi = (size_t)best_pi0 + (best_c & 3u);
+            const uint32_t mark = valid ? (kRecValid | (uint32_t)pi) : 0u;
+            if (valid) idx = (int32_t)pi;
+            // Outer iterations >= 2: most queries find the winner they had (the pose moves by millimetres).  Such a query's
+            // record -- point, normal, mark -- is what it would write again: neither the winner's point and normal are
+            // fetched (the last of the query's dependent round trips) nor anything stored.
+            bool same = false;
+            if constexpr (kPrev) same = __float_as_uint(pv.w) == mark && pi < (size_t)kRecValid;
+            if (!same) {
+                f32x3 wp = {0.f, 0.f, 0.f}, wn = {0.f, 0.f, 0.f};
+                if (valid) load_points2(map.pts + pi * 3, map.nrm + pi * 3, wp, wn);  // voxel_grid.h:197-198
+                float4 *rec = reinterpret_cast<float4 *>(out_rec + q);
+                if constexpr (kPrev)
+                    reinterpret_cast<float *>(rec)[3] = wn.x;  // the source point is there since the first search of this scan
+                else
+                    rec[0] = make_float4(sp.x, sp.y, sp.z, wn.x);
+                rec[1] = make_float4(wp.x, wp.y, wp.z, __uint_as_float(mark));
+                rec[2] = make_float4(wn.y, wn.z, 0.f, 0.f);
             }
             if constexpr (!kChained) out_idx[q] = idx;  // (only lom_match_find_pairs reads it)
-            float4 *rec = reinterpret_cast<float4 *>(out_rec + q);
-            if constexpr (kPrev)
-                reinterpret_cast<float *>(rec)[3] = wn.x;  // the source point is there since the first search of this scan
-            else
-                rec[0] = make_float4(sp.x, sp.y, sp.z, wn.x);
-            rec[1] = make_float4(wp.x, wp.y, wp.z, valid ? 1.f : 0.f);
-            rec[2] = make_float4(wn.y, wn.z, 0.f, 0.f);
             if (!kChained && out_stat) {
                 QStat st;
                 st.sq_dist = valid ? best : 0.f;
