@@ -964,6 +964,24 @@ def test_bulk_insert_crowded_voxels_are_sent_back(lom, oracle):
     _assert_same_map(g, og)
 
 
+def test_bulk_insert_beyond_two_million_points(lom, oracle):
+    """Above 2,097,152 points the partitions number 16,384 and grow past 128 points on average: the group kernel's
+    1,024-point shape takes over (k_bi_group<1024>), the claim / scatter passes run eight points per thread.  One batch of
+    2.3 M points (every voxel new, caps cutting buckets), a second one over it; bytewise against the oracle."""
+    rng = np.random.default_rng(34)
+    g, og = _both(lom, oracle, 0.4, 12)
+    pts, nrm = _bulk_cloud(rng, 2_300_000, 20_000, 1.2, lo=-60, hi=60)
+    g.addCloud(pts, nrm)
+    og.addCloud(pts, nrm)
+    assert g.size() == og.size() and g.debugCounter() == 0
+    _assert_same_map(g, og)
+    more, mnrm = _bulk_cloud(rng, 2_150_000, 20_000, 1.6, lo=-60, hi=60)
+    g.addCloud(more, mnrm)
+    og.addCloud(more, mnrm)
+    assert g.debugCounter() == 0
+    _assert_same_map(g, og)
+
+
 def test_bulk_insert_range_error_inserts_nothing(lom, oracle):
     """voxel_grid.h casts unchecked; here a coordinate beyond the index range rejects the whole call (LOM_ERR_RANGE) --
     for a bulk batch too: the map is what it was, and the same batch without the bad point goes in afterwards."""
