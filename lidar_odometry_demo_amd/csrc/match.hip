@@ -1370,17 +1370,23 @@ __global__ __launch_bounds__(kT) void k_lm(const MatchRec *__restrict__ rec, uin
     const uint32_t first = blockIdx.x * blockDim.x + tid, step = nb * blockDim.x;
     // start-up loads issued together (one memory round trip, not three): this lane's first point --
     // it stays in registers for every evaluation of the solve --, the pose, the chain's stop flags
+    // (the records' loads are ISSUED here and waited for behind the other start-up loads: left to the compiler, the second
+    // register point's loads were scheduled behind the first one's wait -- two round trips where one will do; a lane
+    // beyond the cloud reads record 0 and forgets it)
+    typedef float RecQuarter __attribute__((ext_vector_type(4)));
+    RecQuarter raw_a[kRegPts], raw_b[kRegPts], raw_c[kRegPts];
     float4 ra[kRegPts], rb[kRegPts], rc[kRegPts];
+    bool have[kRegPts];
 #pragma unroll
     for (int p = 0; p < kRegPts; p++) {
-        ra[p] = rb[p] = rc[p] = make_float4(0.f, 0.f, 0.f, 0.f);
         const uint32_t i = first + (uint32_t)p * step;
-        if (i < n) {
-            const float4 *r4 = reinterpret_cast<const float4 *>(rec + i);
-            ra[p] = r4[0];
-            rb[p] = r4[1];
-            rc[p] = r4[2];
-        }
+        have[p] = i < n;
+        const MatchRec *at = rec + (have[p] ? i : 0u);
+        asm volatile("global_load_dwordx4 %0, %3, off\n\tglobal_load_dwordx4 %1, %3, off offset:16\n\t"
+                     "global_load_dwordx4 %2, %3, off offset:32"
+                     : "=&v"(raw_a[p]), "=&v"(raw_b[p]), "=&v"(raw_c[p])
+                     : "v"(at)
+                     : "memory");
     }
     // ... and, in the last wave, this lane's block of k_match's counters (reduce_and_exchange folds them)
     uint4 cnt_pre = make_uint4(0u, 0u, 0u, 0u);
@@ -1414,6 +1420,26 @@ __global__ __launch_bounds__(kT) void k_lm(const MatchRec *__restrict__ rec, uin
         prev.occ_total = cs->occ_total;
         prev.queries_total = cs->queries_total;
         if (cs->finished | cs->error) return;  // chained launch after the end
+    }
+    // ... and parked in LDS until then: eleven scalar registers less to carry (or spill) through the solve
+    __shared__ double s_prev[4];
+    __shared__ int32_t s_prev_i[3];
+    if (tid == 0) {
+        s_prev[0] = prev.valid_total;
+        s_prev[1] = prev.cand_total;
+        s_prev[2] = prev.occ_total;
+        s_prev[3] = prev.queries_total;
+        s_prev_i[0] = prev.outer_done;
+        s_prev_i[1] = prev.lm_iterations;
+        s_prev_i[2] = prev.evaluations;
+    }
+    // the records are needed from here on
+#pragma unroll
+    for (int p = 0; p < kRegPts; p++) {
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw_a[p]), "+v"(raw_b[p]), "+v"(raw_c[p])::"memory");
+        ra[p] = have[p] ? make_float4(raw_a[p].x, raw_a[p].y, raw_a[p].z, raw_a[p].w) : make_float4(0.f, 0.f, 0.f, 0.f);
+        rb[p] = have[p] ? make_float4(raw_b[p].x, raw_b[p].y, raw_b[p].z, raw_b[p].w) : make_float4(0.f, 0.f, 0.f, 0.f);
+        rc[p] = have[p] ? make_float4(raw_c[p].x, raw_c[p].y, raw_c[p].z, raw_c[p].w) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     if (tid < 7) s_x[tid] = (double)x0;  // cloud_matcher.cpp:122-131
     if (tid == 0) s_failed = test_give_up;  // LOM_OPT_TEST_GIVE_UP_AT_OUTER: this launch behaves as if its waits had timed out
@@ -1514,6 +1540,13 @@ __global__ __launch_bounds__(kT) void k_lm(const MatchRec *__restrict__ rec, uin
     if (blockIdx.x != 0 || tid != 0) return;
     // ---- end of the outer iteration (workgroup 0, one lane) ----
     const LmShared &S = kRegState ? r_lm : s_lm;
+    prev.outer_done = s_prev_i[0];
+    prev.lm_iterations = s_prev_i[1];
+    prev.evaluations = s_prev_i[2];
+    prev.valid_total = s_prev[0];
+    prev.cand_total = s_prev[1];
+    prev.occ_total = s_prev[2];
+    prev.queries_total = s_prev[3];
     const int outer = prev.outer_done;
     float pq[4], pt[3];
     for (int a = 0; a < 4; a++) pq[a] = (float)S.x[a];      // :161-164
