@@ -1389,19 +1389,28 @@ __global__ __launch_bounds__(kT) void k_lm(const MatchRec *__restrict__ rec, uin
                      : "memory");
     }
     // ... and, in the last wave, this lane's block of k_match's counters (reduce_and_exchange folds them)
+    // (both without a divergent branch around the load -- every lane loads, from a clamped address, and picks afterwards --:
+    // the compiler waits for the loads of a divergent region where the region ends, which made these two more round
+    // trips in a row behind the records')
     uint4 cnt_pre = make_uint4(0u, 0u, 0u, 0u);
-    if (kT == 256 && wave == kT / 64 - 1 && n_match_blocks) {
+    RecQuarter cnt_raw = {0.f, 0.f, 0.f, 0.f};
+    bool cnt_want = false;
+    if constexpr (kT == 256) {
         const uint32_t chunk = (n_match_blocks + nb - 1) / nb;
         const uint32_t b = blockIdx.x * chunk + (uint32_t)lane;
-        if (chunk <= 64u && (uint32_t)lane < chunk && b < n_match_blocks)
-            cnt_pre = *reinterpret_cast<const uint4 *>(block_counters + (size_t)b * 4);
+        cnt_want = wave == kT / 64 - 1 && n_match_blocks && chunk <= 64u && (uint32_t)lane < chunk && b < n_match_blocks;
+        const uint32_t *at = block_counters + (size_t)(cnt_want ? b : 0u) * 4;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(cnt_raw) : "v"(at) : "memory");  // (issued, like the records)
     }
-    float x0 = 0.f;
-    if (tid < 7) {
-        if (first_outer)
-            x0 = tid < 4 ? init.q[tid] : init.t[tid - 4];
-        else
-            x0 = tid < 4 ? state->pose_q[tid] : state->pose_t[tid - 4];
+    float x0;
+    {
+        const int k = tid < 7 ? tid : 0;
+        if (first_outer) {  // (uniform)
+            x0 = k < 4 ? init.q[k] : init.t[k - 4];
+        } else {
+            const float *from = k < 4 ? &state->pose_q[k] : &state->pose_t[k - 4];
+            x0 = *from;
+        }
     }
     // the previous outer iteration's tallies, read now (scalar loads, with everything else that starts the kernel) for
     // workgroup 0's write-back at the very end: read there they were one more memory round trip on the critical path
@@ -1434,6 +1443,9 @@ __global__ __launch_bounds__(kT) void k_lm(const MatchRec *__restrict__ rec, uin
         s_prev_i[2] = prev.evaluations;
     }
     // the records are needed from here on
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(cnt_raw)::"memory");
+    if (cnt_want)
+        cnt_pre = make_uint4(__float_as_uint(cnt_raw.x), __float_as_uint(cnt_raw.y), __float_as_uint(cnt_raw.z), __float_as_uint(cnt_raw.w));
 #pragma unroll
     for (int p = 0; p < kRegPts; p++) {
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw_a[p]), "+v"(raw_b[p]), "+v"(raw_c[p])::"memory");
