@@ -256,6 +256,9 @@ __global__ __launch_bounds__(kMatchThreads, kMinWaves) void k_match(MapView map,
     // scalar-cache miss of its own, and the LDS tables below need a barrier -- one memory round trip instead of two
     // ahead of the first probe (the loop fetches the next query's point the same way, behind the current one's work)
     constexpr int kGroups0 = kMatchThreads / G;
+    // (the chained form: the pointer to the state comes in with the kernel's first argument loads, not in a round trip
+    // of its own between the point's load and the pose's)
+    if constexpr (kChained) asm volatile("" ::"s"(state));
     const uint32_t q_first = blockIdx.x * kGroups0 + threadIdx.x / G;
     f32x3 sp_next = {0.f, 0.f, 0.f};
     // (without the counts the temporal bound decides which slots are loaded at all: the previous record travels with the
