@@ -334,22 +334,32 @@ __global__ __launch_bounds__(kThreads) void k_fe_planar(const float4 *__restrict
         const float4 *row = org + (size_t)(ray - 1u) * W;
         int found = 0;
         float L0 = 0.f, L1 = 0.f, L2 = 0.f, R0 = 0.f, R1 = 0.f, R2 = 0.f;
-        for (uint32_t q = col - 4u; q < col; q++) {  // :116-123 first from the left
-            const float4 nb = row[q];
-            if ((double)nb.w < flat10) {
-                L0 = nb.x, L1 = nb.y, L2 = nb.z;
-                found++;
-                break;
+        // the eight neighbours of the previous ring, all loaded before any is looked at (a loop that stops at the first
+        // hit asks for them one round trip after the other); then the reference's two scans over the loaded values
+        float4 nbl[4], nbr[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            nbl[t] = row[col - 4u + (uint32_t)t];  // :116 q = col - 4 .. col - 1
+            nbr[t] = row[col + 4u - (uint32_t)t];  // :125 q = col + 4 .. col + 1
+        }
+        bool hit = false;
+#pragma unroll
+        for (int t = 0; t < 4; t++) {  // :116-123 first from the left
+            if (!hit && (double)nbl[t].w < flat10) {
+                L0 = nbl[t].x, L1 = nbl[t].y, L2 = nbl[t].z;
+                hit = true;
             }
         }
-        for (uint32_t q = col + 4u; q > col; q--) {  // :125-132 first from the right
-            const float4 nb = row[q];
-            if ((double)nb.w < flat10) {
-                R0 = nb.x, R1 = nb.y, R2 = nb.z;
-                found++;
-                break;
+        found += hit ? 1 : 0;
+        hit = false;
+#pragma unroll
+        for (int t = 0; t < 4; t++) {  // :125-132 first from the right
+            if (!hit && (double)nbr[t].w < flat10) {
+                R0 = nbr[t].x, R1 = nbr[t].y, R2 = nbr[t].z;
+                hit = true;
             }
         }
+        found += hit ? 1 : 0;
         if (found != 2) continue;
         const float a0 = L0 - pt.x, a1 = L1 - pt.y, a2 = L2 - pt.z;
         const float b0 = R0 - pt.x, b1 = R1 - pt.y, b2 = R2 - pt.z;
