@@ -417,6 +417,7 @@ struct lom_frontend {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     void *h_stage = nullptr;  // pinned bounce buffer for the raw frame
+    void *d_stage_view = nullptr;  // ... as the device sees it (looked up once per allocation, not per frame)
     size_t h_stage_bytes = 0;
     hipEvent_t stage_ev = nullptr, done_ev = nullptr;
     lom_point_xyzirt *d_in = nullptr, *d_desk = nullptr;
@@ -601,9 +602,8 @@ int lom_frontend_process(lom_frontend *f, const lom_point_xyzirt *pts, size_t n,
         if (bytes) FE_HIP(f, hipMemcpyAsync(f->d_in, f->h_stage, bytes, hipMemcpyHostToDevice, f->stream));
         FE_HIP(f, hipEventRecord(f->stage_ev, f->stream));
     } else {
-        void *dev_view = nullptr;
-        FE_HIP(f, hipHostGetDevicePointer(&dev_view, f->h_stage, 0));
-        stats_in = static_cast<const lom_point_xyzirt *>(dev_view);
+        if (!f->d_stage_view) FE_HIP(f, hipHostGetDevicePointer(&f->d_stage_view, f->h_stage, 0));
+        stats_in = static_cast<const lom_point_xyzirt *>(f->d_stage_view);
         stats_keep = f->d_in;
     }
     FrameConst F;
@@ -645,6 +645,7 @@ int lom_frontend_stage(lom_frontend *f, size_t n, lom_point_xyzirt **out)
     if (bytes > f->h_stage_bytes) {
         if (f->h_stage) FE_HIP(f, hipHostFree(f->h_stage));
         f->h_stage = nullptr;
+        f->d_stage_view = nullptr;
         f->h_stage_bytes = 0;
         const size_t nb = std::max(bytes + bytes / 2, (size_t)1 << 20);
         FE_HIP(f, hipHostMalloc(&f->h_stage, nb, hipHostMallocDefault));
