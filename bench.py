@@ -298,6 +298,8 @@ def streaming(args, lom, steps=None, warmup=None, cpu_frames=40):
                    "points_per_frame": int(np.mean([len(f) for f in frames])),
                    "keyframe_voxels": odo.stats["keyframe_voxels"],
                    "frames_redone_on_host_or_scans_redone": odo.debugCounter(),
+                   "frames_sent_ahead_during_the_previous_align": odo.debugCounter(lom.capi.COUNTER_FRAMES_SENT_AHEAD),
+                   "cleanup_scans_behind_the_align": odo.debugCounter(lom.capi.COUNTER_CLEANUPS_BEHIND_ALIGN),
                    "matching_points_last": odo.stats["matching_points"],
                    "drift_translation_m": float(np.linalg.norm(pose.translation.astype(np.float64) - gt_t)),
                    "drift_rotation_rad": 2.0 * float(np.arccos(min(1.0, dq))),

@@ -98,6 +98,13 @@ int lom_map_add_points_device_nowait(lom_map *m, const float *d_xyz, const float
                                      size_t stride_bytes);
 int lom_map_status(lom_map *m);
 int lom_map_radius_cleanup(lom_map *m, const float center[3], float radius); /* :236-246 */
+/* src/lidar_odometry.cpp:65-67 calls radiusCleanup with the translation the align has just returned.  A caller that will
+ * do the same arms this before lom_match_align_device: the device-resident align then enqueues the cleanup's scan (it
+ * only reads the map and writes scratch) behind its last solve, with the centre taken from its own result in HBM, and
+ * the lom_map_radius_cleanup that follows takes that scan's result if -- and only if -- its centre and radius are
+ * bit for bit what the scan used and the map has not been touched in between; otherwise it runs as if this had never
+ * been called.  One shot (the next align only), map handles only (not scan contexts); results never differ. */
+int lom_map_radius_cleanup_after_align(lom_map *m, float radius);
 int64_t lom_map_size(const lom_map *m);        /* number of voxels, :248-251 */
 int64_t lom_map_point_count(const lom_map *m); /* number of stored points */
 
@@ -336,11 +343,19 @@ typedef enum {
 int lom_map_set_option(lom_map *m, int option, int64_t value);
 /* diagnostics: LOM_COUNTER_GRID_REDOS = calls of this handle redone with the multi-launch scan after an
  * in-kernel scan gave up (such a call changes nothing; see csrc/grid_scan.hpp) */
-enum { LOM_COUNTER_GRID_REDOS = 0 };
+enum { LOM_COUNTER_GRID_REDOS = 0,
+       LOM_COUNTER_CLEANUPS_BEHIND_ALIGN = 1, /* radius cleanups that took the scan enqueued behind an align */
+       LOM_COUNTER_FRAMES_SENT_AHEAD = 2      /* lom_odometry only: frames found in pinned memory already (staged during the previous frame's align) */ };
 int64_t lom_map_debug_counter(const lom_map *m, int which);
 
 /* make the handle's stream wait for a hipEvent_t recorded elsewhere */
 int lom_map_wait_event(lom_map *m, void *hip_event);
+/* The device-resident align keeps the calling thread waiting for ~0.1 ms with nothing to do.  A caller with host work
+ * that does not depend on the align's result (staging the next frame) hands it over here: fn(user) is called ONCE, by the
+ * next lom_match_align_device on this handle, on the calling thread, after the align's kernels are enqueued and before it
+ * waits for their report.  One shot; fn must not use this handle.  (An align that takes the host-driven path does not
+ * call it: the caller checks whether its work was done.) */
+int lom_map_set_align_idle_hook(lom_map *m, void (*fn)(void *user), void *user);
 /* run the handle's work on a caller-owned hipStream_t (NULL = handle's own stream) */
 int lom_map_set_stream(lom_map *m, void *hip_stream);
 /* the hipStream_t the handle currently works on (to put several handles on one stream) */
@@ -600,6 +615,13 @@ int lom_odometry_process_cloud(lom_odometry *o, const lom_point_xyzirt *pts, siz
  * fails and returns its status; *done = frames processed */
 int lom_odometry_process_sequence(lom_odometry *o, const lom_point_xyzirt *const *frames, const size_t *n, size_t count,
                                   size_t *done);
+/* A caller that already holds the frame that comes after the next lom_odometry_process_cloud (a recorded sequence; a
+ * driver that buffers) says so here: while that call's align runs -- its thread would only watch the report -- the hinted
+ * frame is copied into the front end's pinned staging buffer, and the process_cloud that then comes with exactly this
+ * pointer and size skips that copy (8 us of a C5 frame).  The buffer must stay unchanged until that call has returned.
+ * Host work only; poses and counts never differ; a hint that is not followed by its frame costs one copy.
+ * lom_odometry_process_sequence hints frame i + 1 before frame i by itself. */
+int lom_odometry_hint_next(lom_odometry *o, const lom_point_xyzirt *pts, size_t n);
 int lom_odometry_get_pose(const lom_odometry *o, lom_pose *out);   /* getCurrentPose, :87-89 */
 /* getTempCloud(), lidar_odometry.h:73-75 (the node publishes it as /deskewed_cloud,
  * lidar_odometry_node.cpp:66-75): the time-normalised, deskewed input cloud of the last processCloud

@@ -171,6 +171,11 @@ class VoxelGrid:
     def radiusCleanup(self, point, radius):                # voxel_grid.h:236-246
         capi.check(capi.lib().lom_map_radius_cleanup(self._h, capi.f3(point), float(radius)), self._h)
 
+    def radiusCleanupAfterAlign(self, radius):
+        """Arm the next align on this grid to enqueue the scan of radiusCleanup(<its result translation>, radius) behind
+        itself (lidar_odometry.cpp:65-67's pattern); the radiusCleanup that follows takes it if its arguments match."""
+        capi.check(capi.lib().lom_map_radius_cleanup_after_align(self._h, float(radius)), self._h)
+
     def findMatchingPairs(self, xyz, transform, max_correspondence_distance=0.3):
         """voxel_grid.h:206-234; one entry per source point in source order (index < 0: no match)."""
         xyz = capi.xyz_array(xyz)
@@ -554,6 +559,15 @@ class LidarOdometry:
         if rc != 0:
             text = capi.lib().lom_odometry_last_error(self._h)
             raise LomError(int(rc), text.decode() if text else "")
+
+    def hintNext(self, cloud):
+        """The frame that will come after the next processCloud (lom_odometry_hint_next): its upload is sent ahead while
+        that call's align runs.  The array is kept alive here until the hint is replaced."""
+        self._hinted = _cloud(cloud)
+        rc = capi.lib().lom_odometry_hint_next(self._h, self._hinted.ctypes.data, len(self._hinted))
+        if rc != 0:
+            raise LomError(int(rc), "lom_odometry_hint_next")
+        return self._hinted
 
     def processSequence(self, clouds):
         """processCloud of every frame of `clouds`, in order, issued from compiled code (lom_odometry_process_sequence): the

@@ -112,16 +112,16 @@ EXPORTED = [
     "lom_abi_version", "lom_device_count", "lom_device_local_cpus", "lom_pose_identity", "lom_pose_compose", "lom_pose_inverse",
     "lom_pose_relative_to", "lom_pose_rotation_matrix", "lom_transform_points", "lom_map_create",
     "lom_map_destroy", "lom_last_error", "lom_map_clear", "lom_map_set_max_points", "lom_map_add_points",
-    "lom_map_add_points_device", "lom_map_add_points_device_nowait", "lom_map_status", "lom_map_radius_cleanup", "lom_map_size", "lom_map_point_count",
+    "lom_map_add_points_device", "lom_map_add_points_device_nowait", "lom_map_status", "lom_map_radius_cleanup", "lom_map_radius_cleanup_after_align", "lom_map_size", "lom_map_point_count",
     "lom_map_export", "lom_voxel_downsample", "lom_voxel_downsample_device", "lom_upload_points",
     "lom_transform_points_device", "lom_map_get_stream", "lom_match_find_pairs", "lom_match_find_pairs_sq", "lom_debug_find_pairs_after", "lom_match_align", "lom_match_align_device", "lom_match_align_repeat", "lom_debug_match_stamps", "lom_debug_eval_sums", "lom_debug_lm_trace",
     "lom_map_set_profiling", "lom_profile_match", "lom_profile_insert", "lom_map_set_stream", "lom_comm_unique_id", "lom_comm_init",
     "lom_comm_finalize", "lom_comm_host_id", "lom_host_comm_create", "lom_host_comm_allreduce",
     "lom_host_comm_destroy", "lom_host_comm_allgather", "lom_comm_attach_host", "lom_comm_attach_p2p", "lom_align_with_hooks", "lom_point_time_normalize", "lom_transform_non_rigid",
     "lom_range_filter", "lom_cloud_classify", "lom_odometry_default_params", "lom_odometry_create",
-    "lom_odometry_destroy", "lom_odometry_process_cloud", "lom_odometry_process_sequence", "lom_odometry_get_pose", "lom_odometry_get_stats", "lom_odometry_get_temp_cloud", "lom_odometry_debug_set_state",
+    "lom_odometry_destroy", "lom_odometry_process_cloud", "lom_odometry_process_sequence", "lom_odometry_hint_next", "lom_odometry_get_pose", "lom_odometry_get_stats", "lom_odometry_get_temp_cloud", "lom_odometry_debug_set_state",
     "lom_odometry_keyframe", "lom_odometry_last_error", "lom_pcd_read", "lom_pcd_last_error", "lom_estimate_normals", "lom_frontend_create", "lom_frontend_destroy", "lom_frontend_last_error",
-    "lom_frontend_process", "lom_frontend_results", "lom_frontend_wait", "lom_frontend_fetch", "lom_frontend_stream", "lom_frontend_stage", "lom_frontend_done_event", "lom_map_wait_event", "lom_frontend_sequence", "lom_map_status_words", "lom_debug_sinf",
+    "lom_frontend_process", "lom_frontend_results", "lom_frontend_wait", "lom_frontend_fetch", "lom_frontend_stream", "lom_frontend_stage", "lom_map_set_align_idle_hook", "lom_frontend_done_event", "lom_map_wait_event", "lom_frontend_sequence", "lom_map_status_words", "lom_debug_sinf",
     "lom_voxel_downsample_device_nowait", "lom_map_read_device_words", "lom_map_read_device_words_begin", "lom_map_read_device_words_end",
     "lom_pointcloud2_unpack", "lom_pointcloud2_layout", "lom_pointcloud2_pack_xyz", "lom_pointcloud2_last_error",
     "lom_map_set_option", "lom_map_debug_counter", "lom_odometry_set_option", "lom_odometry_debug_counter",
@@ -136,6 +136,8 @@ OPT_TEST_GIVE_UP_AT_OUTER, OPT_TEST_GRID_GIVE_UP, OPT_TEST_FORCE_HOST_REDO = 100
 OPT_NO_BULK_INSERT, OPT_TEST_BULK_PARTITION_MAX = 7, 106
 OPT_TEST_GRID_GIVE_UP_MATCHING_DS, OPT_TEST_GRID_GIVE_UP_UPDATE_DS, OPT_TEST_GRID_GIVE_UP_KEYFRAME = 103, 104, 105
 COUNTER_GRID_REDOS = 0
+COUNTER_CLEANUPS_BEHIND_ALIGN = 1
+COUNTER_FRAMES_SENT_AHEAD = 2
 
 _lib = None
 
@@ -195,6 +197,7 @@ def lib():
     L.lom_map_add_points_device_nowait.argtypes = [vp, vp, vp, C.c_size_t, C.c_size_t]
     L.lom_map_status.argtypes = [vp]
     L.lom_map_radius_cleanup.argtypes = [vp, fp, C.c_float]
+    L.lom_map_radius_cleanup_after_align.argtypes = [vp, C.c_float]
     L.lom_map_size.argtypes = [vp]
     L.lom_map_size.restype = C.c_int64
     L.lom_map_point_count.argtypes = [vp]
@@ -257,6 +260,7 @@ def lib():
     L.lom_odometry_destroy.argtypes = [vp]
     L.lom_odometry_destroy.restype = None
     L.lom_odometry_process_cloud.argtypes = [vp, vp, C.c_size_t]
+    L.lom_odometry_hint_next.argtypes = [vp, vp, C.c_size_t]
     L.lom_odometry_process_sequence.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t), C.c_size_t, C.POINTER(C.c_size_t)]
     L.lom_odometry_get_pose.argtypes = [vp, pp]
     L.lom_odometry_get_stats.argtypes = [vp, C.POINTER(OdometryFrameStats)]

@@ -216,6 +216,18 @@ struct lom_map {
     void *h_report = nullptr, *d_report = nullptr;  // 1 KiB: AlignReport, and at 512 the words of gather_words()
     uint32_t words_tag = 0;
     int words_pending = 0;  // words of a lom_map_read_device_words_begin not yet collected
+    uint32_t n_dead = 0;  // slabs below n_vox whose voxel a radius cleanup erased without moving the others (k_cleanup_mark)
+    uint32_t dead_below = 0;  // ... all of them below this slab number (the slab count at the last such cleanup)
+    bool opt_dense_cleanup = false;  // LOM_DENSE_CLEANUP=1 at create: every radius cleanup closes its holes at once (as until round 4)
+    void (*idle_hook)(void *) = nullptr;  // lom_map_set_align_idle_hook: one shot
+    void *idle_user = nullptr;
+    // the scan of a radius cleanup enqueued behind an align (lom_map_radius_cleanup_after_align, voxel_map.hip)
+    float spec_radius = 0.f;     // > 0: the next device-resident align on this handle enqueues it
+    bool spec_inflight = false;  // scan and read-back are on the stream; what they were made for:
+    float spec_r = 0.f;
+    uint32_t spec_seq = 0, spec_tag = 0, spec_nv = 0;
+    uint64_t spec_mutations = 0;
+    uint32_t cleanups_taken = 0;  // radius cleanups that used such a scan (lom_map_debug_counter)
     unsigned long long report_seq = 0, lm_seq = 0, lm_launches = 0;
     uint32_t lm_max_blocks[4] = {0, 0, 0, 0};  // co-resident k_lm workgroups this device admits, per variant (occupancy query, cached)
     double last_counters[4] = {0, 0, 0, 0};  // valid, cand, occ, queries of the last k_match
@@ -261,6 +273,7 @@ int set_error(lom_map *m, int code, const char *what, hipError_t e = hipSuccess)
 int ensure(lom_map *m, DeviceBuf &b, size_t bytes);  // grow-only device buffer
 MapView view_of(const lom_map *m);
 int resolve_pending(lom_map *m);  // voxel_map.hip: redo the last single-pass insert if its in-kernel scan gave up
+void cleanup_scan_behind_align(lom_map *m);  // voxel_map.hip: see lom_map_radius_cleanup_after_align
 
 #define LOM_HIP(m, expr)                                                        \
     do {                                                                        \

@@ -2137,6 +2137,17 @@ static int align_chained(lom_map *m, const char *d_src, size_t n, size_t stride,
     };
     for (int i = 0; i < kPairsAhead; i++)
         if ((rc = launch_pair()) != LOM_OK) return rc;
+    // a caller that follows the align with radiusCleanup(result translation) (lidar_odometry.cpp:65-67) has said so: the
+    // cleanup's scan goes out behind the pairs (an align that needs more than these finds it undone and scans later)
+    if (m->spec_radius > 0.f && !m->p2p && !trace_out && !dbg) cleanup_scan_behind_align(m);
+    m->spec_radius = 0.f;
+    if (m->idle_hook) {  // the caller's own work for the ~0.1 ms this thread would only watch the report
+        void (*fn)(void *) = m->idle_hook;
+        m->idle_hook = nullptr;
+        const double t_h = now_s();
+        fn(m->idle_user);
+        c.launch_s += now_s() - t_h;
+    }
     for (;;) {
         const double t_w = now_s();
         const unsigned long long want = seq0 + (unsigned long long)launched;
@@ -2229,8 +2240,21 @@ static int align_chained(lom_map *m, const char *d_src, size_t n, size_t stride,
     return LOM_OK;
 }
 
+static int align_device_paths(lom_map *m, const char *d_src, size_t n, size_t stride, const float guess_t[3],
+                              const float guess_q[4], float out_t[3], float out_q[4], lom_align_stats *stats);
+
 static int align_device(lom_map *m, const char *d_src, size_t n, size_t stride, const float guess_t[3],
                         const float guess_q[4], float out_t[3], float out_q[4], lom_align_stats *stats)
+{
+    const int rc = align_device_paths(m, d_src, n, stride, guess_t, guess_q, out_t, out_q, stats);
+    // lom_map_radius_cleanup_after_align and lom_map_set_align_idle_hook arm ONE align, whichever path it took and however it ended
+    m->spec_radius = 0.f;
+    m->idle_hook = nullptr;
+    return rc;
+}
+
+static int align_device_paths(lom_map *m, const char *d_src, size_t n, size_t stride, const float guess_t[3],
+                              const float guess_q[4], float out_t[3], float out_q[4], lom_align_stats *stats)
 {
     if (n >= 0x7FFFFFFFull) return set_error(m, LOM_ERR_ARG, "too many source points");
     {   // an insert nobody has looked at since (no lom_map_status): the search must see its points
@@ -2354,10 +2378,30 @@ static int64_t find_pairs_core(lom_map *m, const float *src, size_t n, size_t st
     LOM_HIP(m, hipMemcpyAsync(on.data(), m->scan_on.p, n * sizeof(MatchRec), hipMemcpyDeviceToHost, m->stream));
     LOM_HIP(m, hipMemcpyAsync(st.data(), m->scan_stats.p, n * sizeof(QStat), hipMemcpyDeviceToHost, m->stream));
     LOM_HIP(m, hipStreamSynchronize(m->stream));
+    // index = voxel_creation_index * max_points + in_voxel_index, the creation index counting the voxels the map HOLDS: where
+    // a radius cleanup has left erased voxels' slabs in place (k_cleanup_mark) the slab number runs ahead of it
+    std::vector<uint32_t> dense;
+    const lom_map *mp = m->parent ? m->parent : m;
+    const uint32_t n_dead = mp->n_dead, dead_below = mp->dead_below;
+    if (n_dead) {
+        std::vector<uint32_t> cnt(dead_below);
+        LOM_HIP(m, hipMemcpy(cnt.data(), mp->d_slab_count, (size_t)dead_below * 4, hipMemcpyDeviceToHost));
+        dense.resize(dead_below);
+        uint32_t live = 0;
+        for (uint32_t s = 0; s < dead_below; s++) {
+            dense[s] = live;
+            live += cnt[s] != 0u;
+        }
+    }
+    const uint32_t K = mp->K;
     int64_t valid = 0;
     for (size_t i = 0; i < n; i++) {
         lom_correspondence &o = out[i];
         o.index = idx[i];
+        if (n_dead && idx[i] >= 0) {
+            const uint32_t slab = (uint32_t)idx[i] / K, j = (uint32_t)idx[i] % K;
+            o.index = (int64_t)(slab < dead_below ? dense[slab] : slab - n_dead) * K + j;
+        }
         o.origin[0] = on[i].ox;
         o.origin[1] = on[i].oy;
         o.origin[2] = on[i].oz;
@@ -2569,6 +2613,14 @@ int lom_profile_match(lom_map *m, const float *d_src, size_t n, size_t stride, c
         const double prev_b = (c.have_prev && !m->opt_no_temporal) ? 16.0 * nq : 0.0;
         *requested_bytes_out = 12.0 * nq + 16.0 * slots + 12.0 * scanned + 12.0 * sums[28] + 52.0 * nq + prev_b;
     }
+    return LOM_OK;
+}
+
+int lom_map_set_align_idle_hook(lom_map *m, void (*fn)(void *user), void *user)
+{
+    if (!m) return LOM_ERR_ARG;
+    m->idle_hook = fn;
+    m->idle_user = user;
     return LOM_OK;
 }
 

@@ -530,6 +530,15 @@ struct lom_odometry {
     std::atomic<bool> keyframe_has_voxels{false};
     bool test_force_host_redo = false;  // LOM_OPT_TEST_FORCE_HOST_REDO
     bool debug_timing = false;          // LOM_DEBUG_TIMING=1 at create / LOM_OPT_DEBUG_TIMING
+    bool no_cleanup_behind_align = false;  // LOM_NO_CLEANUP_BEHIND_ALIGN=1 at create: the cleanup's scan waits for the host (A/B)
+    bool no_send_ahead = false;            // LOM_NO_SEND_AHEAD=1 at create: hints are ignored (A/B)
+    // lom_odometry_hint_next: the frame the caller will bring next; `ahead_*`: what the align's idle time has sent ahead
+    const lom_point_xyzirt *hint_pts = nullptr, *hint_now = nullptr;  // (hint_now: the hint the running processCloud may use)
+    size_t hint_n = 0;
+    const lom_point_xyzirt *ahead_pts = nullptr;
+    const lom_point_xyzirt *ahead_stage = nullptr;  // where in pinned memory it went
+    size_t ahead_n = 0;
+    uint64_t frames_sent_ahead = 0;
     int64_t grid_redos = 0;             // frames sent to the host stages because an in-kernel scan gave up
     size_t temp_points = 0;  // temp_cloud_ (lidar_odometry.h:73-77) = the first temp_points records of `deskewed`
     ClassifyScratch classify_scratch;
@@ -593,6 +602,8 @@ int lom_odometry_create(const lom_odometry_params *params, int device, lom_odome
     if (!o) return LOM_ERR_OOM;
     o->cfg = *params;
     o->debug_timing = getenv("LOM_DEBUG_TIMING") != nullptr;
+    o->no_cleanup_behind_align = getenv("LOM_NO_CLEANUP_BEHIND_ALIGN") != nullptr;
+    o->no_send_ahead = getenv("LOM_NO_SEND_AHEAD") != nullptr;
     {
         unsigned hw = std::thread::hardware_concurrency();
         if (const char *e = getenv("LOM_HOST_THREADS")) hw = (unsigned)std::max(1, atoi(e));
@@ -698,6 +709,11 @@ int64_t lom_odometry_debug_counter(const lom_odometry *o, int which)
         int64_t v = o->grid_redos;
         for (lom_map *m : {o->keyframe, o->update_ds2[0], o->update_ds2[1], o->matching_ds}) v += lom_map_debug_counter(m, which);
         return v;
+    }
+    if (which == LOM_COUNTER_FRAMES_SENT_AHEAD) return (int64_t)o->frames_sent_ahead;
+    if (which == LOM_COUNTER_CLEANUPS_BEHIND_ALIGN) {
+        const int rc = const_cast<lom_odometry *>(o)->settle();
+        return rc != LOM_OK ? rc : lom_map_debug_counter(o->keyframe, which);
     }
     return LOM_ERR_ARG;
 }
@@ -806,15 +822,22 @@ int stages_on_device(lom_odometry *o, const lom_point_xyzirt *pts, size_t n, con
     // front end and down-samplers take frames of up to ~170k points (their in-kernel scans cover 262144 cells /
     // points); larger ones go through the host stages
     if (n > 170000) return 1;
-    // the frame goes into the front end's pinned buffer by the worker pool (one pass over ~1 MB), then to HBM
+    // the frame goes into the front end's pinned buffer by the worker pool (one pass over ~1 MB), then to HBM -- unless
+    // it went there while the previous frame's align ran (lom_odometry_hint_next)
+    const bool staged = o->ahead_pts != nullptr && o->ahead_pts == pts && o->ahead_n == n;
+    o->ahead_pts = nullptr;
     lom_point_xyzirt *stage = nullptr;
     if ((rc = lom_frontend_stage(o->frontend, n, &stage)) != LOM_OK) {
         o->error = lom_frontend_last_error(o->frontend);
         return rc;
     }
-    run_parts(o->pool.get(), n, [&](size_t b, size_t e, unsigned) {
-        std::memcpy(static_cast<void *>(stage + b), pts + b, (e - b) * sizeof(lom_point_xyzirt));
-    }, 8192);
+    if (staged && stage == o->ahead_stage) {
+        o->frames_sent_ahead++;
+    } else {
+        run_parts(o->pool.get(), n, [&](size_t b, size_t e, unsigned) {
+            std::memcpy(static_cast<void *>(stage + b), pts + b, (e - b) * sizeof(lom_point_xyzirt));
+        }, 8192);
+    }
     if ((rc = lom_frontend_process(o->frontend, stage, n, &rel_inv, &ident, o->cfg.lidar_min_range, o->cfg.lidar_max_range)) !=
         LOM_OK) {
         if (rc == LOM_ERR_ARG) return 1;  // a frame beyond the front end's size limit
@@ -928,9 +951,40 @@ int collect_or_redo_update(lom_odometry *o, FrameInputs &in, const char **why)
     return LOM_OK;
 }
 
+// lom_map_set_align_idle_hook: runs on the caller's thread while the align's kernels work -- the hinted next frame goes
+// into the front end's pinned buffer (the current frame's copy there has long been read by the device).  Host work only:
+// the frame's first kernel (upload + statistics) sent ahead as well was measured and is not (a
+// second queue's kernel is not started while the align's queue holds packets, and a copy-engine upload made frames slower)
+void send_next_frame_ahead(void *user)
+{
+    lom_odometry *o = static_cast<lom_odometry *>(user);
+    const lom_point_xyzirt *pts = o->hint_now;
+    const size_t n = o->hint_n;
+    o->hint_now = nullptr;
+    if (!pts || !n || n > 170000 || !o->frontend) return;
+    StageTimer tm(o->debug_timing);  // ("ahead ..." line: inside the align's lap)
+    lom_point_xyzirt *stage = nullptr;
+    if (lom_frontend_stage(o->frontend, n, &stage) != LOM_OK) return;
+    run_parts(o->pool.get(), n, [&](size_t b, size_t e, unsigned) {
+        std::memcpy(static_cast<void *>(stage + b), pts + b, (e - b) * sizeof(lom_point_xyzirt));
+    }, 8192);
+    tm.lap("ahead copy");
+    o->ahead_pts = pts;
+    o->ahead_n = n;
+    o->ahead_stage = stage;
+}
+
 }  // namespace
 
 extern "C" {
+
+int lom_odometry_hint_next(lom_odometry *o, const lom_point_xyzirt *pts, size_t n)
+{
+    if (!o || (!pts && n)) return LOM_ERR_ARG;
+    o->hint_pts = (o->no_send_ahead || !n) ? nullptr : pts;
+    o->hint_n = n;
+    return LOM_OK;
+}
 
 int lom_odometry_process_cloud(lom_odometry *o, const lom_point_xyzirt *pts, size_t n)
 {
@@ -948,6 +1002,18 @@ int lom_odometry_process_cloud(lom_odometry *o, const lom_point_xyzirt *pts, siz
         lom_pose_identity(&ident);
         FrameInputs in;
         int rc = 1;
+        // a hint is for the call that follows it, what was sent ahead for the call after that: neither outlives its call
+        o->hint_now = o->hint_pts;
+        o->hint_pts = nullptr;
+        struct DropHints {
+            lom_odometry *o;
+            const lom_point_xyzirt *sent_before;
+            ~DropHints()
+            {
+                o->hint_now = nullptr;
+                if (o->ahead_pts == sent_before) o->ahead_pts = nullptr;  // (this call did not use it: the front end drops it)
+            }
+        } drop_hints{o, o->ahead_pts};
         o->parity ^= 1;
         o->update_ds = o->update_ds2[o->parity];
         if (o->frontend) rc = stages_on_device(o, pts, n, rel_inv, ident, cur, in, tm);
@@ -982,6 +1048,12 @@ int lom_odometry_process_cloud(lom_odometry *o, const lom_point_xyzirt *pts, siz
         cur.matching_points = in.nm;
         lom_pose_compose(&o->current, &relative, &guess);  // :51
         lom_align_stats ast;
+        // :65-67: the keyframe update below starts with radiusCleanup(current_transform_.translation): its scan may run
+        // right behind the align, on the align's own result
+        if (!o->no_cleanup_behind_align) (void)lom_map_radius_cleanup_after_align(o->keyframe, o->cfg.keyframe_cleanup_range);
+        // ... and the frame the caller has announced (lom_odometry_hint_next) is sent ahead while this thread would only
+        // watch the align's report
+        if (o->hint_now && o->frontend && o->temp_on_device) (void)lom_map_set_align_idle_hook(o->keyframe, send_next_frame_ahead, o);
         if ((rc = lom_match_align_device(o->keyframe, in.d_match, (size_t)in.nm, 12, guess.t, guess.q, result.t, result.q,
                                          &ast)) != LOM_OK) {  // :49-51
             (void)in.collect_update(nullptr);
@@ -1019,22 +1091,28 @@ int lom_odometry_process_cloud(lom_odometry *o, const lom_point_xyzirt *pts, siz
         const lom_pose pose_now = o->current;
         const size_t n_down = (size_t)in.nd;
         const float *d_down = in.d_down, *d_down_n = in.d_down_n;
-        auto update = [o, pose_now, d_down, d_down_n, n_down]() -> int {
+        const double t_submit = o->debug_timing ? StageTimer::now() : 0.0;
+        auto update = [o, pose_now, d_down, d_down_n, n_down, t_submit]() -> int {
             auto bad = [o](int rc, lom_map *m) {
                 o->deferred_error = lom_last_error(m);
                 return rc;
             };
+            StageTimer ut(o->debug_timing);  // (the helper thread's own laps: "upd ..." lines)
+            if (o->debug_timing) std::fprintf(stderr, "  %-14s %8.1f us\n", "upd hand-off", (ut.t0 - t_submit) * 1e6);
             int rc;
             if ((rc = lom_map_radius_cleanup(o->keyframe, pose_now.t, o->cfg.keyframe_cleanup_range)) != LOM_OK)  // :67
                 return bad(rc, o->keyframe);
+            ut.lap("upd cleanup");
             const float *d_upd = nullptr, *d_upd_n = nullptr;
             if ((rc = lom_transform_points_device(o->keyframe, &pose_now, d_down, d_down_n, n_down, 12, &d_upd,
                                                   &d_upd_n)) != LOM_OK)  // :69
                 return bad(rc, o->keyframe);
             if ((rc = lom_map_add_points_device_nowait(o->keyframe, d_upd, d_upd_n, n_down, 12)) != LOM_OK)  // :70
                 return bad(rc, o->keyframe);
+            ut.lap("upd enqueue");
             // one look at the host per update: the deferred verdict of the insert and the voxel count
             if ((rc = lom_map_status(o->keyframe)) != LOM_OK) return bad(rc, o->keyframe);
+            ut.lap("upd status");
             o->last.keyframe_voxels = lom_map_size(o->keyframe);
             o->keyframe_has_voxels = o->last.keyframe_voxels > 0;
             return LOM_OK;
@@ -1060,6 +1138,7 @@ int lom_odometry_process_sequence(lom_odometry *o, const lom_point_xyzirt *const
     if (done) *done = 0;
     if (!o || (count && (!frames || !n))) return LOM_ERR_ARG;
     for (size_t i = 0; i < count; i++) {
+        if (i + 1 < count) (void)lom_odometry_hint_next(o, frames[i + 1], n[i + 1]);
         const int rc = lom_odometry_process_cloud(o, frames[i], n[i]);
         if (rc != LOM_OK) return rc;
         if (done) *done = i + 1;

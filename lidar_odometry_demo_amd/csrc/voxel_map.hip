@@ -236,8 +236,10 @@ __global__ void k_rebuild(Slot *table, uint32_t mask, uint32_t shift, const unsi
 {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_vox) return;
+    const uint32_t c = slab_count[s];
+    if (!c) return;  // a slab whose voxel a radius cleanup erased (k_cleanup_mark): the key is free again
     const uint32_t h = claim_slot(table, mask, shift, slab_key[s]);
-    table[h].count = slab_count[s];
+    table[h].count = c;
     table[h].slab = s;
 }
 
@@ -1082,25 +1084,71 @@ __global__ __launch_bounds__(kThreads) void k_bi_place(Slot *table, uint32_t n, 
 // cleanup / export kernels
 // ---------------------------------------------------------------------------
 // voxel_grid.h:238-241: erase iff (getOrigin() - point).squaredNorm() > radius_sq (f32, strict)
-__global__ void k_cleanup_flag(const float *pts, uint32_t K, uint32_t n_vox, float cx, float cy, float cz,
-                               float r2, uint32_t *keep)
+// (a slab with no points is a voxel an earlier cleanup erased -- k_cleanup_mark --: not kept, not counted)
+__global__ void k_cleanup_flag(const float *pts, const uint32_t *slab_count, uint32_t K, uint32_t n_vox, float cx, float cy,
+                               float cz, float r2, uint32_t *keep)
 {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_vox) return;
     const float *o = pts + (size_t)s * K * 3;  // voxel_with_planes.h:32-35 front()
     const float dx = o[0] - cx, dy = o[1] - cy, dz = o[2] - cz;
     const float d2 = dx * dx + (dy * dy + dz * dz);
-    keep[s] = (d2 > r2) ? 0u : 1u;
+    keep[s] = (slab_count[s] == 0u || d2 > r2) ? 0u : 1u;
+}
+
+// voxel_grid.h:240 erase(it), without moving anybody: the erased voxel's slab keeps its place in the creation order with no
+// points in it, and its key stays in the table as a claimed slot without a voxel (slab == kNoSlab, count 0 -- what a
+// range error leaves behind, too): a search finds no candidates there, an insert finds "it == end()" (voxel_grid.h:83)
+// and creates the voxel anew at the end of the creation order, exactly as after an erase.  Exports skip empty slabs.
+// The holes are closed (k_compact, table rebuilt) once they are a quarter of the slabs.
+__global__ void k_cleanup_mark(Slot *table, uint32_t mask, uint32_t shift, const uint32_t *__restrict__ keep, uint32_t n_vox,
+                               const unsigned long long *__restrict__ slab_key, uint32_t *slab_count)
+{
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_vox || keep[s] || slab_count[s] == 0u) return;
+    const unsigned long long key = slab_key[s];
+    uint32_t h = hash_key(key, shift) & mask;
+    for (uint32_t probe = 0; probe <= mask; probe++) {  // (the key is there: its voxel was live)
+        const unsigned long long seen = table[h].key;
+        if (seen == key) {
+            table[h].count = 0u;
+            table[h].slab = kNoSlab;
+            break;
+        }
+        if (seen == kEmptyKey) break;
+        h = (h + 1) & mask;
+    }
+    slab_count[s] = 0u;
 }
 
 // the same flags and their exclusive scan in one kernel (kItems consecutive voxels per thread, <= 256
 // workgroups): keep[], newid[] and the number of voxels kept (words[4])
+// `from`: the scan was enqueued behind an align on the same stream (lom_map_radius_cleanup_after_align) and takes its
+// centre from the pose that align ended with -- lidar_odometry.cpp:65-67: current_transform_ = result, then
+// radiusCleanup(current_transform_.translation, ...).  An align that has not ended there (more outer iterations to
+// come, a give-up) leaves words[12] = 0 and the scan undone; otherwise words[12] = seq and words[13..15] = the bits of
+// the centre used: the host takes the result only for exactly the centre it would have passed.  keep[] / newid[] are
+// scratch either way.
 template <int kItems>
-__global__ __launch_bounds__(kThreads) void k_cleanup_scan(const float *pts, uint32_t K, uint32_t n_vox, float cx, float cy,
+__global__ __launch_bounds__(kThreads) void k_cleanup_scan(const float *pts, const uint32_t *slab_count, uint32_t K,
+                                                           uint32_t n_vox, float cx, float cy,
                                                            float cz, float r2, uint32_t *keep, uint32_t *newid,
-                                                           Granule *agg, uint32_t seq, uint32_t *words, uint32_t test_fail_from)
+                                                           Granule *agg, uint32_t seq, uint32_t *words, uint32_t test_fail_from,
+                                                           const AlignState *from = nullptr)
 {
     __shared__ unsigned long long s_w[8];
+    if (from) {  // (uniform over the grid: the align's kernels are through)
+        typedef const __attribute__((address_space(4))) AlignState *ConstState;
+        ConstState cs = (ConstState)(from);
+        const int usable = cs->finished && !cs->error;
+        cx = cs->pose_t[0];
+        cy = cs->pose_t[1];
+        cz = cs->pose_t[2];
+        if (!usable) {
+            if (blockIdx.x == 0 && threadIdx.x == 0) words[12] = 0u;
+            return;
+        }
+    }
     const uint32_t base = (blockIdx.x * kThreads + threadIdx.x) * kItems;
     uint32_t f[kItems], mine = 0;
 #pragma unroll
@@ -1111,7 +1159,7 @@ __global__ __launch_bounds__(kThreads) void k_cleanup_scan(const float *pts, uin
             const float *o = pts + (size_t)s * K * 3;  // voxel_with_planes.h:32-35 front()
             const float dx = o[0] - cx, dy = o[1] - cy, dz = o[2] - cz;
             const float d2 = dx * dx + (dy * dy + dz * dz);
-            f[k] = (d2 > r2) ? 0u : 1u;  // voxel_grid.h:238-241
+            f[k] = (slab_count[s] == 0u || d2 > r2) ? 0u : 1u;  // voxel_grid.h:238-241 (an empty slab: erased before)
         }
         mine += f[k];
     }
@@ -1129,7 +1177,15 @@ __global__ __launch_bounds__(kThreads) void k_cleanup_scan(const float *pts, uin
         }
         run += f[k];
     }
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) words[4] = (uint32_t)(before + total);
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        words[4] = (uint32_t)(before + total);
+        if (from) {
+            words[13] = __float_as_uint(cx);
+            words[14] = __float_as_uint(cy);
+            words[15] = __float_as_uint(cz);
+            words[12] = seq;
+        }
+    }
 }
 
 __global__ void k_compact(const uint32_t *keep, const uint32_t *newid, uint32_t n_vox, uint32_t K,
@@ -1162,7 +1218,7 @@ __global__ void k_compact(const uint32_t *keep, const uint32_t *newid, uint32_t 
 __global__ void k_export_counts(const uint32_t *slab_count, uint32_t n_vox, int mode, uint32_t *out)
 {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s < n_vox) out[s] = (mode == LOM_EXPORT_FIRST_PER_VOXEL) ? 1u : slab_count[s];
+    if (s < n_vox) out[s] = (mode == LOM_EXPORT_FIRST_PER_VOXEL) ? (slab_count[s] ? 1u : 0u) : slab_count[s];  // (empty slab: erased voxel)
 }
 
 __global__ void k_export_write(const uint32_t *off, const uint32_t *slab_count, uint32_t n_vox, uint32_t K,
@@ -1171,7 +1227,7 @@ __global__ void k_export_write(const uint32_t *off, const uint32_t *slab_count, 
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t)n_vox * K) return;
     const uint32_t s = (uint32_t)(idx / K), j = (uint32_t)(idx % K);
-    const uint32_t c = (mode == LOM_EXPORT_FIRST_PER_VOXEL) ? 1u : slab_count[s];
+    const uint32_t c = (mode == LOM_EXPORT_FIRST_PER_VOXEL) ? (slab_count[s] ? 1u : 0u) : slab_count[s];
     if (j >= c) return;
     const size_t a = ((size_t)s * K + j) * 3, b = ((size_t)off[s] + j) * 3;
     out_xyz[b] = pts[a];
@@ -1971,6 +2027,7 @@ int lom_map_create(float voxel_size, size_t max_points, size_t capacity_hint, in
     m->opt_no_temporal = getenv("LOM_NO_TEMPORAL") != nullptr;
     if (const char *e = getenv("LOM_COUNT_CANDIDATES")) m->opt_count = atoi(e) != 0;
     m->opt_no_bulk = getenv("LOM_NO_BULK_INSERT") != nullptr;
+    m->opt_dense_cleanup = getenv("LOM_DENSE_CLEANUP") != nullptr;
     if (const char *e = getenv("LOM_BULK_PPT")) m->bulk_ppt = (uint32_t)atoi(e);  // development: points per thread of k_bi_claim
     if (handle_setup(m) != LOM_OK) {
         lom_map_destroy(m);
@@ -2082,6 +2139,7 @@ int64_t lom_map_debug_counter(const lom_map *m, int which)
 {
     if (!m) return LOM_ERR_ARG;
     if (which == LOM_COUNTER_GRID_REDOS) return (int64_t)m->grid_redos;
+    if (which == LOM_COUNTER_CLEANUPS_BEHIND_ALIGN) return (int64_t)m->cleanups_taken;
     return LOM_ERR_ARG;
 }
 
@@ -2091,6 +2149,7 @@ int lom_map_clear(lom_map *m, float voxel_size)
     LOM_HIP(m, hipSetDevice(m->device));
     m->voxel_size = voxel_size;
     m->n_vox = 0;
+    m->n_dead = 0;
     m->n_vox_ub = 0;
     m->n_vox_stale = false;
     m->n_points = 0;
@@ -2259,27 +2318,15 @@ int lom_map_add_points(lom_map *m, const float *xyz, const float *nrm, size_t n,
     return add_points_device(m, dx, dn, n, stride, true, false);
 }
 
-int lom_map_radius_cleanup(lom_map *m, const float center[3], float radius)
+// the single-pass scan of a radius cleanup: flags, new slab numbers, number of voxels kept (words[4]); `from` as k_cleanup_scan's
+static bool launch_cleanup_scan(lom_map *m, uint32_t nv, const float center[3], float r2, uint32_t seq, const AlignState *from)
 {
-    if (!m || !center) return LOM_ERR_ARG;
-    LOM_HIP(m, hipSetDevice(m->device));
-    int rc;
-    if ((rc = refresh_nvox(m)) != LOM_OK) return rc;
-    if (m->n_vox == 0) return LOM_OK;
-    const uint32_t nv = m->n_vox;
-    if ((rc = ensure(m, m->scr[S_FLAG], (size_t)nv * 4)) != LOM_OK) return rc;
-    if ((rc = ensure(m, m->scr[S_RANK], (size_t)nv * 4)) != LOM_OK) return rc;
-    if ((rc = ensure(m, m->scr[S_SCAN], scan_tmp_words(nv) * 4)) != LOM_OK) return rc;
     uint32_t *keep = (uint32_t *)m->scr[S_FLAG].p, *newid = (uint32_t *)m->scr[S_RANK].p;
-    const float r2 = radius * radius;  // voxel_grid.h:238
-    const uint32_t seq = ++m->call_seq;
-    m->mutations++;
-    bool one_pass = true;
     auto launch_scan = [&](auto items) {
         constexpr int kItems = decltype(items)::value;
         hipLaunchKernelGGL((k_cleanup_scan<kItems>), dim3(blocks_for((nv + kItems - 1) / kItems)), dim3(kThreads), 0,
-                           m->stream, m->d_pts, m->K, nv, center[0], center[1], center[2], r2, keep, newid, d_agg(m), seq,
-                           d_word(m, 0), take_test_fail_from(m));
+                           m->stream, m->d_pts, m->d_slab_count, m->K, nv, center[0], center[1], center[2], r2, keep, newid, d_agg(m), seq,
+                           d_word(m, 0), take_test_fail_from(m), from);
     };
     if (nv <= kOnePassMax)
         launch_scan(std::integral_constant<int, 1>());
@@ -2288,28 +2335,153 @@ int lom_map_radius_cleanup(lom_map *m, const float center[3], float radius)
     else if (nv <= 16 * kOnePassMax)
         launch_scan(std::integral_constant<int, 16>());
     else
-        one_pass = false;
-    if (!one_pass) {
-        hipLaunchKernelGGL(k_cleanup_flag, dim3(blocks_for(nv)), dim3(kThreads), 0, m->stream, m->d_pts, m->K, nv,
-                           center[0], center[1], center[2], r2, keep);
-        LOM_HIP(m, hipGetLastError());
-        if ((rc = scan_exclusive(m, keep, newid, nv, d_word(m, 4), (uint32_t *)m->scr[S_SCAN].p)) != LOM_OK) return rc;
+        return false;
+    return true;
+}
+
+// lidar_odometry.cpp:65-67 calls radiusCleanup with the translation the align has just produced: the scan of that cleanup
+// only reads the map and writes scratch, so it can run right behind the align's last solve -- with the centre taken from
+// the align's state in HBM -- instead of a host round trip, a thread hand-off and a launch later.  The caller arms it
+// (lom_map_radius_cleanup_after_align), the next device-resident align on the handle enqueues scan and read-back behind
+// its first five (k_match, k_lm) pairs (match.hip), and lom_map_radius_cleanup takes the result if, and only if, it was
+// made for exactly its arguments on exactly this state of the map; everything else is the plain path below.
+constexpr size_t kSpecWordsOffset = 768;  // of h_report / d_report: the words of a scan enqueued behind an align
+constexpr int kSpecWords = 6;             // words 4 (kept), 7 (scan gave up), 12 (made for this call), 13..15 (centre used)
+
+int lom_map_radius_cleanup_after_align(lom_map *m, float radius)
+{
+    if (!m) return LOM_ERR_ARG;
+    m->spec_radius = (radius > 0.f && !m->parent) ? radius : 0.f;
+    return LOM_OK;
+}
+
+}  // extern "C"
+namespace lom {
+void cleanup_scan_behind_align(lom_map *m)
+{
+    const float radius = m->spec_radius;
+    m->spec_radius = 0.f;  // armed for one align
+    // (a scan nobody has asked for since -- the caller did something else with the map -- is simply superseded: the
+    // read-back of this one follows it on the stream and carries the next tag)
+    m->spec_inflight = false;
+    if (!(radius > 0.f) || m->parent || m->n_vox_stale || m->pending_n.load() || m->n_vox == 0 || !m->align_state.p) return;
+    const uint32_t nv = m->n_vox;
+    // (scratch that has to grow: the plain path does that; an allocation here would wait for the align)
+    if (m->scr[S_FLAG].bytes < (size_t)nv * 4 || m->scr[S_RANK].bytes < (size_t)nv * 4 || nv > 16 * kOnePassMax) return;
+    const float zero[3] = {0.f, 0.f, 0.f};
+    const uint32_t seq = ++m->call_seq;
+    if (!launch_cleanup_scan(m, nv, zero, radius * radius, seq, (const AlignState *)m->align_state.p)) return;
+    WordPtrs w;
+    const int idx[kSpecWords] = {4, 7, 12, 13, 14, 15};
+    for (int i = 0; i < 32; i++) w.p[i] = i < kSpecWords ? d_word(m, idx[i]) : nullptr;
+    if (++m->spec_tag == 0) m->spec_tag = 1;
+    hipLaunchKernelGGL(k_gather_words, dim3(1), dim3(64), 0, m->stream, w, kSpecWords,
+                       reinterpret_cast<unsigned long long *>((char *)m->d_report + kSpecWordsOffset), m->spec_tag);
+    if (hipGetLastError() != hipSuccess) return;  // (nothing in flight that anybody will wait for)
+    m->spec_inflight = true;
+    m->spec_seq = seq;
+    m->spec_nv = nv;
+    m->spec_r = radius;
+    m->spec_mutations = m->mutations.load();
+}
+}  // namespace lom
+extern "C" {
+
+// the result of a scan enqueued behind an align, if it was made for this call: 1 = h_flags[0] (kept) and h_flags[3]
+// (give-up word) are set as read_words(m, 4, 4) would have, *seq_out = the scan's sequence number; 0 = not usable
+static int take_cleanup_behind_align(lom_map *m, const float center[3], float radius, uint32_t *seq_out)
+{
+    if (!m->spec_inflight) return 0;
+    m->spec_inflight = false;
+    volatile unsigned long long *hw = reinterpret_cast<volatile unsigned long long *>((char *)m->h_report + kSpecWordsOffset);
+    uint32_t got[kSpecWords];
+    uint64_t spins = 0;
+    for (int i = 0; i < kSpecWords; i++) {
+        while ((uint32_t)(hw[i] >> 32) != m->spec_tag) {
+            __builtin_ia32_pause();
+            if ((++spins & 0x3FFF) != 0) continue;
+            const hipError_t e = hipStreamQuery(m->stream);
+            if (e == hipSuccess) {
+                if ((uint32_t)(hw[i] >> 32) == m->spec_tag) break;
+                return 0;
+            }
+            if (e != hipErrorNotReady) return 0;  // (the plain path meets the same stream and reports it)
+        }
+        got[i] = (uint32_t)hw[i];
     }
-    LOM_HIP(m, hipGetLastError());
-    if ((rc = read_words(m, 4, 4)) != LOM_OK) return rc;
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    uint32_t cb[3];
+    std::memcpy(cb, center, 12);
+    const bool usable = got[2] == m->spec_seq && got[3] == cb[0] && got[4] == cb[1] && got[5] == cb[2] &&
+                        std::memcmp(&radius, &m->spec_r, 4) == 0 && m->call_seq == m->spec_seq &&
+                        m->mutations.load() == m->spec_mutations && m->n_vox == m->spec_nv && !m->n_vox_stale;
+    if (!usable) return 0;
+    m->h_flags[0] = got[0];
+    m->h_flags[3] = got[1];
+    *seq_out = m->spec_seq;
+    return 1;
+}
+
+int lom_map_radius_cleanup(lom_map *m, const float center[3], float radius)
+{
+    if (!m || !center) return LOM_ERR_ARG;
+    LOM_HIP(m, hipSetDevice(m->device));
+    int rc;
+    if ((rc = refresh_nvox(m)) != LOM_OK) return rc;
+    uint32_t seq = 0;
+    const bool taken = take_cleanup_behind_align(m, center, radius, &seq) == 1;
+    if (m->n_vox == 0) return LOM_OK;
+    const uint32_t nv = m->n_vox;
+    // (twice what this call needs: a scan enqueued behind an align does not allocate, a growing keyframe should not
+    // outgrow the scratch every few frames)
+    // (a scan that has been taken left its flags and new slab numbers in these two: they stay where they are)
+    if (!taken) {
+        if ((rc = ensure(m, m->scr[S_FLAG], (size_t)nv * 8)) != LOM_OK) return rc;
+        if ((rc = ensure(m, m->scr[S_RANK], (size_t)nv * 8)) != LOM_OK) return rc;
+    }
+    if ((rc = ensure(m, m->scr[S_SCAN], scan_tmp_words(nv) * 4)) != LOM_OK) return rc;
+    uint32_t *keep = (uint32_t *)m->scr[S_FLAG].p, *newid = (uint32_t *)m->scr[S_RANK].p;
+    const float r2 = radius * radius;  // voxel_grid.h:238
+    if (!taken) seq = ++m->call_seq;
+    m->mutations++;
+    bool one_pass = true;
+    if (!taken) {
+        one_pass = launch_cleanup_scan(m, nv, center, r2, seq, nullptr);
+        if (!one_pass) {
+            hipLaunchKernelGGL(k_cleanup_flag, dim3(blocks_for(nv)), dim3(kThreads), 0, m->stream, m->d_pts, m->d_slab_count, m->K, nv,
+                               center[0], center[1], center[2], r2, keep);
+            LOM_HIP(m, hipGetLastError());
+            if ((rc = scan_exclusive(m, keep, newid, nv, d_word(m, 4), (uint32_t *)m->scr[S_SCAN].p)) != LOM_OK) return rc;
+        }
+        LOM_HIP(m, hipGetLastError());
+        if ((rc = read_words(m, 4, 4)) != LOM_OK) return rc;
+    } else {
+        m->cleanups_taken++;
+    }
     if (one_pass && m->h_flags[3] == seq) {
         // the in-kernel scan gave up (it has written scratch only): flags + multi-launch scan instead
         m->grid_redos++;
         m->status_seq = std::max(m->status_seq, seq);
-        hipLaunchKernelGGL(k_cleanup_flag, dim3(blocks_for(nv)), dim3(kThreads), 0, m->stream, m->d_pts, m->K, nv,
+        hipLaunchKernelGGL(k_cleanup_flag, dim3(blocks_for(nv)), dim3(kThreads), 0, m->stream, m->d_pts, m->d_slab_count, m->K, nv,
                            center[0], center[1], center[2], r2, keep);
         LOM_HIP(m, hipGetLastError());
         if ((rc = scan_exclusive(m, keep, newid, nv, d_word(m, 4), (uint32_t *)m->scr[S_SCAN].p)) != LOM_OK) return rc;
         if ((rc = read_words(m, 4, 1)) != LOM_OK) return rc;
     }
-    const uint32_t n_keep = m->h_flags[0];
-    if (n_keep == nv) return LOM_OK;
+    const uint32_t n_keep = m->h_flags[0], n_live = nv - m->n_dead;
+    if (n_keep == n_live) return LOM_OK;
+    if (!m->opt_dense_cleanup && (uint64_t)(nv - n_keep) * 4u <= (uint64_t)nv) {
+        // few holes: the erased voxels' slabs stay where they are, empty (see k_cleanup_mark)
+        const MapView v = view_of(m);
+        hipLaunchKernelGGL(k_cleanup_mark, dim3(blocks_for(nv)), dim3(kThreads), 0, m->stream, m->d_table, v.mask, v.shift, keep, nv,
+                           m->d_slab_key, m->d_slab_count);
+        LOM_HIP(m, hipGetLastError());
+        m->n_dead = nv - n_keep;
+        m->dead_below = nv;
+        return LOM_OK;
+    }
     // stable compaction into the second (persistent) set of slab arrays, swap, rebuild the table
+    m->n_dead = 0;
     if (m->alt_cap != m->slab_cap) {
         Slabs stale{m->alt_key, m->alt_count, m->alt_pts, m->alt_nrm};
         LOM_HIP(m, hipStreamSynchronize(m->stream));
@@ -2356,7 +2528,7 @@ int64_t lom_map_size(const lom_map *cm)
         const int rc = refresh_nvox(m);
         if (rc != LOM_OK) return rc;
     }
-    return (int64_t)m->n_vox;
+    return (int64_t)(m->n_vox - m->n_dead);  // (slabs in use minus those whose voxel a cleanup erased)
 }
 
 int64_t lom_map_point_count(const lom_map *cm)

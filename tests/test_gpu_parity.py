@@ -391,6 +391,113 @@ def test_radius_cleanup_parity(lom, oracle, fixture_cloud):
     _assert_same_pairs(c, oc)
 
 
+@pytest.mark.parametrize("dense", [False, True])
+def test_radius_cleanup_leaves_holes_until_they_are_a_quarter(lom, oracle, monkeypatch, dense):
+    """voxel_grid.h:236-246 erases voxels; the slabs of the others do not move for that: an erased voxel's slab stays in the
+    creation order, empty, its key a claimed slot without a voxel (k_cleanup_mark) -- until a quarter of the slabs are
+    holes, then they are closed (k_compact).  A walk of a small radius across the map: every step erases a few voxels and
+    re-creates some erased earlier (at the END of the creation order, as after an erase in the reference); size, exports,
+    searches (with the creation index counting held voxels only) and aligns equal the oracle's at every step -- with the
+    holes (default) and with LOM_DENSE_CLEANUP=1 (every cleanup closes its holes at once, as until round 4)."""
+    if dense:
+        monkeypatch.setenv("LOM_DENSE_CLEANUP", "1")
+    sm = scenes.small_synth_case()
+    g, og = _both(lom, oracle, 0.5, 20)
+    xyz, nrm = sm["map_xyz"], sm["map_nrm"]
+    g.addCloud(xyz, nrm)
+    og.addCloud(xyz, nrm)
+    rng = np.random.default_rng(77)
+    q = np.ascontiguousarray(xyz[rng.choice(len(xyz), 3000, replace=False)] + np.float32(0.02))
+    sizes = []
+    for step in range(14):
+        centre = np.array([-12.0 + 2.0 * step, 3.0 * np.sin(step), 0.0], np.float32)
+        g.radiusCleanup(centre, 38.0)
+        og.radiusCleanup(centre, 38.0)
+        assert g.size() == og.size(), step
+        sizes.append(g.size())
+        # part of the original cloud comes back: erased voxels are created anew, kept ones take what they have room for
+        sel = rng.choice(len(xyz), 6000, replace=False)
+        sel.sort()
+        g.addCloud(xyz[sel], nrm[sel])
+        og.addCloud(xyz[sel], nrm[sel])
+        assert g.size() == og.size() and g.pointCount() == og.pointCount(), step
+        if step % 3 == 0 or step == 13:
+            _assert_same_map(g, og)
+            _assert_same_pairs(g.findMatchingPairs(q, lom.Pose3D(), 0.3), og.findMatchingPairs(q, oracle.Pose3D(), 0.3))
+    assert len(set(sizes)) > 5, "the walk was meant to erase voxels at every step"
+    m, om = lom.CloudMatcher(), oracle.CloudMatcher()
+    guess = ((0.05, -0.02, 0.0), scenes.angle_axis_q(0.01, (0, 0, 1)))
+    p, op = m.align(g, sm["scan"], lom.Pose3D(*guess)), om.align(og, sm["scan"], oracle.Pose3D(*guess))
+    dt, dr = scenes.pose_delta(p.translation, p.rotation, op.translation, op.rotation)
+    assert dt < POSE_TOL_M and dr < POSE_TOL_RAD and m.stats["outer_iterations"] == om.stats["outer_iterations"]
+    # the cap changed with holes in place, a cleanup that erases everything, and the map goes on
+    g.setMaxPoints(7)
+    og.setMaxPoints(7)
+    g.addCloud(xyz[:5000], nrm[:5000])
+    og.addCloud(xyz[:5000], nrm[:5000])
+    _assert_same_map(g, og)
+    g.radiusCleanup((500.0, 0.0, 0.0), 1.0)
+    og.radiusCleanup((500.0, 0.0, 0.0), 1.0)
+    assert g.size() == og.size() == 0
+    g.addCloud(xyz[:5000], nrm[:5000])
+    og.addCloud(xyz[:5000], nrm[:5000])
+    _assert_same_map(g, og)
+
+
+def test_radius_cleanup_scan_behind_align(lom, oracle):
+    """lidar_odometry.cpp:65-67: radiusCleanup(translation the align has just returned).  Armed before the align, the
+    cleanup's scan runs behind the align's last solve with the centre taken from the align's result in HBM; the
+    radiusCleanup that follows takes it only for exactly that centre and radius on an untouched map -- and the map is
+    the oracle's either way."""
+    sm = scenes.small_synth_case()
+    taken = lom.capi.COUNTER_CLEANUPS_BEHIND_ALIGN
+    m, om = lom.CloudMatcher(), oracle.CloudMatcher()
+    guess = ((0.05, -0.02, 0.0), scenes.angle_axis_q(0.01, (0, 0, 1)))
+    far = ((0.2, -0.2, 0.0), scenes.angle_axis_q(0.01, (0, 0, 1)))  # needs a sixth outer iteration: the scan finds the align unfinished
+    # (radius, what happens between arming and the cleanup, expected to be taken)
+    cases = [(30.0, "plain", True), (6.0, "plain", True), (6.0, "other_centre", False), (6.0, "other_radius", False),
+             (6.0, "map_touched", False), (6.0, "six_iterations", False), (6.0, "scan_gives_up", True), (6.0, "host_lm", False),
+             (6.0, "not_armed", False)]
+    for radius, what, expect in cases:
+        g, og = _both(lom, oracle, 0.5, 20)
+        g.addCloud(sm["map_xyz"], sm["map_nrm"])
+        og.addCloud(sm["map_xyz"], sm["map_nrm"])
+        g.radiusCleanup((0, 0, 0), 1e6)  # (sizes the cleanup's scratch: a scan behind an align does not allocate)
+        if what == "host_lm":
+            g.setOption(lom.capi.OPT_HOST_LM, 1)
+        if what != "not_armed":
+            g.radiusCleanupAfterAlign(5.0 if what == "other_radius" else radius)
+        if what == "scan_gives_up":
+            g.setOption(lom.capi.OPT_TEST_GRID_GIVE_UP, 1)
+        use = far if what == "six_iterations" else guess
+        p = m.align(g, sm["scan"], lom.Pose3D(*use))
+        op = om.align(og, sm["scan"], oracle.Pose3D(*use))
+        assert m.stats["outer_iterations"] == om.stats["outer_iterations"], what
+        if what == "map_touched":
+            g.addCloud(sm["map_xyz"][:50] + np.float32(0.01), sm["map_nrm"][:50])
+            og.addCloud(sm["map_xyz"][:50] + np.float32(0.01), sm["map_nrm"][:50])
+        centre = np.asarray(p.translation, np.float32)
+        if what == "other_centre":
+            centre = centre + np.float32(1e-3)
+        before, redos = g.debugCounter(taken), g.debugCounter()
+        g.radiusCleanup(centre, radius)
+        og.radiusCleanup(centre, radius)
+        assert g.debugCounter(taken) - before == (1 if expect else 0), what
+        assert g.debugCounter() - redos == (1 if what == "scan_gives_up" else 0), what
+        if radius < 10.0:
+            assert g.size() < len(np.unique(np.floor(sm["map_xyz"] / 0.5), axis=0)), "the cleanup was meant to remove voxels"
+        _assert_same_map(g, og)
+        # the map goes on as the oracle's: an insert and a search after the compaction
+        g.addCloud(sm["map_xyz"][:3000], sm["map_nrm"][:3000])
+        og.addCloud(sm["map_xyz"][:3000], sm["map_nrm"][:3000])
+        _assert_same_map(g, og)
+        # an arming nobody used does not reach the align after the next one
+        p2 = m.align(g, sm["scan"], lom.Pose3D(*guess))
+        before = g.debugCounter(taken)
+        g.radiusCleanup(np.asarray(p2.translation, np.float32), radius)
+        assert g.debugCounter(taken) == before, what
+
+
 # ---- correspondence parity ----------------------------------------------------
 
 def test_strict_min_first_wins(lom, oracle):

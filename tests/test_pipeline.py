@@ -243,6 +243,73 @@ def test_process_sequence_equals_the_frame_loop(lom, monkeypatch, dma):
                 "keyframe_voxels"):
         assert sa[key] == sb[key], key
     assert a.getFullKeyFrameCloud().tobytes() == b.getFullKeyFrameCloud().tobytes()
+    # the sequence call announces frame i + 1 before frame i: its upload goes out while frame i's align runs (not the first
+    # frame's -- it has no align)
+    sent = b.debugCounter(lom.capi.COUNTER_FRAMES_SENT_AHEAD)
+    assert sent == len(frames) - 2, sent
+    assert a.debugCounter(lom.capi.COUNTER_FRAMES_SENT_AHEAD) == 0
+
+
+@pytest.mark.gpu
+def test_hints_that_are_not_followed_change_nothing(lom):
+    """lom_odometry_hint_next: the announced frame's upload and statistics kernel go out during the align of the frame before
+    it.  A hint followed by ANOTHER frame, a hint given twice, a hint nobody follows up, a frame announced and then brought
+    as a copy at another address: the poses, counts and keyframe are those of the run without hints, bit for bit -- and
+    getTempCloud still shows the frame that was processed, not the one sent ahead."""
+    boxes = synth.make_boxes()
+    frames = [synth.make_sequence_frame(k, boxes=boxes) for k in range(14)]
+    plain, hinted = lom.LidarOdometry(), lom.LidarOdometry()
+    for k, f in enumerate(frames):
+        plain.processCloud(f)
+        nxt = frames[k + 1] if k + 1 < len(frames) else None
+        if nxt is not None:
+            if k % 4 == 0:
+                hinted.hintNext(nxt)                       # followed
+            elif k % 4 == 1:
+                hinted.hintNext(frames[(k + 5) % len(frames)])   # another frame comes
+            elif k % 4 == 2:
+                hinted.hintNext(frames[0])
+                hinted.hintNext(nxt)                       # replaced before use: the second one counts
+            # k % 4 == 3: no hint
+        hinted.processCloud(f if k % 8 != 5 else f.copy())   # (k = 5: announced at k = 4, brought at another address)
+        for key in ("planar_points", "filtered_points", "update_points", "matching_points", "outer_iterations", "queries",
+                    "keyframe_voxels", "host_stages"):
+            assert plain.stats[key] == hinted.stats[key], (k, key)
+        a, b = plain.getCurrentPose(), hinted.getCurrentPose()
+        assert a.translation.tobytes() == b.translation.tobytes() and a.rotation.tobytes() == b.rotation.tobytes(), k
+        if k in (1, 2, 6):
+            assert plain.getTempCloud().tobytes() == hinted.getTempCloud().tobytes(), k
+    assert plain.getFullKeyFrameCloud().tobytes() == hinted.getFullKeyFrameCloud().tobytes()
+    # (frames 3, 7, 9, 11, 13 were announced and came at the announced address behind a frame with an align)
+    assert 3 <= hinted.debugCounter(lom.capi.COUNTER_FRAMES_SENT_AHEAD) <= 5
+
+
+@pytest.mark.gpu
+def test_cleanup_scan_behind_the_align_changes_nothing(lom, monkeypatch):
+    """processCloud arms the keyframe's radius cleanup (lidar_odometry.cpp:67) before the align (:49-51): its scan runs behind
+    the align's last solve on the align's own result.  With LOM_NO_CLEANUP_BEHIND_ALIGN=1 the scan waits for the host as
+    before: same pose bits, counts and keyframe; and the default really takes the early scan on (nearly) every frame."""
+    boxes = synth.make_boxes()
+    early = lom.LidarOdometry()
+    monkeypatch.setenv("LOM_NO_CLEANUP_BEHIND_ALIGN", "1")
+    late = lom.LidarOdometry()
+    monkeypatch.delenv("LOM_NO_CLEANUP_BEHIND_ALIGN")
+    n_frames = 40
+    for k in range(n_frames):
+        f = synth.make_sequence_frame(k, boxes=boxes)
+        early.processCloud(f)
+        late.processCloud(f)
+        for key in ("update_points", "matching_points", "outer_iterations", "queries", "keyframe_voxels"):
+            assert early.stats[key] == late.stats[key], (k, key)
+        a, b = early.getCurrentPose(), late.getCurrentPose()
+        assert a.translation.tobytes() == b.translation.tobytes() and a.rotation.tobytes() == b.rotation.tobytes(), k
+    assert early.getFullKeyFrameCloud().tobytes() == late.getFullKeyFrameCloud().tobytes()
+    taken = early.debugCounter(lom.capi.COUNTER_CLEANUPS_BEHIND_ALIGN)
+    # (not the first frame -- no align --, not the frame after: the cleanup's scratch is allocated by the plain path, and
+    # again whenever the keyframe has outgrown it -- often in these first frames --; not an align of more than five outer
+    # iterations: the scan goes out behind the fifth)
+    assert n_frames - 10 <= taken <= n_frames - 1, taken
+    assert late.debugCounter(lom.capi.COUNTER_CLEANUPS_BEHIND_ALIGN) == 0
 
 
 @pytest.mark.gpu
