@@ -1100,13 +1100,15 @@ int lom_odometry_process_cloud(lom_odometry *o, const lom_point_xyzirt *pts, siz
             StageTimer ut(o->debug_timing);  // (the helper thread's own laps: "upd ..." lines)
             if (o->debug_timing) std::fprintf(stderr, "  %-14s %8.1f us\n", "upd hand-off", (ut.t0 - t_submit) * 1e6);
             int rc;
+            // :69 first: the rigid transform of the update cloud reads neither the map nor what the cleanup leaves, and its
+            // launch fills the time the cleanup spends waiting for its scan (enqueued behind the align) to report
+            const float *d_upd = nullptr, *d_upd_n = nullptr;
+            if ((rc = lom_transform_points_device(o->keyframe, &pose_now, d_down, d_down_n, n_down, 12, &d_upd,
+                                                  &d_upd_n)) != LOM_OK)
+                return bad(rc, o->keyframe);
             if ((rc = lom_map_radius_cleanup(o->keyframe, pose_now.t, o->cfg.keyframe_cleanup_range)) != LOM_OK)  // :67
                 return bad(rc, o->keyframe);
             ut.lap("upd cleanup");
-            const float *d_upd = nullptr, *d_upd_n = nullptr;
-            if ((rc = lom_transform_points_device(o->keyframe, &pose_now, d_down, d_down_n, n_down, 12, &d_upd,
-                                                  &d_upd_n)) != LOM_OK)  // :69
-                return bad(rc, o->keyframe);
             if ((rc = lom_map_add_points_device_nowait(o->keyframe, d_upd, d_upd_n, n_down, 12)) != LOM_OK)  // :70
                 return bad(rc, o->keyframe);
             ut.lap("upd enqueue");
