@@ -236,6 +236,9 @@ public:
     }
 
     void radiusCleanup(const Vector3f &point, float radius) { check(lom_map_radius_cleanup(h_, point.v, radius)); }
+    // not in the reference: says that the next align on this grid is followed by radiusCleanup(<its result translation>,
+    // radius), as lidar_odometry.cpp:65-67 does -- the cleanup's scan then runs right behind the align (results never differ)
+    void radiusCleanupAfterAlign(float radius) { check(lom_map_radius_cleanup_after_align(h_, radius)); }
 
     size_t size() const
     {
@@ -472,6 +475,13 @@ public:
     void processCloud(const CloudType &input_cloud)  // lidar_odometry.cpp:22-77
     {
         const int rc = lom_odometry_process_cloud(h_, input_cloud.points.data(), input_cloud.points.size());
+        if (rc != LOM_OK) throw Error(rc, lom_odometry_last_error(h_));
+    }
+    // not in the reference: the cloud that will come after the next processCloud, for callers that hold it already; it must
+    // stay unchanged until it has been processed (it is copied to pinned memory while that processCloud's align runs)
+    void hintNextCloud(const CloudType &next_cloud)
+    {
+        const int rc = lom_odometry_hint_next(h_, next_cloud.points.data(), next_cloud.points.size());
         if (rc != LOM_OK) throw Error(rc, lom_odometry_last_error(h_));
     }
     Pose3D getCurrentPose() const  // :87-89
