@@ -33,7 +33,7 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 # same guide, "Indexed rows": uniformly random rows of a 38 MB table are served from the Infinity Cache at 8.6 TB/s
 # chip-wide -- the level the C3 / C4 maps (48 MB payload + table) are read from
 CACHE_PEAK_GBS = 8600.0
-EVENT_PERIOD = 16      # HIP events around the k_match / k_lm launches of every 16th step (see main)
+EVENT_PERIOD = 32      # HIP events around the k_match / k_lm launches of every 32nd step (see event_period)
 EXTRA_BLOCKS = 5       # further blocks of K steps after the official one: median and spread of ms_per_step
 
 
@@ -258,6 +258,13 @@ def cpu_baseline(work, budget_s=10.0):
                       "CPU restatement of the reference algorithm (oracle/), not the reference binary"}
 
 
+def event_period(steps):
+    """A step whose launches carry HIP events takes ~40 % longer (an event is a packet of its own on the stream): of a long
+    block every 32nd step carries them (200 steps: 7 steps, 35 launches of each kernel), of a short one -- the driver's
+    20 steps -- the first step alone.  Two of twenty had cost the short block 3.7 % (0.1323 against 0.1285 ms per step)."""
+    return EVENT_PERIOD if steps >= 3 * EVENT_PERIOD else max(int(steps), 1)
+
+
 def streaming(args, lom, steps=None, warmup=None, cpu_frames=40):
     """BASELINE.json configs[4]: 10 Hz VLP16 sequence through the full per-frame pipeline
     (time-normalise, deskew, classify, range filter, two down-samplers, align, cleanup, keyframe
@@ -448,7 +455,7 @@ def counted_replay(lom, grid, d_scan, guess):
 def align_block(lom, torch, work, dev, steps, warmup_aligns=200):
     """A short block of aligns of another configuration on this GPU (the default run's extra_configs): map build,
     warm-up, `steps` aligns issued back to back from compiled code, k_match / k_lm durations from HIP events on
-    every 8th align.  Same definitions as the main line."""
+    some of the aligns (event_period).  Same definitions as the main line."""
     grid = lom.VoxelGrid(0.5, 20, device=dev.index or 0)
     d_map_xyz = torch.from_numpy(work["map_xyz"]).to(dev)
     d_map_nrm = torch.from_numpy(work["map_nrm"]).to(dev)
@@ -459,7 +466,7 @@ def align_block(lom, torch, work, dev, steps, warmup_aligns=200):
     torch.cuda.synchronize()
     guess = lom.Pose3D()
     lom.align_repeat(grid, d_scan.data_ptr(), d_scan.shape[0], guess, warmup_aligns)
-    grid.setProfiling(8)
+    grid.setProfiling(event_period(steps))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     pose, tot = lom.align_repeat(grid, d_scan.data_ptr(), d_scan.shape[0], guess, steps)
@@ -560,8 +567,8 @@ def main():
     del d_map_xyz, d_map_nrm
     # live HIP-event measurement of k_match inside the timed region: an event pair costs the stream
     # ~5 us per launch (0.218 ms per step with every launch bracketed against 0.170 ms with none), so
-    # the launches of every 16th step carry the events and the others run as a caller would run them
-    grid.setProfiling(EVENT_PERIOD)
+    # the launches of every 32nd step carry the events and the others run as a caller would run them (event_period)
+    grid.setProfiling(event_period(args.steps))
     d_scan = torch.from_numpy(work["shard"]).to(dev)
     torch.cuda.synchronize()
 
@@ -640,6 +647,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    grid.setProfiling(event_period(args.steps))   # (counts from here: the block's first step carries the events)
     fence()
     t0 = time.perf_counter()
     # exactly K steps, issued back to back from compiled code (the reference's callers are C++)
@@ -675,9 +683,15 @@ def main():
     for _ in range(EXTRA_BLOCKS):
         fence()
         tb = time.perf_counter()
-        lom.align_repeat(grid, d_scan.data_ptr(), d_scan.shape[0], guess, args.steps)
+        _, tot_b = lom.align_repeat(grid, d_scan.data_ptr(), d_scan.shape[0], guess, args.steps)
         fence()
         el = time.perf_counter() - tb
+        # the kernels' event samples of these blocks count as well (a short block carries the events of ONE step: five
+        # launches of each kernel are a thin average)
+        match_ms += tot_b["match_kernel_ms"]
+        profiled += tot_b["profiled_launches"]
+        lm_ms += tot_b["lm_kernel_ms"]
+        lm_profiled += tot_b["lm_profiled_launches"]
         if use_dist:
             t = torch.tensor([el], dtype=torch.float64, device="cpu" if one_device else dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -724,7 +738,7 @@ def main():
         # stats are global (summed over ranks) after the in-library all-gather
         value = queries / elapsed / 1e6
         # -- the dominant kernel, k_match: duration measured live inside the timed region (HIP events on the
-        # library's stream around the launches of every 16th step).  An event pair around ONE short kernel carries
+        # library's stream around the launches of every 32nd step, of a short block's first step).  An event pair around ONE short kernel carries
         # packet overhead; it is measured right here (same launches at the final pose once as a back-to-back
         # train under one pair, once with a pair each) and subtracted: the result is what
         # `rocprofv3 --kernel-trace --stats` reports as the kernel's average duration (profiles/).
@@ -736,11 +750,12 @@ def main():
         achieved = alg_per_launch / (in_loop_us * 1e-6) / 1e9
         traffic, traffic_source = traffic_record(args.config) if n == 1 else (None, None)
         roof = match_roofline(int(d_scan.shape[0]), alg_per_launch, req_per_launch, in_loop_us, traffic, traffic_source, {
-            "avg_launch_us_method": "HIP event pairs around the k_match launches of every 16th step inside the timed "
+            "avg_launch_us_method": "HIP event pairs around the k_match launches of every 32nd step (short blocks: the first step) inside the timed "
                                     "region, minus the per-pair event overhead measured in this run",
             "in_loop_raw_us": in_loop_raw_us,
             "event_pair_overhead_us": event_overhead_us,
             "in_loop_launches_measured": profiled,
+            "in_loop_launches_from": f"the timed block and the {EXTRA_BLOCKS} blocks of the same K steps behind it (ms_per_step_blocks)",
             "train_avg_launch_us": train_us,
             "train_note": "200 back-to-back launches at the final pose under one event pair (best case: warm caches, "
                           "converged pose)",
