@@ -5,6 +5,8 @@
     bytewise;
   * the second of two searches of one scan (previous winner's bound, records left alone where the winner stays):
     identical poses, millimetre moves, large moves, searches after a map change -- every entry;
+  * radius cleanups (erase in place, holes closed at a quarter; half of them with the scan enqueued behind an align),
+    points coming back into erased voxels: the map bytewise, searches with their creation indices;
   * aligns: pose within 1e-4 m / 1e-4 rad, iteration and evaluation counts equal.
 usage: python tools/stress_round4.py [cases]"""
 import os
@@ -23,6 +25,8 @@ n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 rng = np.random.default_rng(20261005)
 bad = 0
 redone = 0
+cleanups = 0
+taken_behind = 0
 
 
 def same_map(g, og):
@@ -73,8 +77,41 @@ for case in range(n_cases):
             if not same_pairs(a, b):
                 bad += 1
                 print("SEARCH MISMATCH", case, voxel, K, dt_, da, d, flush=True)
-    # an align on this map
+    # radius cleanups that erase in place (holes until a quarter of the slabs are empty, then closed), points coming back
+    # into erased voxels, cleanups whose scan ran behind an align: the map bytewise, searches entry by entry
     m, om = lom.CloudMatcher(), oracle.CloudMatcher()
+    for rnd in range(int(rng.integers(3, 9))):
+        c = centers[rng.integers(0, n_centers)] + rng.normal(0, 3.0, 3)
+        r = float(rng.choice([8.0, 15.0, 25.0, 40.0, 70.0]))
+        behind = rng.random() < 0.5
+        if behind:
+            g.radiusCleanupAfterAlign(r)
+            scan_c = np.ascontiguousarray(q[:1500])
+            gp = (rng.uniform(-0.03, 0.03, 3), scenes.angle_axis_q(rng.uniform(-0.01, 0.01), (0, 0, 1)))
+            p, op = m.align(g, scan_c, lom.Pose3D(*gp)), om.align(og, scan_c, oracle.Pose3D(*gp))
+            c = np.asarray(p.translation, np.float32)  # (the oracle's cleanup takes the product's centre: the map is what is compared)
+        cleanups_behind_before = g.debugCounter(lom.capi.COUNTER_CLEANUPS_BEHIND_ALIGN)
+        g.radiusCleanup(c, r)
+        og.radiusCleanup(c, r)
+        taken_behind += g.debugCounter(lom.capi.COUNTER_CLEANUPS_BEHIND_ALIGN) - cleanups_behind_before
+        cleanups += 1
+        if g.size() != og.size():
+            bad += 1
+            print("SIZE MISMATCH after cleanup", case, rnd, g.size(), og.size(), flush=True)
+        back = rng.integers(0, n_centers, 20_000)
+        pts = (centers[back] + rng.normal(0, spread, (len(back), 3))).astype(np.float32)
+        nrm = scenes._unit(rng.standard_normal(pts.shape)).astype(np.float32)
+        g.addCloud(pts, nrm)
+        og.addCloud(pts, nrm)
+        if not same_map(g, og):
+            bad += 1
+            print("MAP MISMATCH after cleanup + insert", case, rnd, voxel, K, r, flush=True)
+        a = g.findMatchingPairs(q[:3000], lom.Pose3D(*base), 0.3)
+        b = og.findMatchingPairs(q[:3000], oracle.Pose3D(*base), 0.3)
+        if not (same_pairs(a, b) and np.array_equal(a["index"], b["index"])):
+            bad += 1
+            print("SEARCH MISMATCH after cleanup", case, rnd, voxel, K, r, flush=True)
+    # an align on this map
     scan = np.ascontiguousarray(q[: int(rng.choice([300, 2000, 6000]))])
     guess = (rng.uniform(-0.05, 0.05, 3), scenes.angle_axis_q(rng.uniform(-0.01, 0.01), (0, 0, 1)))
     p, op = m.align(g, scan, lom.Pose3D(*guess)), om.align(og, scan, oracle.Pose3D(*guess))
@@ -85,5 +122,6 @@ for case in range(n_cases):
         print("ALIGN MISMATCH", case, voxel, K, dt, dr, m.stats["outer_iterations"], om.stats["outer_iterations"], flush=True)
     print(f"case {case}: voxel {voxel} cap {K} centers {n_centers} spread {spread}: voxels {g.size()}, bulk inserts sent back so far {redone}, "
           f"mismatches so far {bad}", flush=True)
-print(f"{n_cases} cases: mismatches {bad}; bulk inserts sent back to the four-kernel path {redone}")
+print(f"{n_cases} cases: mismatches {bad}; bulk inserts sent back to the four-kernel path {redone}; radius cleanups {cleanups}, "
+      f"{taken_behind} of them with the scan that ran behind an align")
 sys.exit(1 if bad else 0)
