@@ -294,6 +294,27 @@ def streaming(args, lom, steps=None, warmup=None, cpu_frames=40):
     queries = odo.stats["queries_total"] - q0   # waits for the last keyframe update: inside the timed region
     elapsed = time.perf_counter() - t0
     pose = odo.getCurrentPose()
+    odo_stats = dict(odo.stats)
+    odo_counters = {"redone": odo.debugCounter(), "staged": odo.debugCounter(lom.capi.COUNTER_FRAMES_SENT_AHEAD),
+                    "behind": odo.debugCounter(lom.capi.COUNTER_CLEANUPS_BEHIND_ALIGN)}
+    del odo   # (its streams go with it: a process has four hardware queues, handles beyond that share them)
+    # beside it (never `value`): the same frames to a caller that does NOT hold the next frame while one is processed -- a
+    # live sensor --, i.e. without lom_odometry_hint_next: each frame is copied to pinned memory at the start of its own call
+    os.environ["LOM_NO_SEND_AHEAD"] = "1"   # (read once, at create)
+    try:
+        live = lom.LidarOdometry()
+    finally:
+        del os.environ["LOM_NO_SEND_AHEAD"]
+    for k in range(warmup):
+        live.processCloud(frames[k])
+    _ = live.stats["queries_total"]      # (waits for the warm-up's last keyframe update)
+    t_live = time.perf_counter()
+    live.processSequence(frames[warmup:n_frames])
+    _ = live.stats["queries_total"]      # (... and for the last one: inside the timed region, as above)
+    live_ms = (time.perf_counter() - t_live) / steps * 1e3
+    same_pose = (live.getCurrentPose().translation.tobytes() == pose.translation.tobytes()
+                 and live.getCurrentPose().rotation.tobytes() == pose.rotation.tobytes())
+    del live
     gt_t, gt_q = synth.sequence_pose(n_frames * synth.FRAME_PERIOD)
     dq = abs(float(np.dot(pose.rotation.astype(np.float64), gt_q)))
     line = {
@@ -303,11 +324,16 @@ def streaming(args, lom, steps=None, warmup=None, cpu_frames=40):
         "frames_per_s": steps / elapsed,
         "config": {"workload": "C5: streaming 10 Hz VLP16 sequence, full per-frame pipeline, default params",
                    "points_per_frame": int(np.mean([len(f) for f in frames])),
-                   "keyframe_voxels": odo.stats["keyframe_voxels"],
-                   "frames_redone_on_host_or_scans_redone": odo.debugCounter(),
-                   "frames_sent_ahead_during_the_previous_align": odo.debugCounter(lom.capi.COUNTER_FRAMES_SENT_AHEAD),
-                   "cleanup_scans_behind_the_align": odo.debugCounter(lom.capi.COUNTER_CLEANUPS_BEHIND_ALIGN),
-                   "matching_points_last": odo.stats["matching_points"],
+                   "keyframe_voxels": odo_stats["keyframe_voxels"],
+                   "frames_redone_on_host_or_scans_redone": odo_counters["redone"],
+                   "frames_handed_over_by": "lom_odometry_process_sequence: the caller's frame loop in compiled code; it announces "
+                                            "frame i + 1 before frame i (lom_odometry_hint_next), which is then copied to pinned "
+                                            "memory while frame i's align runs",
+                   "frames_staged_during_the_previous_align": odo_counters["staged"],
+                   "ms_per_frame_without_announcing_the_next_frame": live_ms,
+                   "final_pose_bits_equal_without_announcing": bool(same_pose),
+                   "cleanup_scans_behind_the_align": odo_counters["behind"],
+                   "matching_points_last": odo_stats["matching_points"],
                    "drift_translation_m": float(np.linalg.norm(pose.translation.astype(np.float64) - gt_t)),
                    "drift_rotation_rad": 2.0 * float(np.arccos(min(1.0, dq))),
                    "drift_note": "x is weakly observable in the street-canyon scene and the reference's "

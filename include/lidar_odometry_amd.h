@@ -632,7 +632,8 @@ int64_t lom_odometry_get_temp_cloud(const lom_odometry *o, lom_point_xyzirt *out
 int lom_odometry_get_stats(const lom_odometry *o, lom_odometry_frame_stats *out);
 /* switches of the pipeline (LOM_OPT_TEST_FORCE_HOST_REDO, the LOM_OPT_TEST_GRID_GIVE_UP family) and, for every other
  * option, of its keyframe handle (the align's).  The environment is read once, by lom_odometry_create
- * (LOM_HOST_THREADS, LOM_SYNC_KEYFRAME_UPDATE, LOM_HOST_FRONTEND, LOM_DEBUG_TIMING). */
+ * (LOM_HOST_THREADS, LOM_SYNC_KEYFRAME_UPDATE, LOM_HOST_FRONTEND, LOM_DEBUG_TIMING, and the A/B switches
+ * LOM_NO_CLEANUP_BEHIND_ALIGN, LOM_NO_SEND_AHEAD; lom_map_create reads LOM_DENSE_CLEANUP). */
 int lom_odometry_set_option(lom_odometry *o, int option, int64_t value);
 int64_t lom_odometry_debug_counter(const lom_odometry *o, int which); /* LOM_COUNTER_GRID_REDOS: all its handles + frames redone */
 /* test hook (teacher-forced parity tests): overwrite previous_transform_ / current_transform_
