@@ -357,14 +357,17 @@ def streaming(args, lom, steps=None, warmup=None, cpu_frames=40):
     return line
 
 
-def concurrent_contexts(lom, torch, grid, d_scan, guess, steps, counts=(2, 3, 4, 6, 8)):
+def concurrent_contexts(lom, torch, grid, d_scan, guess, steps, counts=(2, 3, 4, 8)):
     """Side figure (never `value`): `k` host threads, one scan context each (lom_scan_create), all aligning the same
     device-resident scan against the ONE keyframe at the same time -- what `const VoxelGrid&` allows the reference's
     callers (voxel_grid.h:206, cloud_matcher.h:15).  A solve keeps ~53 of the 256 CUs busy on a VLP16-sized scan and every
     launch of an align waits for the one before it, so concurrent callers are how one GPU is filled.  Two forms: contexts
     that share the whole GPU (each search grid fills every SIMD, so the callers' kernels queue behind each other), and
     contexts on k disjoint slices of the compute units (lom_scan_create_on_partition: a CU mask per stream), where the
-    callers' chains run side by side.  The C calls release the GIL."""
+    callers' chains run side by side.  The C calls release the GIL.
+    (k = 6 is left out on purpose: 256 compute units do not split into six equal slices of whole shader arrays, a slice's
+    solve kernel then finds fewer resident workgroups than the occupancy query promised, waits out its patience and the
+    aligns fall back to the host-driven loop -- correct, and ~50 ms each.)"""
     import threading
 
     out = {}
