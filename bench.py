@@ -365,9 +365,9 @@ def concurrent_contexts(lom, torch, grid, d_scan, guess, steps, counts=(2, 3, 4,
     that share the whole GPU (each search grid fills every SIMD, so the callers' kernels queue behind each other), and
     contexts on k disjoint slices of the compute units (lom_scan_create_on_partition: a CU mask per stream), where the
     callers' chains run side by side.  The C calls release the GIL.
-    (k = 6 is left out on purpose: 256 compute units do not split into six equal slices of whole shader arrays, a slice's
-    solve kernel then finds fewer resident workgroups than the occupancy query promised, waits out its patience and the
-    aligns fall back to the host-driven loop -- correct, and ~50 ms each.)"""
+    (slices of 5, 6 or 7 hold a solve of 32 workgroups at once, like 8: the library counts what every (XCD, shader engine)
+    pair of a slice is sure to have -- tests/test_gpu_parity.py::test_uneven_slices_hold_their_solve; until that was fixed a
+    six-slice context waited out its patience on every align, which is why six was taken off this list.)"""
     import threading
 
     out = {}

@@ -1892,10 +1892,18 @@ static hipError_t create_stream(lom_map *m, int part, int nparts)
     // round-robin over the XCDs: a contiguous range of bits is the same number of CUs on every XCD.
     const uint32_t lo = (uint32_t)((uint64_t)cus * (uint32_t)part / (uint32_t)nparts);
     const uint32_t hi = (uint32_t)((uint64_t)cus * ((uint32_t)part + 1u) / (uint32_t)nparts);
+    // What the slice holds AT ONCE of a grid whose workgroups wait for each other (k_lm): the dispatcher deals workgroups
+    // round-robin over the 8 XCDs and, inside an XCD, over its 4 shader engines, whatever the mask says; a slice of c CUs
+    // has at least floor(c / 32) of them in each of the 32 (XCD, engine) pairs, so that many workgroups per pair always find
+    // a CU.  2, 4, 8 slices: 128, 64, 32 (all of the slice); 3 slices: 64 of 85; 5, 6, 7 slices: 32 of 51, 42, 36 -- with
+    // the whole 42 counted, a solve of 42 workgroups found one pair short and waited out its patience on every align.
+    constexpr uint32_t kDispatchPairs = 32;
+    uint32_t usable = hi - lo;
+    if ((uint32_t)cus % kDispatchPairs == 0u && usable >= kDispatchPairs) usable = usable / kDispatchPairs * kDispatchPairs;
     std::vector<uint32_t> mask(((size_t)cus + 31) / 32, 0u);
     for (uint32_t c = lo; c < hi; c++) mask[c >> 5] |= 1u << (c & 31);
     e = hipExtStreamCreateWithCUMask(&m->own_stream, (uint32_t)mask.size(), mask.data());
-    if (e == hipSuccess) m->partition_cus = hi - lo;
+    if (e == hipSuccess) m->partition_cus = std::max(usable, 1u);
     return e;
 }
 

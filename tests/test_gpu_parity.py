@@ -1431,6 +1431,33 @@ def test_contexts_created_concurrently_settle_a_pending_insert_once(lom, oracle,
         del d_xyz, d_nrm
 
 
+def test_uneven_slices_hold_their_solve(lom):
+    """Slices of the compute units that are no multiple of the XCD count (256 / 6 = 42 or 43, 256 / 5, 256 / 7): the
+    dispatcher deals a grid's workgroups round-robin over the XCDs whatever the CU mask says, so the solve kernel -- whose
+    workgroups wait for each other -- fits as often as the XCD with the fewest enabled CUs allows.  A VLP16-sized scan
+    (more workgroups than any such slice holds): no align waits out its patience (host_fallback == 0), same bits as on the
+    whole GPU."""
+    sm = scenes.small_synth_case()
+    g = lom.VoxelGrid(0.5, 20)
+    g.addCloud(sm["map_xyz"], sm["map_nrm"])
+    rng = np.random.default_rng(5)
+    scan = np.ascontiguousarray(np.tile(sm["scan"], (14, 1)) + rng.normal(0, 0.01, (14 * len(sm["scan"]), 3)).astype(np.float32))
+    guess = lom.Pose3D((0.05, -0.02, 0.0), scenes.angle_axis_q(0.01, (0, 0, 1)))
+    m = lom.CloudMatcher()
+    want = m.align(g, scan, guess)
+    want_stats = dict(m.stats)
+    assert want_stats["host_fallback"] == 0
+    for part in ((0, 6), (3, 6), (5, 6), (1, 5), (4, 7), (2, 3)):
+        cx = lom.ScanContext(g, partition=part)
+        for _ in range(3):
+            p = m.align(cx, scan, guess)
+            assert m.stats["host_fallback"] == 0, part
+            assert p.translation.tobytes() == want.translation.tobytes() and p.rotation.tobytes() == want.rotation.tobytes(), part
+            for k in _keys("outer_iterations", "lm_iterations", "evaluations", "queries", "valid_last"):
+                assert m.stats[k] == want_stats[k], (part, k)
+        cx.close()
+
+
 def test_partitioned_contexts_run_side_by_side_with_the_same_bits(lom):
     """lom_scan_create_on_partition: k contexts on k disjoint slices of the compute units (a CU mask on each context's
     stream).  Four threads, many aligns each, all at once: every result carries the bits of the same align issued alone
