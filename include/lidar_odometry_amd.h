@@ -345,7 +345,8 @@ int lom_map_set_option(lom_map *m, int option, int64_t value);
  * in-kernel scan gave up (such a call changes nothing; see csrc/grid_scan.hpp) */
 enum { LOM_COUNTER_GRID_REDOS = 0,
        LOM_COUNTER_CLEANUPS_BEHIND_ALIGN = 1, /* radius cleanups that took the scan enqueued behind an align */
-       LOM_COUNTER_FRAMES_SENT_AHEAD = 2      /* lom_odometry only: frames found in pinned memory already (staged during the previous frame's align) */ };
+       LOM_COUNTER_FRAMES_SENT_AHEAD = 2,     /* lom_odometry only: frames found in pinned memory already (staged during the previous frame's align) */
+       LOM_COUNTER_EMPTY_SLABS = 3            /* slabs whose voxel a radius cleanup erased in place and that are not closed yet */ };
 int64_t lom_map_debug_counter(const lom_map *m, int which);
 
 /* make the handle's stream wait for a hipEvent_t recorded elsewhere */

@@ -138,6 +138,7 @@ OPT_TEST_GRID_GIVE_UP_MATCHING_DS, OPT_TEST_GRID_GIVE_UP_UPDATE_DS, OPT_TEST_GRI
 COUNTER_GRID_REDOS = 0
 COUNTER_CLEANUPS_BEHIND_ALIGN = 1
 COUNTER_FRAMES_SENT_AHEAD = 2
+COUNTER_EMPTY_SLABS = 3
 
 _lib = None
 

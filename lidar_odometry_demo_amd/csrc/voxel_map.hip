@@ -2148,6 +2148,7 @@ int64_t lom_map_debug_counter(const lom_map *m, int which)
     if (!m) return LOM_ERR_ARG;
     if (which == LOM_COUNTER_GRID_REDOS) return (int64_t)m->grid_redos;
     if (which == LOM_COUNTER_CLEANUPS_BEHIND_ALIGN) return (int64_t)m->cleanups_taken;
+    if (which == LOM_COUNTER_EMPTY_SLABS) return (int64_t)m->n_dead;
     return LOM_ERR_ARG;
 }
 

@@ -408,13 +408,14 @@ def test_radius_cleanup_leaves_holes_until_they_are_a_quarter(lom, oracle, monke
     og.addCloud(xyz, nrm)
     rng = np.random.default_rng(77)
     q = np.ascontiguousarray(xyz[rng.choice(len(xyz), 3000, replace=False)] + np.float32(0.02))
-    sizes = []
+    sizes, holes = [], []
     for step in range(14):
         centre = np.array([-12.0 + 2.0 * step, 3.0 * np.sin(step), 0.0], np.float32)
         g.radiusCleanup(centre, 38.0)
         og.radiusCleanup(centre, 38.0)
         assert g.size() == og.size(), step
         sizes.append(g.size())
+        holes.append(g.debugCounter(lom.capi.COUNTER_EMPTY_SLABS))
         # part of the original cloud comes back: erased voxels are created anew, kept ones take what they have room for
         sel = rng.choice(len(xyz), 6000, replace=False)
         sel.sort()
@@ -425,6 +426,10 @@ def test_radius_cleanup_leaves_holes_until_they_are_a_quarter(lom, oracle, monke
             _assert_same_map(g, og)
             _assert_same_pairs(g.findMatchingPairs(q, lom.Pose3D(), 0.3), og.findMatchingPairs(q, oracle.Pose3D(), 0.3))
     assert len(set(sizes)) > 5, "the walk was meant to erase voxels at every step"
+    if dense:
+        assert max(holes) == 0
+    else:  # holes pile up, are closed once they are a quarter of the slabs, pile up again
+        assert max(holes) > 0 and any(b < a for a, b in zip(holes, holes[1:])), holes
     m, om = lom.CloudMatcher(), oracle.CloudMatcher()
     guess = ((0.05, -0.02, 0.0), scenes.angle_axis_q(0.01, (0, 0, 1)))
     p, op = m.align(g, sm["scan"], lom.Pose3D(*guess)), om.align(og, sm["scan"], oracle.Pose3D(*guess))
