@@ -2490,7 +2490,6 @@ int lom_map_radius_cleanup(lom_map *m, const float center[3], float radius)
         return LOM_OK;
     }
     // stable compaction into the second (persistent) set of slab arrays, swap, rebuild the table
-    m->n_dead = 0;
     if (m->alt_cap != m->slab_cap) {
         Slabs stale{m->alt_key, m->alt_count, m->alt_pts, m->alt_nrm};
         LOM_HIP(m, hipStreamSynchronize(m->stream));
@@ -2518,6 +2517,7 @@ int lom_map_radius_cleanup(lom_map *m, const float center[3], float radius)
     std::swap(m->d_nrm, m->alt_nrm);
     m->n_vox = n_keep;
     m->n_vox_ub = n_keep;
+    m->n_dead = 0;  // (the holes are closed)
     const MapView v = view_of(m);
     hipLaunchKernelGGL(k_table_init, dim3(blocks_for(m->cap)), dim3(kThreads), 0, m->stream, m->d_table, m->cap);
     if (n_keep) {
