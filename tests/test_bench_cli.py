@@ -36,6 +36,17 @@ def test_self_launch_reports_failing_ranks_and_leaves_nothing_behind():
     assert "failed; ending the others" in err or "still running" in err
 
 
+def test_event_sampling_of_short_and_long_blocks():
+    """bench.event_period: a step that carries HIP events takes ~40 % longer, so a short block (the driver's 20 steps) carries
+    them on its first step only and a long one on every 32nd."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    assert bench.event_period(20) == 20 and bench.event_period(5) == 5 and bench.event_period(1) == 1
+    assert bench.event_period(95) == 95 and bench.event_period(96) == 32 and bench.event_period(200) == 32
+    assert bench.event_period(0) == 1
+
+
 @pytest.mark.gpu
 def test_plain_command_with_two_ranks_prints_one_line():
     """`python bench.py --gpus 2 --steps 5`, nothing else: two fresh rank processes (here both on the one GPU of the
