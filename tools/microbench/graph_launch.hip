@@ -16,6 +16,41 @@ __global__ void k_small(float *p, unsigned n, Args a, unsigned seq, const unsign
     if (i < n) p[i] = p[i] * a.r[i % 12] + (float)seq + (words ? (float)words[0] : 0.f) + (q ? q[i] : 0.f) + (float)stride;
 }
 
+// the same 22 values as 22 kernel arguments and as one struct argument: what a launch costs the host per argument
+struct Many {
+    float *a0;
+    unsigned a1;
+    float *a2;
+    const unsigned *a3;
+    unsigned a4, a5, a6, a7;
+    const char *a8, *a9;
+    size_t a10;
+    unsigned a11, a12;
+    float *a13, *a14;
+    unsigned *a15, *a16;
+    unsigned a17;
+    const unsigned *a18;
+    unsigned *a19, *a20;
+    float a21;
+};
+__global__ void k_many(float *a0, unsigned a1, float *a2, const unsigned *a3, unsigned a4, unsigned a5, unsigned a6, unsigned a7,
+                       const char *a8, const char *a9, size_t a10, unsigned a11, unsigned a12, float *a13, float *a14, unsigned *a15,
+                       unsigned *a16, unsigned a17, const unsigned *a18, unsigned *a19, unsigned *a20, float a21)
+{
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < a1) a0[i] += a21 + (float)(a4 + a5 + a6 + a7 + a11 + a12 + a17) + (float)a10 + (a3 ? (float)a3[0] : 0.f) +
+                         (float)((size_t)a2 + (size_t)a8 + (size_t)a9 + (size_t)a13 + (size_t)a14 + (size_t)a15 + (size_t)a16 +
+                                 (size_t)a18 + (size_t)a19 + (size_t)a20 == 1);
+}
+__global__ void k_one(Many m)
+{
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m.a1) m.a0[i] += m.a21 + (float)(m.a4 + m.a5 + m.a6 + m.a7 + m.a11 + m.a12 + m.a17) + (float)m.a10 +
+                             (m.a3 ? (float)m.a3[0] : 0.f) +
+                             (float)((size_t)m.a2 + (size_t)m.a8 + (size_t)m.a9 + (size_t)m.a13 + (size_t)m.a14 + (size_t)m.a15 +
+                                     (size_t)m.a16 + (size_t)m.a18 + (size_t)m.a19 + (size_t)m.a20 == 1);
+}
+
 #define CK(x)                                                                     \
     do {                                                                          \
         hipError_t e_ = (x);                                                      \
@@ -114,6 +149,32 @@ int main()
     CK(hipEventRecord(e1, s));
     CK(hipEventSynchronize(e1));
     CK(hipEventElapsedTime(&ms_graph, e0, e1));
+    {   // 22 arguments against one struct
+        Many mm{};
+        mm.a0 = d;
+        mm.a1 = n;
+        mm.a3 = w;
+        double t22 = 0, t1s = 0;
+        for (int it = 0; it < kIters + 100; it++) {
+            const double t0 = now_us();
+            for (int k = 0; k < kNodes; k++)
+                hipLaunchKernelGGL(k_many, dim3((n + 255) / 256), dim3(256), 0, s, mm.a0, mm.a1, mm.a2, mm.a3, mm.a4, mm.a5, mm.a6, mm.a7,
+                                   mm.a8, mm.a9, mm.a10, mm.a11, mm.a12, mm.a13, mm.a14, mm.a15, mm.a16, mm.a17, mm.a18, mm.a19,
+                                   mm.a20, mm.a21);
+            const double t1 = now_us();
+            CK(hipStreamSynchronize(s));
+            const double t2 = now_us();
+            for (int k = 0; k < kNodes; k++) hipLaunchKernelGGL(k_one, dim3((n + 255) / 256), dim3(256), 0, s, mm);
+            const double t3 = now_us();
+            CK(hipStreamSynchronize(s));
+            if (it >= 100) {
+                t22 += t1 - t0;
+                t1s += t3 - t2;
+            }
+        }
+        std::printf("host time per launch: 22 arguments %.2f us, the same values as one struct argument %.2f us\n", t22 / kIters / kNodes,
+                    t1s / kIters / kNodes);
+    }
     std::printf("six small dependent kernels, host time per chain: direct launches %.2f us (%.2f each); graph: set params %.2f us + launch %.2f us; "
                 "graph launch alone %.2f us\n",
                 t_direct / kIters, t_direct / kIters / kNodes, t_set / kIters, t_graph / kIters, t_plain / kIters);
